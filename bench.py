@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the NSF / NPE hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`
+prints ONE JSON line on rank 0.  A "step" is one pass of the hot path over one
+batch of 65 536 synthetic linear-Gaussian (theta, x) pairs per GPU (weak
+scaling): in `train` mode one NPE training step (fused loss fwd+bwd, gradient
+all-reduce over RCCL for N>1, fused clip+Adam), in `log_prob` mode one batched
+NSF log_prob evaluation.  Inputs are resident in HBM before the timed region.
+
+Workload = BASELINE.json configs[1]: NPE + NSF, theta-dim 10, x-dim 10,
+batch 65 536, sbi's default NSF hyper-parameters (98 025 parameters).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D = C = 10
+BATCH = 65536
+F_EVAL = 191_000.0          # dense FLOP per log_prob eval
+F_TRAIN = 3 * F_EVAL        # fwd + 2x bwd per training pair (recompute not counted)
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def make_data(n, device, seed=0):
+    """10-D linear-Gaussian task of tests/mini_sbibm/gaussian_linear.py:30-32,101-123:
+    prior N(0, 0.1 I), x = theta + sqrt(0.1) eps."""
+    g = torch.Generator().manual_seed(seed)
+    theta = torch.randn(n, D, generator=g) * (0.1**0.5)
+    x = theta + (0.1**0.5) * torch.randn(n, C, generator=g)
+    return theta.to(device), x.to(device)
+
+
+def build_estimator(theta, x, device):
+    from sbi_amd.neural_nets.net_builders.flow import build_nsf
+
+    torch.manual_seed(1)
+    est = build_nsf(theta.cpu(), x.cpu())
+    return est.to(device)
+
+
+def cpu_baseline(mode, budget_s=12.0):
+    """Oracle (= op-for-op restatement of what sbi+nflows execute) timed on host cores."""
+    from oracle.nsf_oracle import NSFOracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    theta, x = make_data(BATCH, "cpu")
+    torch.manual_seed(1)
+    oracle = NSFOracle(theta, x)
+    n = 16384
+    th, xx = theta[:n], x[:n]
+    if mode == "log_prob":
+        with torch.no_grad():
+            oracle.log_prob(th, xx)
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s or reps < 2:
+                oracle.log_prob(th, xx)
+                reps += 1
+            dt = time.perf_counter() - t0
+        return {"value": n * reps / dt, "unit": "log_prob evals/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x {n}-row oracle log_prob calls ({dt:.1f} s), torch {torch.__version__} CPU fp32"}
+    opt = torch.optim.Adam(oracle.parameters(), lr=5e-4)
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s or reps < 2:
+        opt.zero_grad()
+        loss = oracle.loss(th, xx).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 5.0)
+        opt.step()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * reps / dt, "unit": "train pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {n}-row oracle train steps, pre-batched tensors ({dt:.1f} s), "
+                      f"torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["train", "log_prob"], default=os.environ.get("SBI_AMD_BENCH_MODE", "train"))
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    B = args.batch
+    theta, x = make_data(B, device, seed=rank)     # per-GPU batch, weak scaling
+    est = build_estimator(*make_data(B, "cpu", seed=0), device)
+    if distributed:
+        dist.broadcast(est.net.flat_params.data, src=0)
+
+    if args.mode == "train":
+        from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+        stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+
+        def step():
+            stepper.step(theta, x)
+    else:
+        def step():
+            with torch.no_grad():
+                est.log_prob(theta, x)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall], device=device, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    if rank == 0:
+        units = B * world * args.steps
+        value = units / wall
+        flop_per_unit = F_TRAIN if args.mode == "train" else F_EVAL
+        # dominant kernel(s): per-launch duration measured with HIP events on the launch stream
+        achieved = flop_per_unit * B * args.steps / (dev_ms * 1e-3) / 1e12
+        out = {
+            "metric": "NPE train (theta,x)-pairs/sec" if args.mode == "train" else "NSF log_prob evals/sec",
+            "value": value,
+            "unit": "pairs/s" if args.mode == "train" else "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NPE+NSF theta-dim {D}, x-dim {C}, batch {B}/GPU, linear-Gaussian, "
+                                   f"mode={args.mode}", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "device_ms_per_step": dev_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.mode)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

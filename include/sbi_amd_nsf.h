@@ -1,0 +1,117 @@
+/*
+ * sbi_amd_nsf.h -- C ABI of the MI355X (gfx950) NSF / NPE hot-path library
+ * (libsbi_amd_nsf.so, built from sbi_amd/csrc/ by hipcc).
+ *
+ * The reference (sbi-dev/sbi) is pure Python and has NO FFI for this path; the
+ * arithmetic it executes lives in nflows 0.14 behind
+ *     sbi/neural_nets/estimators/nflows_flow.py:77-151  (NFlowsFlow.log_prob /
+ *     loss / sample / inverse_transform)
+ * and the optimiser step in
+ *     sbi/inference/trainers/base.py:1150-1193           (_train_epoch).
+ * Each entry point below replaces the eager-op sequence behind ONE of those
+ * Python calls; INTEGRATION.md shows the ctypes stub a maintainer would add to
+ * nflows_flow.py to bind them.
+ *
+ * Conventions
+ *   - all pointers except `cfg` and `*_host` are DEVICE pointers (HBM), fp32,
+ *     row-major, contiguous; `stream` is a hipStream_t (NULL = default stream)
+ *   - every call is asynchronous on `stream`; nothing allocates or syncs
+ *   - return value: 0 = launched; <0 = SBI_AMD_E_* (nothing launched);
+ *                   >0 = hipError_t from the launch
+ *   - `params` is ONE flat fp32 buffer in nflows' natural parameter order
+ *     (see sbi_amd_nsf_param_count / DESIGN.md "flat parameter layout"):
+ *     per transform t = 0..T-1:
+ *        initial_layer.weight (H, d_id+C), .bias (H)
+ *        per block b: context_layer.weight (H,C), .bias (H),
+ *                     linear_layers.0.weight (H,H), .bias (H),
+ *                     linear_layers.1.weight (H,H), .bias (H)
+ *        final_layer.weight (d_tr*(3K-1), H), .bias (d_tr*(3K-1))
+ *        LULinear: lower_entries, upper_entries (D(D-1)/2 each),
+ *                  unconstrained_upper_diag (D), bias (D)
+ *   - `zstats` is 2*D + 2*C floats: theta shift (D), theta scale (D)
+ *     [PointwiseAffineTransform buffers, sbiutils.py:226-247], x mean (C),
+ *     x std (C) [Standardize buffers, sbiutils.py:418-428]; no z-scoring =
+ *     shift 0 / scale 1 / mean 0 / std 1
+ *   - condition broadcasting: `x` has `x_rows` rows; row n of the batch uses
+ *     x[n % x_rows] (x_rows == n: paired; x_rows == 1: single x_o; x_rows == B
+ *     with n == S*B: NFlowsFlow's (S,B) flattening, nflows_flow.py:91-93)
+ */
+#ifndef SBI_AMD_NSF_H
+#define SBI_AMD_NSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBI_AMD_E_UNSUPPORTED (-1) /* config outside what the kernels are instantiated for */
+#define SBI_AMD_E_BADARG (-2)
+#define SBI_AMD_E_LDS (-3) /* config needs more than 160 KiB LDS per workgroup */
+
+typedef struct sbi_amd_nsf_config {
+  int32_t D;          /* theta features (>= 2)                 flow.py:393  x_numel          */
+  int32_t C;          /* embedded condition features           flow.py:394  y_numel          */
+  int32_t H;          /* hidden_features (<= 64)               flow.py:343                   */
+  int32_t K;          /* num_bins (4,5,8,10,16)                flow.py:345                   */
+  int32_t T;          /* num_transforms (<= 16)                flow.py:344                   */
+  int32_t NB;         /* num_blocks of the ResidualNet (<= 4)  flow.py:349                   */
+  float tail_bound;   /* spline tail bound                     flow.py:347                   */
+  float min_bin_width, min_bin_height, min_derivative; /* nflows defaults 1e-3 (estimator_configs.py:49-51) */
+  float lu_eps;       /* LULinear eps, nflows default 1e-3 */
+} sbi_amd_nsf_config;
+
+/* Number of floats in the flat parameter buffer for `cfg` (98 025 for the
+ * default D=C=10,H=50,K=10,T=5,NB=2); <0 on unsupported config. */
+int64_t sbi_amd_nsf_param_count(const sbi_amd_nsf_config* cfg);
+
+/* Float offset of transform t's block inside the flat buffer, and of its
+ * LULinear sub-block (host helper for state_dict <-> flat conversion). */
+int64_t sbi_amd_nsf_layer_offset(const sbi_amd_nsf_config* cfg, int32_t t);
+int64_t sbi_amd_nsf_lu_offset(const sbi_amd_nsf_config* cfg, int32_t t);
+
+/* log p(theta | x) for n rows: replaces nflows Flow.log_prob behind
+ * NFlowsFlow.log_prob (nflows_flow.py:77-97).  noise_out (n,D) is optional
+ * (NULL) and receives transform(theta) = NFlowsFlow.inverse_transform
+ * (nflows_flow.py:43-75). */
+int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+                         const float* theta, const float* x, int64_t n, int64_t x_rows,
+                         float* logp_out, float* noise_out, void* stream);
+
+/* theta = transform^{-1}(noise | x) for n rows: the arithmetic of
+ * Flow._sample behind NFlowsFlow.sample (nflows_flow.py:111-128) for GIVEN
+ * base noise (the caller draws it with torch's generator, see DESIGN.md RNG).
+ * logabsdet_out (n) optional: log|det d theta/d noise|. */
+int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+                       const float* noise, const float* x, int64_t n, int64_t x_rows,
+                       float* theta_out, float* logabsdet_out, void* stream);
+
+/* Training pass for one minibatch: per-row loss = -log p (NFlowsFlow.loss,
+ * nflows_flow.py:99-109) and d(sum_n w_n * loss_n)/d params accumulated into
+ * grad_out (P floats, OVERWRITTEN), w_n = row_weight[n] or `uniform_weight`
+ * when row_weight is NULL (1/B gives the gradient of the batch mean,
+ * trainers/base.py:1178-1181).  grad_theta_out (n,D) optional: d loss_n /
+ * d theta_n (needed by MAP / gradient_ascent, base_posterior.py:216-323).
+ * `workspace` must hold sbi_amd_nsf_train_workspace_floats(cfg, n) floats. */
+int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n);
+int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+                             const float* theta, const float* x, int64_t n, int64_t x_rows,
+                             const float* row_weight, float uniform_weight, float* loss_out,
+                             float* grad_out, float* grad_theta_out, float* workspace, void* stream);
+
+/* Fused global-norm clip + Adam on the flat buffer: replaces
+ * clip_grad_norm_(max_norm) + torch.optim.Adam.step (trainers/base.py:1181-1187,
+ * :1097).  `step` is the 1-based step count; max_norm <= 0 disables clipping.
+ * scratch: >= 130 floats (scratch[0] receives the pre-clip gradient norm). */
+int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                           int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
+                           float max_norm, float* scratch, void* stream);
+
+/* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
+int sbi_amd_nsf_abi_version(void);
+const char* sbi_amd_nsf_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBI_AMD_NSF_H */

@@ -1,0 +1,52 @@
+"""In-tree build of libsbi_amd_nsf.so (hipcc, gfx950 only).
+
+Used by ``__graft_entry__.build()`` and by ``sbi_amd._lib`` when the shared
+library is missing.  hipcc cross-compiles without a GPU present.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = Path(__file__).resolve().parent / "libsbi_amd_nsf.so"
+SOURCES = ["nsf_plan.cpp", "nsf_flow.hip", "nsf_train.hip", "adam.hip"]
+HEADERS = ["nsf_plan.h", "nsf_device.h", "../../include/sbi_amd_nsf.h"]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the sbi_amd HIP extension cannot be built")
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    files = [CSRC / s for s in SOURCES] + [CSRC / h for h in HEADERS]
+    return any(f.exists() and f.stat().st_mtime > t for f in files)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB_PATH
+    srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
+    cmd = [
+        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-Wno-unused-result", *srcs, "-o", str(LIB_PATH),
+    ]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

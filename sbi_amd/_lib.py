@@ -1,0 +1,127 @@
+"""ctypes binding of the C ABI declared in include/sbi_amd_nsf.h.
+
+There is no CPU fallback: if the shared library cannot be loaded, or a call is
+made with tensors that are not on a ROCm device, the call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+from sbi_amd import _build
+
+_LIB: Optional[ctypes.CDLL] = None
+
+E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
+_ERRORS = {
+    E_UNSUPPORTED: "configuration not supported by the HIP kernels "
+    "(need 2<=D<=64, H<=64, num_bins in {4,5,8,10,16}, num_transforms<=16, num_blocks<=4)",
+    E_BADARG: "bad argument",
+    E_LDS: "configuration needs more than 160 KiB of LDS per workgroup",
+}
+
+
+class NSFConfigC(Structure):
+    """Mirror of ``struct sbi_amd_nsf_config``."""
+
+    _fields_ = [
+        ("D", c_int32), ("C", c_int32), ("H", c_int32), ("K", c_int32), ("T", c_int32), ("NB", c_int32),
+        ("tail_bound", c_float), ("min_bin_width", c_float), ("min_bin_height", c_float),
+        ("min_derivative", c_float), ("lu_eps", c_float),
+    ]
+
+
+_SIGNATURES = {
+    "sbi_amd_nsf_param_count": (c_int64, [POINTER(NSFConfigC)]),
+    "sbi_amd_nsf_layer_offset": (c_int64, [POINTER(NSFConfigC), c_int32]),
+    "sbi_amd_nsf_lu_offset": (c_int64, [POINTER(NSFConfigC), c_int32]),
+    "sbi_amd_nsf_log_prob": (
+        c_int,
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "sbi_amd_nsf_sample": (
+        c_int,
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "sbi_amd_nsf_train_workspace_floats": (c_int64, [POINTER(NSFConfigC), c_int64]),
+    "sbi_amd_nsf_loss_fwd_bwd": (
+        c_int,
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_adam_clip_step": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
+         c_void_p, c_void_p],
+    ),
+    "sbi_amd_nsf_abi_version": (c_int, []),
+    "sbi_amd_nsf_arch": (c_char_p, []),
+}
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load libsbi_amd_nsf.so (building it in-tree with hipcc if needed)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if not path.exists():
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _build.build()
+    lib = ctypes.CDLL(str(path))
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"sbi_amd: {what}: {_ERRORS.get(rc, rc)}")
+    raise RuntimeError(f"sbi_amd: {what}: HIP error {rc}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on one ROCm device, fp32, contiguous."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "sbi_amd: the NSF hot path runs only on a ROCm device (MI355X); got a "
+                f"{t.device} tensor. There is deliberately no CPU fallback."
+            )
+        if t.dtype != torch.float32:
+            raise TypeError(f"sbi_amd: expected float32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError("sbi_amd: expected contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"sbi_amd: tensors on different devices ({dev} vs {t.device})")
+    assert dev is not None
+    return dev
+
+
+def current_stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream

@@ -1,0 +1,80 @@
+// adam.hip -- fused global-norm gradient clip + Adam step on the flat fp32
+// parameter buffer (gfx950).  Replaces, for the NSF hot path,
+//   torch.nn.utils.clip_grad_norm_(params, max_norm)   trainers/base.py:1182-1186
+//   torch.optim.Adam.step()                            trainers/base.py:1097, 1187
+// (Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
+// Two launches, no atomics, deterministic: (1) per-workgroup partial sums of
+// g^2 -> scratch[1..nwg]; (2) every workgroup re-reduces the <=ADAM_NWG partials
+// in a fixed order, derives the clip coefficient and updates its slice.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/sbi_amd_nsf.h"
+
+#define ADAM_NWG 128
+#define ADAM_THREADS 256
+
+__global__ void __launch_bounds__(ADAM_THREADS)
+grad_sqnorm_partials(const float* __restrict__ g, long long count, float* __restrict__ scratch) {
+  __shared__ float red[ADAM_THREADS / 64];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < count;
+       i += (long long)gridDim.x * ADAM_THREADS) {
+    float v = g[i];
+    acc += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < ADAM_THREADS / 64; ++w) s += red[w];
+    scratch[1 + blockIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(ADAM_THREADS)
+adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            long long count, float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+            float max_norm, int npart, float* __restrict__ scratch) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < npart; ++i) s += scratch[1 + i];
+    float norm = sqrtf(s);
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);   // clip_grad_norm_
+    s_coef = coef;
+    if (blockIdx.x == 0) scratch[0] = norm;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < count;
+       i += (long long)gridDim.x * ADAM_THREADS) {
+    float gi = g[i] * coef;
+    float mi = m[i];
+    mi = mi + (1.f - beta1) * (gi - mi);            // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                      int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
+                                      float max_norm, float* scratch, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !scratch || count < 0 || step < 1) return SBI_AMD_E_BADARG;
+  if (count == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int nwg = (int)((count + ADAM_THREADS * 4 - 1) / (ADAM_THREADS * 4));
+  if (nwg > ADAM_NWG) nwg = ADAM_NWG;
+  if (nwg < 1) nwg = 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(grad_sqnorm_partials, dim3(nwg), dim3(ADAM_THREADS), 0, st, grad, (long long)count, scratch);
+  hipLaunchKernelGGL(adam_update, dim3(nwg), dim3(ADAM_THREADS), 0, st, params, grad, exp_avg, exp_avg_sq,
+                     (long long)count, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, nwg, scratch);
+  return (int)hipGetLastError();
+}

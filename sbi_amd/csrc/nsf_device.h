@@ -1,0 +1,393 @@
+// nsf_device.h -- device building blocks shared by the NSF kernels (gfx950).
+//
+// Execution model (see DESIGN.md "kernel anatomy"):
+//   * one wavefront (64 lanes) owns 16 batch rows; lane = (j = lane&15 : row,
+//     g = lane>>4 : k-slot).  All dense layers of the ResidualNet conditioner
+//     run on v_mfma_f32_16x16x4_f32 with   M = output feature, N = batch row,
+//     K = input feature, so the D fragment of one layer (lane (g,j), reg r of
+//     tile mt holds feature 16*mt + 4*r + g of row j) IS the B fragment of the
+//     next layer's K-step s = 4*mt + r: activations never leave registers.
+//   * weights (A operand) are read from the LDS image staged once per coupling
+//     layer per workgroup: lane (i = lane&15, g) reads W[feat(i)][4*s + g],
+//     feat(i) = 16*mt + 4*(i&3) + (i>>2)   (the within-tile transpose that makes
+//     the D->B hand-off line up); row stride 2*odd => conflict-free ds_read_b32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nsf_plan.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Orders this wave's LDS traffic (DS ops of one wave execute in issue order; the
+// fence only stops the compiler from moving them across phase boundaries).
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct LaneId {
+  int lane, j, g, iperm;
+};
+__device__ __forceinline__ LaneId make_lane() {
+  LaneId L;
+  L.lane = threadIdx.x & 63;
+  L.j = L.lane & 15;
+  L.g = L.lane >> 4;
+  L.iperm = 4 * (L.j & 3) + (L.j >> 2);
+  return L;
+}
+
+// ---- weight staging: flat natural layout (global) -> MFMA A-operand image (LDS)
+__device__ __forceinline__ void stage_linear(float* __restrict__ lds, const float* __restrict__ gl,
+                                             const LinDesc& L, int bias_pad, int bias_group, int bias_group_pad,
+                                             int tid, int nthreads) {
+  const int total = (L.out + 1) * L.ldk;
+  for (int idx = tid; idx < total; idx += nthreads) {
+    int r = idx / L.ldk;
+    int c = idx - r * L.ldk;
+    float v = 0.f;
+    if (r < L.out && c < L.in) v = gl[L.g_w + r * L.in + c];
+    lds[L.l_w + idx] = v;
+  }
+  // bias: groups of `bias_group` real entries padded to `bias_group_pad`
+  for (int idx = tid; idx < bias_pad; idx += nthreads) {
+    int grp = idx / bias_group_pad;
+    int p = idx - grp * bias_group_pad;
+    int src = grp * bias_group + p;
+    float v = 0.f;
+    if (p < bias_group && src < L.out) v = gl[L.g_b + src];
+    lds[L.l_b + idx] = v;
+  }
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ void stage_lu(float* __restrict__ lds, const float* __restrict__ gl,
+                                         const ShapeDesc& S, int D, float eps, int tid, int nthreads) {
+  // LULinear._create_lower_upper: np.tril_indices(D,-1) / np.triu_indices(D,1) order.
+  const int ntri = D * (D - 1) / 2;
+  const float* lower = gl + S.g_lu;
+  const float* upper = lower + ntri;
+  const float* udiag = upper + ntri;
+  const float* bias = udiag + D;
+  for (int idx = tid; idx < D * D; idx += nthreads) {
+    int i = idx / D, k = idx - i * D;
+    float u = 0.f, l = 0.f;
+    if (k > i) u = upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
+    else if (k == i) { u = softplus_f(udiag[i]) + eps; l = 1.f; }
+    else l = lower[i * (i - 1) / 2 + k];
+    lds[S.l_U + idx] = u;
+    lds[S.l_L + idx] = l;
+  }
+  for (int idx = tid; idx < D; idx += nthreads) lds[S.l_lub + idx] = bias[idx];
+}
+
+__device__ __forceinline__ void stage_layer(float* __restrict__ lds, const float* __restrict__ gl,
+                                            const NsfPlan& pl, const ShapeDesc& S, int tid, int nthreads) {
+  const int hb = 16 * NSF_HT;
+  stage_linear(lds, gl, S.lin[0], hb, hb, hb, tid, nthreads);
+  for (int b = 0; b < pl.NB; ++b) {
+    stage_linear(lds, gl, S.lin[1 + 3 * b], hb, hb, hb, tid, nthreads);
+    stage_linear(lds, gl, S.lin[2 + 3 * b], hb, hb, hb, tid, nthreads);
+    stage_linear(lds, gl, S.lin[3 + 3 * b], hb, hb, hb, tid, nthreads);
+  }
+  stage_linear(lds, gl, S.lin[1 + 3 * pl.NB], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
+  stage_lu(lds, gl, S, pl.D, pl.lu_eps, tid, nthreads);
+}
+
+// ---- MFMA GEMM pieces ------------------------------------------------------
+__device__ __forceinline__ void acc_init_bias(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                              f4 (&acc)[NSF_HT]) {
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[mt][r] = lds[L.l_b + 16 * mt + 4 * r + id.g];
+  }
+}
+
+__device__ __forceinline__ void a_row_offsets(const LinDesc& L, const LaneId& id, int (&ro)[NSF_HT]) {
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt) {
+    int f = 16 * mt + id.iperm;
+    ro[mt] = L.l_w + (f < L.out ? f : L.out) * L.ldk + id.g;
+  }
+}
+
+// acc += W * B, B operand read from a per-wave LDS row buffer (conditioner input)
+__device__ __forceinline__ void gemm_blds(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                          const float* __restrict__ brow /* &buf[j*stride + coff + g] */,
+                                          f4 (&acc)[NSF_HT]) {
+  int ro[NSF_HT];
+  a_row_offsets(L, id, ro);
+  for (int s = 0; s < L.ksteps; ++s) {
+    float bv = brow[4 * s];
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(lds[ro[mt] + 4 * s], bv, acc[mt]);
+  }
+}
+
+// acc += W * B, B operand = the previous layer's D fragments (registers)
+__device__ __forceinline__ void gemm_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                          const f4 (&b)[NSF_HT], f4 (&acc)[NSF_HT]) {
+  int ro[NSF_HT];
+  a_row_offsets(L, id, ro);
+#pragma unroll
+  for (int kt = 0; kt < NSF_HT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * kt + r;
+      if (s < L.ksteps) {
+        float bv = b[kt][r];
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(lds[ro[mt] + 4 * s], bv, acc[mt]);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ResidualNet hidden stack (nflows nn/nets/resnet.py, configuration flow.py:411-419):
+// h = W0 [z_id; c] + b0;  per block: t = W2 relu(W1 relu(h) + b1) + b2; h += t * sigmoid(Wc c + bc)
+__device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds, const NsfPlan& pl,
+                                                   const ShapeDesc& S, const LaneId& id,
+                                                   const float* __restrict__ cin_row, f4 (&h)[NSF_HT]) {
+  acc_init_bias(lds, S.lin[0], id, h);
+  gemm_blds(lds, S.lin[0], id, cin_row, h);
+  for (int b = 0; b < pl.NB; ++b) {
+    f4 gate[NSF_HT], t[NSF_HT], u[NSF_HT];
+    acc_init_bias(lds, S.lin[1 + 3 * b], id, gate);
+    gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, gate);
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[mt][r] = fmaxf(h[mt][r], 0.f);
+    acc_init_bias(lds, S.lin[2 + 3 * b], id, u);
+    gemm_breg(lds, S.lin[2 + 3 * b], id, t, u);
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[mt][r] = fmaxf(u[mt][r], 0.f);
+    acc_init_bias(lds, S.lin[3 + 3 * b], id, t);
+    gemm_breg(lds, S.lin[3 + 3 * b], id, u, t);
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[mt][r] += t[mt][r] * sigmoid_f(gate[mt][r]);
+  }
+}
+
+// final_layer for the spline dims [d0, d0+DCH) -> per-wave LDS staging pst[slot][row][param]
+template <int PT>
+__device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds, float* __restrict__ pst,
+                                                  const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
+                                                  const f4 (&h)[NSF_HT], int d0) {
+  const LinDesc& L = S.lin[1 + 3 * pl.NB];
+  f4 acc[NSF_MAX_DCH][PT];
+  int ro[NSF_MAX_DCH][PT];
+#pragma unroll
+  for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
+    const int dd = d0 + sl;
+    const bool on = (sl < pl.DCH) && (dd < S.d_tr);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = 16 * pt + id.iperm;
+      ro[sl][pt] = L.l_w + ((on && p < pl.P) ? dd * pl.P + p : L.out) * L.ldk + id.g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[sl][pt][r] = on ? lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < NSF_HT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * kt + r;
+      if (s < L.ksteps) {
+        float bv = h[kt][r];
+#pragma unroll
+        for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
+          if (sl < pl.DCH && d0 + sl < S.d_tr) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
+    if (sl < pl.DCH && d0 + sl < S.d_tr) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pst[sl * pl.DS + id.j * pl.PSW + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+    }
+  }
+}
+
+// ---- rational-quadratic spline, one (row, dim) per lane ---------------------
+// Restates nflows 0.14 transforms/splines/rational_quadratic.py
+// (unconstrained_rational_quadratic_spline, tails="linear") with the constants
+// sbi passes (flow.py:425-432; estimator_configs.py:49-51).  `p` points at the
+// 3K-1 raw conditioner outputs of this (row, dim).  Forward returns logabsdet,
+// inverse returns -logabsdet (as nflows does).  Optionally exports the selected
+// bin quantities for the backward pass.
+struct SplineBin {
+  int idx;
+  float cw_i, w_i, ch_i, h_i, d_i, d_ip1, ud_i, ud_ip1;
+  float sw, sh;   // softmax denominators (after max subtraction)
+  float mw, mh;   // softmax maxima
+};
+
+template <int K, bool INV>
+__device__ __forceinline__ void rq_spline(const float* __restrict__ p, float x, const NsfPlan& pl, float& y,
+                                          float& ld, SplineBin* bin = nullptr) {
+  const float B = pl.B;
+  const bool inside = (x >= -B) && (x <= B);
+  float ew[K], eh[K];
+  float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    ew[k] = p[k] / pl.sqrt_h;       // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
+    eh[k] = p[K + k] / pl.sqrt_h;
+    mw = fmaxf(mw, ew[k]);
+    mh = fmaxf(mh, eh[k]);
+  }
+  float sw = 0.f, sh = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    ew[k] = expf(ew[k] - mw);
+    eh[k] = expf(eh[k] - mh);
+    sw += ew[k];
+    sh += eh[k];
+  }
+  // knots: cumsum -> pad -> affine to [-B,B] -> overwrite ends
+  float cw[K + 1], ch[K + 1];
+  float cumw = 0.f, cumh = 0.f;
+  cw[0] = -B;
+  ch[0] = -B;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    cumw += pl.min_w + pl.one_minus_kw * (ew[k] / sw);
+    cumh += pl.min_h + pl.one_minus_kh * (eh[k] / sh);
+    cw[k + 1] = (2.f * B) * cumw + (-B);
+    ch[k + 1] = (2.f * B) * cumh + (-B);
+  }
+  cw[K] = B;
+  ch[K] = B;
+  // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) cnt += (x >= (INV ? ch[k] : cw[k])) ? 1 : 0;
+  cnt += (x >= ((INV ? ch[K] : cw[K]) + 1e-6f)) ? 1 : 0;
+  int idx = cnt - 1;
+  idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
+  float cw_i = cw[0], cw_n = cw[1], ch_i = ch[0], ch_n = ch[1];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const bool hit = (idx == k);
+    cw_i = hit ? cw[k] : cw_i;
+    cw_n = hit ? cw[k + 1] : cw_n;
+    ch_i = hit ? ch[k] : ch_i;
+    ch_n = hit ? ch[k + 1] : ch_n;
+  }
+  const float w_i = cw_n - cw_i;
+  const float h_i = ch_n - ch_i;
+  const float ud_i = (idx == 0) ? pl.d_const : p[2 * K + idx - 1];
+  const float ud_n = (idx == K - 1) ? pl.d_const : p[2 * K + idx];
+  const float d_i = pl.min_d + softplus_f(ud_i);
+  const float d_n = pl.min_d + softplus_f(ud_n);
+  const float delta = h_i / w_i;
+  float yo, lo;
+  if (!INV) {
+    const float th = (x - cw_i) / w_i;
+    const float tt = th * (1.f - th);
+    const float num = h_i * (delta * (th * th) + d_i * tt);
+    const float den = delta + ((d_i + d_n - 2.f * delta) * tt);
+    yo = ch_i + num / den;
+    const float omt = 1.f - th;
+    const float dnum = (delta * delta) * (d_n * (th * th) + 2.f * delta * tt + d_i * (omt * omt));
+    lo = logf(dnum) - 2.f * logf(den);
+  } else {
+    const float s = d_i + d_n - 2.f * delta;
+    const float xc = x - ch_i;
+    const float a = xc * s + h_i * (delta - d_i);
+    const float b = h_i * d_i - xc * s;
+    const float c = -delta * xc;
+    const float disc = b * b - 4.f * a * c;
+    const float root = (2.f * c) / (-b - sqrtf(disc));
+    yo = root * w_i + cw_i;
+    const float tt = root * (1.f - root);
+    const float den = delta + s * tt;
+    const float omr = 1.f - root;
+    const float dnum = (delta * delta) * (d_n * (root * root) + 2.f * delta * tt + d_i * (omr * omr));
+    lo = -(logf(dnum) - 2.f * logf(den));
+  }
+  y = inside ? yo : x;
+  ld = inside ? lo : 0.f;
+  if (bin) {
+    bin->idx = inside ? idx : -1;
+    bin->cw_i = cw_i; bin->w_i = w_i; bin->ch_i = ch_i; bin->h_i = h_i;
+    bin->d_i = d_i; bin->d_ip1 = d_n; bin->ud_i = ud_i; bin->ud_ip1 = ud_n;
+    bin->sw = sw; bin->sh = sh; bin->mw = mw; bin->mh = mh;
+  }
+}
+
+// ---- LULinear on the per-wave state rows (nflows transforms/lu.py) ----------
+// forward: y = L (U z) + b           (F.linear(F.linear(x, U), L, bias))
+__device__ __forceinline__ void lu_forward(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S,
+                                           const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
+  const int D = pl.D;
+  for (int i = id.g; i < D; i += 4) {
+    float a = 0.f;
+    for (int k = i; k < D; ++k) a += lds[S.l_U + i * D + k] * zs[id.j * pl.ZW + k];
+    us[id.j * pl.ZW + i] = a;
+  }
+  wave_lds_fence();
+  for (int i = id.g; i < D; i += 4) {
+    float a = lds[S.l_lub + i];
+    for (int k = 0; k <= i; ++k) a += lds[S.l_L + i * D + k] * us[id.j * pl.ZW + k];
+    zs[id.j * pl.ZW + i] = a;
+  }
+  wave_lds_fence();
+}
+// inverse: z = U^{-1} L^{-1} (y - b) by forward/back substitution; one lane per row.
+__device__ __forceinline__ void lu_inverse(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S,
+                                           const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
+  const int D = pl.D;
+  if (id.g == 0) {
+    float* z = zs + id.j * pl.ZW;
+    float* u = us + id.j * pl.ZW;
+    for (int i = 0; i < D; ++i) {
+      float a = z[i] - lds[S.l_lub + i];
+      for (int k = 0; k < i; ++k) a -= lds[S.l_L + i * D + k] * u[k];
+      u[i] = a;
+    }
+    for (int i = D - 1; i >= 0; --i) {
+      float a = u[i];
+      for (int k = i + 1; k < D; ++k) a -= lds[S.l_U + i * D + k] * z[k];
+      z[i] = a / lds[S.l_U + i * D + i];
+    }
+  }
+  wave_lds_fence();
+}
+__device__ __forceinline__ float lu_logabsdet(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S) {
+  float a = 0.f;
+  for (int i = 0; i < pl.D; ++i) a += logf(lds[S.l_U + i * pl.D + i]);
+  return a;
+}
+
+// conditioner input rows: cin[j] = [ z[identity dims] ; standardized context ; 0 pad ]
+__device__ __forceinline__ void build_cin(const NsfPlan& pl, const ShapeDesc& S, int parity, const LaneId& id,
+                                          const float* __restrict__ zs, const float* __restrict__ cs,
+                                          float* __restrict__ cin) {
+  for (int k = id.g; k < pl.CINW; k += 4) {
+    float v = 0.f;
+    if (k < S.d_id) v = zs[id.j * pl.ZW + 2 * k + (1 - parity)];
+    else if (k < S.in0) v = cs[id.j * pl.CW + (k - S.d_id)];
+    cin[id.j * pl.CINW + k] = v;
+  }
+  wave_lds_fence();
+}

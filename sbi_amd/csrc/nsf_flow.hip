@@ -1,0 +1,177 @@
+// nsf_flow.hip -- whole-flow fused NSF kernels for gfx950 (MI355X):
+//   nsf_flow_kernel<K, false>: theta, x -> log p(theta|x) [+ noise]   (Flow.log_prob)
+//   nsf_flow_kernel<K, true >: noise, x -> theta [+ logabsdet]        (Flow._sample's inverse)
+// One launch covers z-scoring, all T x (RQ-spline coupling + LULinear) and the
+// base density; per coupling layer a workgroup stages the layer's weights into
+// LDS once and every wave pushes its 16 rows through the conditioner on MFMA.
+// Reference path replaced: nflows_flow.py:77-128 -> nflows Flow/CompositeTransform
+// (SURVEY.md 3.2, Appendix A).
+#include <hip/hip_runtime.h>
+#include "nsf_device.h"
+
+template <int K, bool INV>
+__global__ void __launch_bounds__(512)
+nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ params, const float* __restrict__ zstats,
+                const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
+                float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash) {
+  constexpr int PT = (3 * K - 1 + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int wave = tid >> 6;
+  const int nw = nthreads >> 6;
+  const LaneId id = make_lane();
+  float* sc = lds + pl.lds_w_floats + wave * pl.sc_total;
+  float* zs = sc + pl.sc_zs;
+  float* us = sc + pl.sc_us;
+  float* cs = sc + pl.sc_cs;
+  float* cin = sc + pl.sc_cin;
+  float* pst = sc + pl.sc_pst;
+
+  const long long row = (long long)blockIdx.x * (16 * nw) + 16 * wave + id.j;
+  const bool valid = row < n;
+  const int D = pl.D, C = pl.C;
+  const float* th_shift = zstats;
+  const float* th_scale = zstats + D;
+  const float* x_mean = zstats + 2 * D;
+  const float* x_std = x_mean + C;
+
+  float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
+  // ---- load + z-score (PointwiseAffineTransform fwd / Standardize) ----
+  {
+    const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
+    for (int d = id.g; d < D; d += 4) {
+      float v = valid ? in[row * D + d] : 0.f;
+      if (!INV) {
+        v = v * th_scale[d] + th_shift[d];
+        ld_acc += logf(fabsf(th_scale[d]));
+      }
+      zs[id.j * pl.ZW + d] = v;
+    }
+    for (int c = id.g; c < C; c += 4) {
+      float v = valid ? x[xr * C + c] : 0.f;
+      cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
+    }
+  }
+  wave_lds_fence();
+
+  for (int li = 0; li < pl.T; ++li) {
+    const int t = INV ? (pl.T - 1 - li) : li;
+    const int par = t & 1;
+    const ShapeDesc& S = pl.shape[par];
+    __syncthreads();   // every wave is done with the previous layer's weights
+    stage_layer(lds, params + pl.g_layer[t], pl, S, tid, nthreads);
+    __syncthreads();
+
+    if (!INV && z_stash) {
+      for (int d = id.g; d < D; d += 4)
+        if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
+    }
+    if (INV) {
+      lu_inverse(lds, pl, S, id, zs, us);
+      if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
+    }
+    build_cin(pl, S, par, id, zs, cs, cin);
+
+    f4 h[NSF_HT];
+    conditioner_hidden(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
+
+    for (int d0 = 0; d0 < S.d_tr; d0 += pl.DCH) {
+      final_layer_chunk<PT>(lds, pst, pl, S, id, h, d0);
+      wave_lds_fence();
+      const int dd = d0 + id.g;
+      if (id.g < pl.DCH && dd < S.d_tr) {
+        const int zi = id.j * pl.ZW + 2 * dd + par;
+        float y, ld;
+        rq_spline<K, INV>(pst + id.g * pl.DS + id.j * pl.PSW, zs[zi], pl, y, ld);
+        zs[zi] = y;
+        ld_acc += ld;
+      }
+      wave_lds_fence();
+    }
+    if (!INV) {
+      lu_forward(lds, pl, S, id, zs, us);
+      if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
+    }
+  }
+
+  // ---- epilogue ----
+  if (!INV) {
+    float part = 0.f;
+    for (int d = id.g; d < D; d += 4) {
+      float z = zs[id.j * pl.ZW + d];
+      part += z * z;
+      if (out_aux && valid) out_aux[row * D + d] = z;
+    }
+    float v = -0.5f * part + ld_acc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (id.g == 0 && valid) out_main[row] = v - pl.log_z;
+  } else {
+    for (int d = id.g; d < D; d += 4) {
+      float z = zs[id.j * pl.ZW + d];
+      ld_acc -= logf(fabsf(th_scale[d]));
+      if (valid) out_main[row * D + d] = (z - th_shift[d]) / th_scale[d];
+    }
+    float v = ld_acc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (out_aux && id.g == 0 && valid) out_aux[row] = v;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+template <int K, bool INV>
+static int launch_flow(const NsfPlan& pl, int nw, const float* params, const float* zstats, const float* in,
+                       const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                       float* z_stash, hipStream_t stream) {
+  const int64_t lds_bytes = nsf_lds_bytes(pl, nw);
+  auto kern = nsf_flow_kernel<K, INV>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  const int64_t rows_per_wg = 16 * nw;
+  const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, params, zstats, in,
+                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash);
+  return (int)hipGetLastError();
+}
+
+template <bool INV>
+static int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats, const float* in,
+                         const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                         float* z_stash, void* stream) {
+  if (!cfg || !params || !zstats || !in || !x || !out_main || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
+  if (n == 0) return 0;
+  NsfPlan pl;
+  int nw = 0;
+  int rc = nsf_plan_for_rows(cfg, n, &pl, &nw);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  switch (cfg->K) {
+    case 4: return launch_flow<4, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 5: return launch_flow<5, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 8: return launch_flow<8, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 10: return launch_flow<10, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 16: return launch_flow<16, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    default: return SBI_AMD_E_UNSUPPORTED;
+  }
+}
+
+// used by the training path (nsf_train.hip): forward with per-layer state stash
+int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats, const float* theta,
+                       const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
+                       float* z_stash, void* stream) {
+  return dispatch_flow<false>(cfg, params, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, stream);
+}
+
+extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+                                    const float* theta, const float* x, int64_t n, int64_t x_rows,
+                                    float* logp_out, float* noise_out, void* stream) {
+  return dispatch_flow<false>(cfg, params, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, stream);
+}
+
+extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+                                  const float* noise, const float* x, int64_t n, int64_t x_rows,
+                                  float* theta_out, float* logabsdet_out, void* stream) {
+  return dispatch_flow<true>(cfg, params, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, stream);
+}

@@ -1,0 +1,154 @@
+// nsf_plan.cpp -- host-side plan builder (see nsf_plan.h).
+#include "nsf_plan.h"
+
+#include <math.h>
+#include <string.h>
+
+static int two_odd_at_least(int v) {   // smallest 2*odd >= v
+  int x = (v + 1) / 2;                 // ceil(v/2)
+  if ((x & 1) == 0) x += 1;
+  return 2 * x;
+}
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int supported_bins(int K) { return K == 4 || K == 5 || K == 8 || K == 10 || K == 16; }
+
+static int check_cfg(const sbi_amd_nsf_config* c) {
+  if (!c) return SBI_AMD_E_BADARG;
+  if (c->D < 2 || c->C < 1 || c->H < 1 || c->T < 1 || c->NB < 0) return SBI_AMD_E_BADARG;
+  if (c->H > 16 * NSF_HT || c->T > NSF_MAX_T || c->NB > NSF_MAX_NB || !supported_bins(c->K))
+    return SBI_AMD_E_UNSUPPORTED;
+  if (c->D > 64 || c->C > 256) return SBI_AMD_E_UNSUPPORTED;
+  if (c->min_bin_width * c->K > 1.0f || c->min_bin_height * c->K > 1.0f) return SBI_AMD_E_BADARG;
+  return 0;
+}
+
+static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad) {
+  L->out = out;
+  L->in = in;
+  L->ksteps = (in + 3) / 4;
+  L->ldk = two_odd_at_least(4 * L->ksteps);
+  L->g_w = *g;
+  *g += out * in;
+  L->g_b = *g;
+  *g += out;
+  L->l_w = *l;
+  *l += (out + 1) * L->ldk;   // +1: all-zero row that out-of-range MFMA rows read
+  L->l_b = *l;
+  *l += bias_pad;
+}
+
+int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  memset(pl, 0, sizeof(*pl));
+  const int D = cfg->D, C = cfg->C, H = cfg->H, K = cfg->K, T = cfg->T, NB = cfg->NB;
+  pl->D = D; pl->C = C; pl->H = H; pl->K = K; pl->T = T; pl->NB = NB;
+  pl->P = 3 * K - 1;
+  pl->PT = (pl->P + 15) / 16;
+  pl->B = cfg->tail_bound;
+  pl->min_w = cfg->min_bin_width; pl->min_h = cfg->min_bin_height; pl->min_d = cfg->min_derivative;
+  pl->lu_eps = cfg->lu_eps;
+  pl->sqrt_h = (float)sqrt((double)H);
+  pl->one_minus_kw = (float)(1.0 - (double)cfg->min_bin_width * K);
+  pl->one_minus_kh = (float)(1.0 - (double)cfg->min_bin_height * K);
+  pl->d_const = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
+  pl->log_z = (float)(0.5 * D * log(2.0 * M_PI));
+
+  for (int par = 0; par < 2; ++par) {
+    ShapeDesc* s = &pl->shape[par];
+    // create_alternating_binary_mask (torchutils.py:396-410): even transforms
+    // transform the even feature indices, odd ones the odd indices.
+    s->d_tr = (par == 0) ? (D + 1) / 2 : D / 2;
+    s->d_id = D - s->d_tr;
+    s->in0 = s->d_id + C;
+    int g = 0, l = 0;
+    const int hb = 16 * NSF_HT;
+    set_lin(&s->lin[0], &g, &l, H, s->in0, hb);
+    for (int b = 0; b < NB; ++b) {
+      set_lin(&s->lin[1 + 3 * b], &g, &l, H, C, hb);
+      set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb);
+      set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb);
+    }
+    set_lin(&s->lin[1 + 3 * NB], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT);
+    s->g_lu = g;
+    g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias
+    s->n_params = g;
+    s->l_U = l; l += D * D;
+    s->l_L = l; l += D * D;
+    s->l_lub = l; l += D;
+    s->lds_floats = round_up(l + 8, 4);   // slack: last K-step may read past a row end
+    if (s->lds_floats > pl->lds_w_floats) pl->lds_w_floats = s->lds_floats;
+  }
+  int off = 0;
+  for (int t = 0; t < T; ++t) {
+    pl->g_layer[t] = off;
+    off += pl->shape[t & 1].n_params;
+  }
+  pl->n_params = off;
+
+  // per-wave scratch; every row stride is 2*odd (bank-conflict-free b32 access
+  // by (row = lane&15, k-slot = lane>>4) lane pairs)
+  pl->ZW = two_odd_at_least(D);
+  pl->CW = two_odd_at_least(C);
+  int d_id_max = pl->shape[0].d_id > pl->shape[1].d_id ? pl->shape[0].d_id : pl->shape[1].d_id;
+  int need = d_id_max + round_up(C, 4);
+  int need2 = round_up(d_id_max + C, 4);
+  pl->CINW = two_odd_at_least(need > need2 ? need : need2);
+  pl->PSW = two_odd_at_least(16 * pl->PT);
+  pl->DS = 16 * pl->PSW + 1;
+  int o = 0;
+  pl->sc_zs = o; o += 16 * pl->ZW;
+  pl->sc_us = o; o += 16 * pl->ZW;
+  pl->sc_cs = o; o += 16 * pl->CW;
+  pl->sc_cin = o; o += 16 * pl->CINW;
+  pl->sc_pst = o;
+  int fixed = o;
+  int d_tr_max = pl->shape[0].d_tr;
+  int dch = NSF_MAX_DCH < d_tr_max ? NSF_MAX_DCH : d_tr_max;
+  for (; dch >= 1; --dch) {
+    int tot = round_up(fixed + dch * pl->DS, 4);
+    if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * tot) <= NSF_LDS_LIMIT_BYTES) {
+      pl->DCH = dch;
+      pl->sc_total = tot;
+      return 0;
+    }
+  }
+  return SBI_AMD_E_LDS;
+}
+
+int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out) {
+  // 16 rows per wave; aim for >= 256 workgroups (one per CU) before growing the
+  // workgroup, cap at 8 waves (2 per SIMD).
+  int nw = 8;
+  while (nw > 1 && (n + 16 * nw - 1) / (16 * nw) < 256) nw >>= 1;
+  for (; nw >= 1; nw >>= 1) {
+    int rc = nsf_build_plan(cfg, nw, pl);
+    if (rc == 0) { *nw_out = nw; return 0; }
+    if (rc != SBI_AMD_E_LDS) return rc;
+  }
+  return SBI_AMD_E_LDS;
+}
+
+extern "C" int64_t sbi_amd_nsf_param_count(const sbi_amd_nsf_config* cfg) {
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, 1, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return rc;
+  return pl.n_params;
+}
+extern "C" int64_t sbi_amd_nsf_layer_offset(const sbi_amd_nsf_config* cfg, int32_t t) {
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, 1, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return rc;
+  if (t < 0 || t >= pl.T) return SBI_AMD_E_BADARG;
+  return pl.g_layer[t];
+}
+extern "C" int64_t sbi_amd_nsf_lu_offset(const sbi_amd_nsf_config* cfg, int32_t t) {
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, 1, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return rc;
+  if (t < 0 || t >= pl.T) return SBI_AMD_E_BADARG;
+  return pl.g_layer[t] + pl.shape[t & 1].g_lu;
+}
+extern "C" int sbi_amd_nsf_abi_version(void) { return 100; }
+extern "C" const char* sbi_amd_nsf_arch(void) { return "gfx950"; }

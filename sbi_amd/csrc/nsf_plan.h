@@ -1,0 +1,60 @@
+// nsf_plan.h -- host-computed execution plan shared by every NSF kernel.
+//
+// The plan turns an sbi_amd_nsf_config (the hyper-parameters build_nsf takes,
+// /root/reference/sbi/neural_nets/net_builders/flow.py:333-460) into
+//   * offsets into the flat fp32 parameter buffer (nflows' natural order),
+//   * the LDS image one workgroup stages per coupling layer (MFMA A-operand
+//     layout: row-major [out+1][ldk], ldk = 2*odd so that the 16x16x4 f32
+//     MFMA operand reads are LDS-bank-conflict free, zero padded), and
+//   * the per-wave LDS scratch (flow state, conditioner input, spline params).
+// It is passed to kernels by value (~1.3 KB of kernarg).
+#pragma once
+#include <stdint.h>
+#include "../../include/sbi_amd_nsf.h"
+
+#define NSF_MAX_T 16
+#define NSF_MAX_NB 4
+#define NSF_MAX_LIN (2 + 3 * NSF_MAX_NB)
+#define NSF_HT 4          // hidden tiles of 16 -> H <= 64
+#define NSF_MAX_DCH 4     // spline dims processed per chunk (one per 16-lane group)
+#define NSF_LDS_LIMIT_BYTES (160 * 1024)
+
+struct LinDesc {
+  int g_w, g_b;   // float offsets relative to the layer's block in the flat buffer
+  int l_w, l_b;   // float offsets inside the LDS weight image
+  int out, in;    // natural dims of nn.Linear(in, out)
+  int ldk;        // LDS row stride (floats), 2*odd, >= 4*ksteps
+  int ksteps;     // ceil(in / 4) MFMA K-steps
+};
+
+struct ShapeDesc {   // one per mask parity (even / odd transform index)
+  int d_id, d_tr, in0;
+  LinDesc lin[NSF_MAX_LIN];   // 0 initial | 1+3b ctx_b | 2+3b lin0_b | 3+3b lin1_b | 1+3NB final
+  int g_lu;                   // LULinear block offset relative to the layer block
+  int l_U, l_L, l_lub;        // LDS offsets of expanded U[D][D], L[D][D], bias[D]
+  int n_params;               // floats in this layer block
+  int lds_floats;             // size of the LDS image
+};
+
+struct NsfPlan {
+  int D, C, H, K, T, NB, P, PT;   // P = 3K-1, PT = ceil(P/16)
+  float B, min_w, min_h, min_d, lu_eps, sqrt_h;
+  float one_minus_kw, one_minus_kh;   // 1 - min_w*K, 1 - min_h*K
+  float d_const;                      // log(exp(1-min_d)-1): boundary derivative pre-activation
+  float log_z;                        // 0.5*D*log(2*pi), fp32 (flow.py:1486-1487)
+  ShapeDesc shape[2];
+  int g_layer[NSF_MAX_T];
+  int n_params;
+  int lds_w_floats;             // LDS weight image size (max over parities)
+  // per-wave scratch (float offsets relative to the wave's scratch base)
+  int ZW, CW, CINW, PSW, DS, DCH;
+  int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_total;
+};
+
+// Builds the plan for nw waves per workgroup; returns 0 or SBI_AMD_E_*.
+int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl);
+// Largest nw in {8,4,2,1} (<= nw_max) whose LDS footprint fits 160 KiB.
+int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out);
+static inline int64_t nsf_lds_bytes(const NsfPlan& pl, int nw) {
+  return 4ll * ((int64_t)pl.lds_w_floats + (int64_t)nw * pl.sc_total);
+}

@@ -1,0 +1,352 @@
+"""NSF density estimator on the MI355X HIP kernels.
+
+``NSFFlow`` is the drop-in for sbi's ``NFlowsFlow(build_nsf(...))``
+(sbi/neural_nets/estimators/nflows_flow.py:14-151): same constructor role,
+``log_prob`` / ``loss`` / ``sample`` / ``sample_and_log_prob`` /
+``inverse_transform`` with the same shapes.  All arithmetic runs in
+``libsbi_amd_nsf.so`` through the C ABI of include/sbi_amd_nsf.h; there is no
+PyTorch or CPU fallback.
+
+Parameters live in ONE flat fp32 ``nn.Parameter`` (``net.flat_params``) laid
+out in nflows' natural order, so Adam state, gradient clipping and the
+data-parallel all-reduce each touch a single contiguous buffer.  Weight
+exchange with a real nflows ``Flow`` goes through ``nflows_state_dict`` /
+``load_nflows_state_dict`` (key names of SURVEY.md Appendix C).
+"""
+
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from sbi_amd import _lib
+from sbi_amd.neural_nets.estimators.base import ConditionalDensityEstimator
+
+
+@dataclass(frozen=True)
+class NSFHyper:
+    """Hyper-parameters ``build_nsf`` bakes into the flow (flow.py:333-352)."""
+
+    D: int
+    C: int
+    hidden_features: int = 50
+    num_transforms: int = 5
+    num_bins: int = 10
+    num_blocks: int = 2
+    tail_bound: float = 3.0
+    min_bin_width: float = 1e-3
+    min_bin_height: float = 1e-3
+    min_derivative: float = 1e-3
+    lu_eps: float = 1e-3
+
+    def c_config(self) -> _lib.NSFConfigC:
+        return _lib.NSFConfigC(
+            self.D, self.C, self.hidden_features, self.num_bins, self.num_transforms, self.num_blocks,
+            self.tail_bound, self.min_bin_width, self.min_bin_height, self.min_derivative, self.lu_eps,
+        )
+
+    # -- layout of the flat buffer (must agree with csrc/nsf_plan.cpp) -----------
+    def d_tr(self, t: int) -> int:
+        return (self.D + 1) // 2 if t % 2 == 0 else self.D // 2
+
+    def d_id(self, t: int) -> int:
+        return self.D - self.d_tr(t)
+
+    def layer_entries(self, t: int) -> List[Tuple[str, Tuple[int, ...]]]:
+        """(nflows sub-key, shape) in flat order for transform t."""
+        H, C, P = self.hidden_features, self.C, 3 * self.num_bins - 1
+        out = [("transform_net.initial_layer.weight", (H, self.d_id(t) + C)),
+               ("transform_net.initial_layer.bias", (H,))]
+        for b in range(self.num_blocks):
+            pre = f"transform_net.blocks.{b}."
+            out += [(pre + "context_layer.weight", (H, C)), (pre + "context_layer.bias", (H,)),
+                    (pre + "linear_layers.0.weight", (H, H)), (pre + "linear_layers.0.bias", (H,)),
+                    (pre + "linear_layers.1.weight", (H, H)), (pre + "linear_layers.1.bias", (H,))]
+        out += [("transform_net.final_layer.weight", (self.d_tr(t) * P, H)),
+                ("transform_net.final_layer.bias", (self.d_tr(t) * P,))]
+        return out
+
+    def lu_entries(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        n_tri = self.D * (self.D - 1) // 2
+        return [("lower_entries", (n_tri,)), ("upper_entries", (n_tri,)),
+                ("unconstrained_upper_diag", (self.D,)), ("bias", (self.D,))]
+
+    def param_count(self) -> int:
+        n = 0
+        for t in range(self.num_transforms):
+            n += sum(int(np.prod(s)) for _, s in self.layer_entries(t))
+            n += sum(int(np.prod(s)) for _, s in self.lu_entries())
+        return n
+
+
+class NSFNet(nn.Module):
+    """Parameter/buffer holder playing the role of nflows' ``Flow`` object.
+
+    Buffers: ``zstats`` = [theta shift (D), theta scale (D), x mean (C), x std (C)]
+    (PointwiseAffineTransform / Standardize buffers, sbiutils.py:226-247, 418-428),
+    ``_log_z`` (flow.py:1481-1488).
+    """
+
+    def __init__(self, hyper: NSFHyper, zstats: Tensor, z_score_theta: bool, z_score_x: bool,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.hyper = hyper
+        self.z_score_theta = z_score_theta
+        self.z_score_x = z_score_x
+        self.flat_params = nn.Parameter(torch.zeros(hyper.param_count(), dtype=torch.float32))
+        self.register_buffer("zstats", zstats.to(torch.float32).contiguous())
+        self.register_buffer(
+            "_log_z", torch.tensor(0.5 * hyper.D * math.log(2 * math.pi), dtype=torch.float64).to(dtype),
+            persistent=False,
+        )
+        self.reset_parameters()
+
+    # nflows-equivalent initialisation, drawing from torch's global generator in
+    # the same order nflows constructs its modules.
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        h = self.hyper
+        chunks: List[Tensor] = []
+        for t in range(h.num_transforms):
+            mods: Dict[str, nn.Linear] = {}
+            mods["transform_net.initial_layer"] = nn.Linear(h.d_id(t) + h.C, h.hidden_features)
+            for b in range(h.num_blocks):
+                pre = f"transform_net.blocks.{b}."
+                mods[pre + "context_layer"] = nn.Linear(h.C, h.hidden_features)
+                mods[pre + "linear_layers.0"] = nn.Linear(h.hidden_features, h.hidden_features)
+                last = nn.Linear(h.hidden_features, h.hidden_features)
+                nn.init.uniform_(last.weight, -1e-3, 1e-3)   # ResidualBlock zero_initialization
+                nn.init.uniform_(last.bias, -1e-3, 1e-3)
+                mods[pre + "linear_layers.1"] = last
+            mods["transform_net.final_layer"] = nn.Linear(h.hidden_features, h.d_tr(t) * (3 * h.num_bins - 1))
+            for key, _shape in h.layer_entries(t):
+                mod, attr = key.rsplit(".", 1)
+                chunks.append(getattr(mods[mod], attr).detach().reshape(-1))
+            n_tri = h.D * (h.D - 1) // 2
+            chunks.append(torch.zeros(2 * n_tri))                                   # L, U strict entries
+            chunks.append(torch.full((h.D,), float(np.log(np.exp(1 - h.lu_eps) - 1))))  # identity init
+            chunks.append(torch.zeros(h.D))                                         # bias
+        flat = torch.cat(chunks)
+        assert flat.numel() == self.flat_params.numel()
+        self.flat_params.copy_(flat)
+
+    # -- nflows state_dict exchange -------------------------------------------------
+    def _slices(self):
+        h = self.hyper
+        first = 1 if self.z_score_theta else 0
+        off = 0
+        for t in range(h.num_transforms):
+            pre = f"_transform._transforms.{first + 2 * t}."
+            for key, shape in h.layer_entries(t):
+                n = int(np.prod(shape))
+                yield pre + key, off, n, shape
+                off += n
+            pre = f"_transform._transforms.{first + 2 * t + 1}."
+            for key, shape in h.lu_entries():
+                n = int(np.prod(shape))
+                yield pre + key, off, n, shape
+                off += n
+
+    def nflows_state_dict(self, prefix: str = "net.") -> "OrderedDict[str, Tensor]":
+        h = self.hyper
+        sd: "OrderedDict[str, Tensor]" = OrderedDict()
+        flat = self.flat_params.detach()
+        if self.z_score_theta:
+            sd[prefix + "_transform._transforms.0._shift"] = self.zstats[: h.D].clone()
+            sd[prefix + "_transform._transforms.0._scale"] = self.zstats[h.D : 2 * h.D].clone()
+        for key, off, n, shape in self._slices():
+            sd[prefix + key] = flat[off : off + n].reshape(shape).clone()
+        if self.z_score_x:
+            sd[prefix + "_embedding_net.0._mean"] = self.zstats[2 * h.D : 2 * h.D + h.C].clone()
+            sd[prefix + "_embedding_net.0._std"] = self.zstats[2 * h.D + h.C :].clone()
+        return sd
+
+    @torch.no_grad()
+    def load_nflows_state_dict(self, sd: Dict[str, Tensor], prefix: str = "net.") -> None:
+        h = self.hyper
+        for key, off, n, shape in self._slices():
+            src = sd[prefix + key]
+            if tuple(src.shape) != tuple(shape):
+                raise ValueError(f"{key}: expected {shape}, got {tuple(src.shape)}")
+            self.flat_params[off : off + n].copy_(src.reshape(-1).to(self.flat_params))
+        if self.z_score_theta:
+            self.zstats[: h.D].copy_(sd[prefix + "_transform._transforms.0._shift"].reshape(-1))
+            self.zstats[h.D : 2 * h.D].copy_(sd[prefix + "_transform._transforms.0._scale"].reshape(-1))
+        if self.z_score_x:
+            mean = sd[prefix + "_embedding_net.0._mean"].reshape(-1)
+            std = sd[prefix + "_embedding_net.0._std"].reshape(-1)
+            self.zstats[2 * h.D : 2 * h.D + h.C].copy_(mean.expand(h.C))
+            self.zstats[2 * h.D + h.C :].copy_(std.expand(h.C))
+
+
+# --------------------------------------------------------------------- kernel calls
+def _log_prob_call(net: NSFNet, theta: Tensor, x: Tensor, want_noise: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """theta (N,D), x (x_rows,C) -> logp (N,), noise (N,D)|None."""
+    dev = _lib.require_device(theta, x, net.flat_params, net.zstats)
+    lib = _lib.load()
+    n = theta.shape[0]
+    logp = torch.empty(n, dtype=torch.float32, device=dev)
+    noise = torch.empty_like(theta) if want_noise else None
+    cfg = net.hyper.c_config()
+    with torch.cuda.device(dev):
+        rc = lib.sbi_amd_nsf_log_prob(
+            cfg, _lib.ptr(net.flat_params), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
+            _lib.ptr(logp), _lib.ptr(noise), _lib.current_stream(dev),
+        )
+    _lib.check(rc, "nsf_log_prob")
+    return logp, noise
+
+
+def _sample_call(net: NSFNet, noise: Tensor, x: Tensor, want_ld: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    dev = _lib.require_device(noise, x, net.flat_params, net.zstats)
+    lib = _lib.load()
+    n = noise.shape[0]
+    theta = torch.empty_like(noise)
+    ld = torch.empty(n, dtype=torch.float32, device=dev) if want_ld else None
+    cfg = net.hyper.c_config()
+    with torch.cuda.device(dev):
+        rc = lib.sbi_amd_nsf_sample(
+            cfg, _lib.ptr(net.flat_params), _lib.ptr(net.zstats), _lib.ptr(noise), _lib.ptr(x), n, x.shape[0],
+            _lib.ptr(theta), _lib.ptr(ld), _lib.current_stream(dev),
+        )
+    _lib.check(rc, "nsf_sample")
+    return theta, ld
+
+
+def loss_fwd_bwd(net: NSFNet, theta: Tensor, x: Tensor, row_weight: Optional[Tensor], uniform_weight: float,
+                 grad_out: Tensor, want_grad_theta: bool = False, workspace: Optional[Tensor] = None):
+    """Fused training pass: returns (per-row loss, grad_theta|None); fills grad_out (P,)."""
+    dev = _lib.require_device(theta, x, net.flat_params, net.zstats, grad_out, row_weight)
+    lib = _lib.load()
+    n = theta.shape[0]
+    cfg = net.hyper.c_config()
+    need = lib.sbi_amd_nsf_train_workspace_floats(cfg, n)
+    if need < 0:
+        _lib.check(int(need), "nsf_train_workspace_floats")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(int(need), 1), dtype=torch.float32, device=dev)
+    loss = torch.empty(n, dtype=torch.float32, device=dev)
+    gtheta = torch.empty_like(theta) if want_grad_theta else None
+    with torch.cuda.device(dev):
+        rc = lib.sbi_amd_nsf_loss_fwd_bwd(
+            cfg, _lib.ptr(net.flat_params), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
+            _lib.ptr(row_weight), float(uniform_weight), _lib.ptr(loss), _lib.ptr(grad_out), _lib.ptr(gtheta),
+            _lib.ptr(workspace), _lib.current_stream(dev),
+        )
+    _lib.check(rc, "nsf_loss_fwd_bwd")
+    return loss, gtheta
+
+
+class _NSFLogProbFn(torch.autograd.Function):
+    """Autograd bridge: forward = fused log_prob kernel; backward = fused
+    recompute+backward kernel with row weights -dL/dlogp."""
+
+    @staticmethod
+    def forward(ctx, theta: Tensor, x: Tensor, flat_params: Tensor, net: NSFNet):
+        logp, _ = _log_prob_call(net, theta, x, want_noise=False)
+        ctx.net = net
+        ctx.save_for_backward(theta, x)
+        return logp
+
+    @staticmethod
+    def backward(ctx, grad_logp: Tensor):
+        theta, x = ctx.saved_tensors
+        net: NSFNet = ctx.net
+        gparams = torch.empty_like(net.flat_params)
+        w = (-grad_logp).contiguous().to(torch.float32)
+        _, gtheta = loss_fwd_bwd(net, theta, x, w, 0.0, gparams, want_grad_theta=ctx.needs_input_grad[0])
+        if gtheta is not None:
+            gtheta = gtheta * w.unsqueeze(1)   # kernel returns d loss_n / d theta_n (unweighted)
+        return gtheta, None, (gparams if ctx.needs_input_grad[2] else None), None
+
+
+class NSFFlow(ConditionalDensityEstimator):
+    r"""Neural Spline Flow :math:`p(\theta|x)` evaluated by the gfx950 kernels."""
+
+    def __init__(self, net: NSFNet, input_shape: torch.Size, condition_shape: torch.Size) -> None:
+        super().__init__(net, input_shape=input_shape, condition_shape=condition_shape)
+        if len(torch.Size(input_shape)) != 1 or len(torch.Size(condition_shape)) != 1:
+            raise NotImplementedError(
+                "sbi_amd NSF kernels take 1-D theta and (embedded) x events; embedding nets "
+                "are outside this path (SURVEY.md section 2 row 19)."
+            )
+        self.net: NSFNet
+
+    @property
+    def embedding_net(self) -> nn.Module:
+        return nn.Identity()
+
+    # -- helpers ---------------------------------------------------------------------
+    def _flatten_pair(self, input: Tensor, condition: Tensor) -> Tuple[Tensor, Tensor, int, int]:
+        """(S,B,D)/(B,D) input + condition -> theta (S*B, D), x (x_rows, C), S, B without
+        materialising a broadcast condition (the kernel indexes x[n % x_rows])."""
+        self._check_input_shape(input)
+        self._check_condition_shape(condition)
+        input, S, B, cond_has_sample = self._broadcast_dims(input, condition)
+        D = self.input_shape[0]
+        theta = input.expand(S, B, D).reshape(S * B, D)
+        if cond_has_sample:
+            x = condition.expand(S, B, *self.condition_shape).reshape(S * B, -1)
+        else:
+            x = condition.reshape(condition.shape[0], -1)   # (1|B, C): n % x_rows does the broadcast
+        return theta.contiguous().float(), x.contiguous().float(), S, B
+
+    # -- estimator surface -----------------------------------------------------------
+    def log_prob(self, input: Tensor, condition: Tensor, **kwargs) -> Tensor:
+        theta, x, S, B = self._flatten_pair(input, condition)
+        needs_grad = torch.is_grad_enabled() and (theta.requires_grad or self.net.flat_params.requires_grad)
+        if needs_grad:
+            lp = _NSFLogProbFn.apply(theta, x, self.net.flat_params, self.net)
+        else:
+            lp, _ = _log_prob_call(self.net, theta, x, want_noise=False)
+        return lp.reshape(S, B)
+
+    def loss(self, input: Tensor, condition: Tensor, **kwargs) -> Tensor:
+        return -self.log_prob(input.unsqueeze(0), condition)[0]
+
+    def inverse_transform(self, input: Tensor, condition: Tensor) -> Tensor:
+        self._check_condition_shape(condition)
+        bshape = torch.broadcast_shapes(input.shape[:-1], condition.shape[: condition.dim() - 1])
+        theta = input.expand(bshape + (input.shape[-1],)).reshape(-1, input.shape[-1]).contiguous().float()
+        x = condition.expand(bshape + self.condition_shape).reshape(-1, self.condition_shape[0]).contiguous().float()
+        with torch.no_grad():
+            _, noise = _log_prob_call(self.net, theta, x, want_noise=True)
+        return noise.reshape(bshape + (noise.shape[-1],))
+
+    def sample_from_noise(self, noise: Tensor, condition: Tensor, with_logabsdet: bool = False):
+        """theta = transform^{-1}(noise | condition); noise (N,D), condition (1|N, C)."""
+        with torch.no_grad():
+            theta, ld = _sample_call(self.net, noise.contiguous().float(),
+                                     condition.reshape(condition.shape[0], -1).contiguous().float(), with_logabsdet)
+        return (theta, ld) if with_logabsdet else theta
+
+    def sample(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tensor:
+        self._check_condition_shape(condition)
+        Bc = condition.shape[0]
+        n = torch.Size(sample_shape).numel()
+        D = self.input_shape[0]
+        # nflows draws randn(Bc*n, D) viewed (Bc, n, D) and NFlowsFlow transposes to
+        # (n, Bc, D) (nflows_flow.py:124-128): draw in that order, keep rows sample-major
+        # so the kernel's x[row % Bc] pairs every draw with its condition.
+        noise = torch.randn(Bc * n, D, device=condition.device, dtype=torch.float32)
+        noise = noise.reshape(Bc, n, D).transpose(0, 1).reshape(n * Bc, D).contiguous()
+        theta = self.sample_from_noise(noise, condition)
+        return theta.reshape((*sample_shape, Bc, *self.input_shape))
+
+    def sample_and_log_prob(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tuple[Tensor, Tensor]:
+        self._check_condition_shape(condition)
+        Bc = condition.shape[0]
+        n = torch.Size(sample_shape).numel()
+        D = self.input_shape[0]
+        noise = torch.randn(Bc * n, D, device=condition.device, dtype=torch.float32)
+        noise = noise.reshape(Bc, n, D).transpose(0, 1).reshape(n * Bc, D).contiguous()
+        theta, ld = self.sample_from_noise(noise, condition, with_logabsdet=True)
+        base = -0.5 * (noise**2).sum(1) - self.net._log_z.to(noise.dtype)
+        logp = base - ld   # Flow.sample_and_log_prob: log p(noise) - logabsdet(inverse)
+        return theta.reshape((*sample_shape, Bc, -1)), logp.reshape((*sample_shape, -1))

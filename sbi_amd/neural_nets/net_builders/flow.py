@@ -1,0 +1,91 @@
+"""``build_nsf`` -- builds the NSF estimator for p(x|y) (= p(theta|x) in NPE).
+
+Drop-in for sbi/neural_nets/net_builders/flow.py:333-460 restricted to what the
+HIP path implements: ResidualNet-conditioned RQ-spline couplings with linear
+tails + LULinear, alternating masks, z-scoring of both sides, identity
+embedding.  Unsupported options raise instead of silently degrading.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, NSFHyper, NSFNet
+from sbi_amd.utils.sbiutils import (
+    assert_transform_to_unconstrained_supported,
+    standardizing_stats,
+    z_score_parser,
+    z_standardization,
+)
+
+
+def check_data_device(datum_1: Tensor, datum_2: Tensor) -> None:
+    """sbi/utils/torchutils.py `check_data_device`: both batches on one device."""
+    if datum_1.device != datum_2.device:
+        raise AssertionError(
+            "Mismatch in fed data's device: "
+            f"datum_1 has device '{datum_1.device}' whereas datum_2 has device '{datum_2.device}'. "
+            "Please use data from a common device."
+        )
+
+
+def build_nsf(
+    batch_x: Tensor,
+    batch_y: Tensor,
+    z_score_x: Optional[str] = "independent",
+    z_score_y: Optional[str] = "independent",
+    hidden_features: int = 50,
+    num_transforms: int = 5,
+    num_bins: int = 10,
+    embedding_net: nn.Module = nn.Identity(),
+    tail_bound: float = 3.0,
+    hidden_layers_spline_context: int = 1,
+    num_blocks: int = 2,
+    dropout_probability: float = 0.0,
+    use_batch_norm: bool = False,
+    **kwargs,
+) -> NSFFlow:
+    """Same signature and meaning as the reference ``build_nsf`` (flow.py:333-352)."""
+    check_data_device(batch_x, batch_y)
+    assert_transform_to_unconstrained_supported(
+        z_score_x, "build_nsf",
+        "Use one of 'none', 'independent', 'structured'.",
+    )
+    if not isinstance(embedding_net, nn.Identity):
+        raise NotImplementedError(
+            "sbi_amd.build_nsf: embedding nets are outside the accelerated path (SURVEY.md section 2 "
+            "row 19); embed x first and pass the embedded features."
+        )
+    if dropout_probability != 0.0 or use_batch_norm:
+        raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
+    x_numel = batch_x[0].numel()
+    y_numel = batch_y[0].numel()
+    if x_numel == 1:
+        raise NotImplementedError(
+            "sbi_amd.build_nsf: 1-D theta uses sbi's ContextSplineMap conditioner (flow.py:1419-1478), "
+            "which the HIP path does not implement yet."
+        )
+    if batch_x[0].dim() != 1 or batch_y[0].dim() != 1:
+        raise NotImplementedError("sbi_amd.build_nsf: theta and x events must be 1-D")
+
+    D, C = x_numel, y_numel
+    zstats = torch.cat([torch.zeros(D), torch.ones(D), torch.zeros(C), torch.ones(C)])
+    zx, structured_x = z_score_parser(z_score_x)
+    if zx:
+        mean, std = z_standardization(batch_x.detach().cpu().float(), structured_x)
+        # PointwiseAffineTransform(shift=-mean/std, scale=1/std)  (sbiutils.py:247)
+        zstats[:D] = (-mean / std).expand(D)
+        zstats[D : 2 * D] = (1 / std).expand(D)
+    zy, structured_y = z_score_parser(z_score_y)
+    if zy:
+        mean, std = standardizing_stats(batch_y.detach().cpu().float(), structured_y)
+        zstats[2 * D : 2 * D + C] = mean.expand(C)
+        zstats[2 * D + C :] = std.expand(C)
+
+    hyper = NSFHyper(D=D, C=C, hidden_features=hidden_features, num_transforms=num_transforms,
+                     num_bins=num_bins, num_blocks=num_blocks, tail_bound=float(tail_bound))
+    net = NSFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy, dtype=kwargs.get("dtype", torch.float32))
+    return NSFFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape)

@@ -1,0 +1,128 @@
+"""z-scoring and data-hygiene helpers on the NSF/NPE path.
+
+Behavioural mirrors of sbi/utils/sbiutils.py: z_score_parser (:154-189),
+z_standardization (:376-415), standardizing_net statistics (:431-488),
+handle_invalid_x (:491-525), within_support (:729-766).
+"""
+
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+
+def z_score_parser(z_score_flag: Optional[str] = None) -> Tuple[bool, bool]:
+    """-> (do z-score, structured dims)."""
+    if z_score_flag is None or z_score_flag == "none":
+        return False, False
+    if z_score_flag in ("independent", "structured"):
+        return True, z_score_flag == "structured"
+    if z_score_flag == "transform_to_unconstrained":
+        return False, False
+    raise ValueError(
+        "Invalid z-scoring option. Use 'none', 'independent' 'structured' or "
+        "'transform_to_unconstrained'."
+    )
+
+
+def assert_transform_to_unconstrained_supported(z_score_x: Optional[str], builder_name: str, suggestion: str):
+    if z_score_x == "transform_to_unconstrained":
+        raise ValueError(
+            f"`z_score_x='transform_to_unconstrained'` is not supported by `{builder_name}`. {suggestion}"
+        )
+
+
+def handle_invalid_x(x: Tensor, exclude_invalid_x: bool = True) -> Tuple[Tensor, int, int]:
+    """Rows with NaN / Inf -> (is_valid mask, num_nans, num_infs) (sbiutils.py:491-525)."""
+    batch = x.reshape(x.shape[0], -1)
+    x_is_nan = torch.isnan(batch).any(dim=1)
+    x_is_inf = torch.isinf(batch).any(dim=1)
+    num_nans = int(x_is_nan.sum().item())
+    num_infs = int(x_is_inf.sum().item())
+    if exclude_invalid_x:
+        is_valid = ~x_is_nan & ~x_is_inf
+    else:
+        is_valid = torch.ones(batch.shape[0], dtype=torch.bool, device=x.device)
+    return is_valid, num_nans, num_infs
+
+
+def warn_on_invalid_x(num_nans: int, num_infs: int, exclude_invalid_x: bool) -> None:
+    if num_nans + num_infs > 0:
+        if exclude_invalid_x:
+            logging.warning(
+                f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. They will be excluded "
+                "from training."
+            )
+        else:
+            logging.warning(
+                f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. Training might fail."
+            )
+
+
+def z_standardization(batch_t: Tensor, structured_dims: bool = False, min_std: float = 1e-14):
+    """Mean / std used to z-score theta (sbiutils.py:376-415)."""
+    is_valid_t, *_ = handle_invalid_x(batch_t, True)
+    t = batch_t[is_valid_t]
+    if structured_dims:
+        t_mean = torch.mean(t)
+        sample_std = torch.std(t, dim=1)
+        sample_std[sample_std < min_std] = min_std
+        t_std = torch.mean(sample_std)
+    else:
+        t_mean = torch.mean(t, dim=0)
+        t_std = torch.std(t, dim=0)
+        t_std[t_std < min_std] = min_std
+    return t_mean, t_std
+
+
+def standardizing_stats(batch_t: Tensor, structured_dims: bool = False, min_std: float = 1e-7):
+    """Mean / std of the ``Standardize`` layer prepended to the x embedding
+    (sbiutils.py:431-488, incl. the single-row special case)."""
+    is_valid_t, *_ = handle_invalid_x(batch_t, True)
+    t = batch_t[is_valid_t]
+    t_mean = torch.mean(t) if structured_dims else torch.mean(t, dim=0)
+    if len(batch_t) > 1:
+        if structured_dims:
+            sample_std = torch.std(t, dim=1)
+            sample_std[sample_std < min_std] = min_std
+            t_std = torch.mean(sample_std)
+        else:
+            t_std = torch.std(t, dim=0)
+            t_std[t_std < min_std] = min_std
+    else:
+        t_std = torch.ones(1)
+        logging.warning(
+            "Using a one-dimensional batch will instantiate a Standardize transform with (mean, std) "
+            "parameters which are not representative of the data."
+        )
+    if torch.isnan(t_mean).any() or torch.isnan(t_std).any():
+        raise AssertionError(
+            "Training data mean or std for standardizing net must not contain NaNs. In case you are "
+            "encoding missing trials with NaNs, consider setting z_score_x='none' to disable z-scoring."
+        )
+    return t_mean, t_std
+
+
+def within_support(distribution, samples: Tensor) -> Tensor:
+    """Boolean mask of samples inside the prior support (sbiutils.py:729-766)."""
+    try:
+        sample_check = distribution.support.check(samples)
+        if sample_check.shape == samples.shape:
+            sample_check = torch.all(sample_check, dim=-1)
+        return sample_check
+    except (NotImplementedError, AttributeError):
+        return torch.isfinite(distribution.log_prob(samples))
+
+
+def warn_if_outside_prior_support(prior, samples: Tensor) -> None:
+    inside = within_support(prior, samples)
+    if not bool(inside.all()):
+        frac = 1.0 - float(inside.float().mean())
+        warnings.warn(
+            f"{frac:.1%} of the samples drawn without rejection lie outside the prior support.",
+            stacklevel=2,
+        )
