@@ -53,7 +53,9 @@ def cpu_baseline(mode, budget_s=12.0):
     """Oracle (= op-for-op restatement of what sbi+nflows execute) timed on host cores."""
     from oracle.nsf_oracle import NSFOracle
 
-    cores = os.cpu_count() or 1
+    # Intra-op threads: eager PyTorch on (N,145)-sized temporaries stops scaling (and
+    # collapses when oversubscribed) well before a 2-socket host's core count.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("SBI_AMD_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
     theta, x = make_data(BATCH, "cpu")
     torch.manual_seed(1)

@@ -18,7 +18,8 @@
  *   - every call is asynchronous on `stream`; nothing allocates or syncs
  *   - return value: 0 = launched; <0 = SBI_AMD_E_* (nothing launched);
  *                   >0 = hipError_t from the launch
- *   - `params` is ONE flat fp32 buffer in nflows' natural parameter order
+ *   - `params` is ONE flat fp32 buffer in nflows' natural parameter order; `packed`
+ *     is its kernel-side image (sbi_amd_nsf_pack)
  *     (see sbi_amd_nsf_param_count / DESIGN.md "flat parameter layout"):
  *     per transform t = 0..T-1:
  *        initial_layer.weight (H, d_id+C), .bias (H)
@@ -70,11 +71,19 @@ int64_t sbi_amd_nsf_param_count(const sbi_amd_nsf_config* cfg);
 int64_t sbi_amd_nsf_layer_offset(const sbi_amd_nsf_config* cfg, int32_t t);
 int64_t sbi_amd_nsf_lu_offset(const sbi_amd_nsf_config* cfg, int32_t t);
 
+/* The compute kernels read the weights from a PACKED image (per transform: the
+ * MFMA A-operand layout one workgroup stages into LDS, with LULinear's L/U
+ * expanded -- what nflows' LULinear._create_lower_upper rebuilds on every call).
+ * sbi_amd_nsf_pack converts flat `params` -> `packed`
+ * (sbi_amd_nsf_packed_floats(cfg) floats); call it whenever params changed. */
+int64_t sbi_amd_nsf_packed_floats(const sbi_amd_nsf_config* cfg);
+int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream);
+
 /* log p(theta | x) for n rows: replaces nflows Flow.log_prob behind
  * NFlowsFlow.log_prob (nflows_flow.py:77-97).  noise_out (n,D) is optional
  * (NULL) and receives transform(theta) = NFlowsFlow.inverse_transform
  * (nflows_flow.py:43-75). */
-int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                          const float* theta, const float* x, int64_t n, int64_t x_rows,
                          float* logp_out, float* noise_out, void* stream);
 
@@ -82,7 +91,7 @@ int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* params, con
  * Flow._sample behind NFlowsFlow.sample (nflows_flow.py:111-128) for GIVEN
  * base noise (the caller draws it with torch's generator, see DESIGN.md RNG).
  * logabsdet_out (n) optional: log|det d theta/d noise|. */
-int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                        const float* noise, const float* x, int64_t n, int64_t x_rows,
                        float* theta_out, float* logabsdet_out, void* stream);
 
@@ -94,7 +103,8 @@ int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* params, const
  * d theta_n (needed by MAP / gradient_ascent, base_posterior.py:216-323).
  * `workspace` must hold sbi_amd_nsf_train_workspace_floats(cfg, n) floats. */
 int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n);
-int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
+                             const float* zstats,
                              const float* theta, const float* x, int64_t n, int64_t x_rows,
                              const float* row_weight, float uniform_weight, float* loss_out,
                              float* grad_out, float* grad_theta_out, float* workspace, void* stream);

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "sbi_amd_nsf_param_count": (c_int64, [POINTER(NSFConfigC)]),
     "sbi_amd_nsf_layer_offset": (c_int64, [POINTER(NSFConfigC), c_int32]),
     "sbi_amd_nsf_lu_offset": (c_int64, [POINTER(NSFConfigC), c_int32]),
+    "sbi_amd_nsf_packed_floats": (c_int64, [POINTER(NSFConfigC)]),
+    "sbi_amd_nsf_pack": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p]),
     "sbi_amd_nsf_log_prob": (
         c_int,
         [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
@@ -52,8 +54,8 @@ _SIGNATURES = {
     "sbi_amd_nsf_train_workspace_floats": (c_int64, [POINTER(NSFConfigC), c_int64]),
     "sbi_amd_nsf_loss_fwd_bwd": (
         c_int,
-        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_adam_clip_step": (
         c_int,

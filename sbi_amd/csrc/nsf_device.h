@@ -38,17 +38,21 @@ __device__ __forceinline__ LaneId make_lane() {
   return L;
 }
 
-// ---- weight staging: flat natural layout (global) -> MFMA A-operand image (LDS)
-__device__ __forceinline__ void stage_linear(float* __restrict__ lds, const float* __restrict__ gl,
-                                             const LinDesc& L, int bias_pad, int bias_group, int bias_group_pad,
-                                             int tid, int nthreads) {
+// ---- weight packing: flat natural layout -> per-layer MFMA A-operand image ----
+// Run by nsf_pack_kernel (one workgroup per transform) whenever the parameters
+// change; the compute kernels then stage a layer with a plain float4 copy.
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ void pack_linear(float* __restrict__ img, const float* __restrict__ gl,
+                                            const LinDesc& L, int bias_pad, int bias_group, int bias_group_pad,
+                                            int tid, int nthreads) {
   const int total = (L.out + 1) * L.ldk;
   for (int idx = tid; idx < total; idx += nthreads) {
     int r = idx / L.ldk;
     int c = idx - r * L.ldk;
     float v = 0.f;
     if (r < L.out && c < L.in) v = gl[L.g_w + r * L.in + c];
-    lds[L.l_w + idx] = v;
+    img[L.l_w + idx] = v;
   }
   // bias: groups of `bias_group` real entries padded to `bias_group_pad`
   for (int idx = tid; idx < bias_pad; idx += nthreads) {
@@ -57,14 +61,12 @@ __device__ __forceinline__ void stage_linear(float* __restrict__ lds, const floa
     int src = grp * bias_group + p;
     float v = 0.f;
     if (p < bias_group && src < L.out) v = gl[L.g_b + src];
-    lds[L.l_b + idx] = v;
+    img[L.l_b + idx] = v;
   }
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-
-__device__ __forceinline__ void stage_lu(float* __restrict__ lds, const float* __restrict__ gl,
-                                         const ShapeDesc& S, int D, float eps, int tid, int nthreads) {
+__device__ __forceinline__ void pack_lu(float* __restrict__ img, const float* __restrict__ gl,
+                                        const ShapeDesc& S, int D, float eps, int tid, int nthreads) {
   // LULinear._create_lower_upper: np.tril_indices(D,-1) / np.triu_indices(D,1) order.
   const int ntri = D * (D - 1) / 2;
   const float* lower = gl + S.g_lu;
@@ -77,23 +79,45 @@ __device__ __forceinline__ void stage_lu(float* __restrict__ lds, const float* _
     if (k > i) u = upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
     else if (k == i) { u = softplus_f(udiag[i]) + eps; l = 1.f; }
     else l = lower[i * (i - 1) / 2 + k];
-    lds[S.l_U + idx] = u;
-    lds[S.l_L + idx] = l;
+    img[S.l_U + idx] = u;
+    img[S.l_L + idx] = l;
   }
-  for (int idx = tid; idx < D; idx += nthreads) lds[S.l_lub + idx] = bias[idx];
+  for (int idx = tid; idx < D; idx += nthreads) img[S.l_lub + idx] = bias[idx];
 }
 
-__device__ __forceinline__ void stage_layer(float* __restrict__ lds, const float* __restrict__ gl,
-                                            const NsfPlan& pl, const ShapeDesc& S, int tid, int nthreads) {
+__device__ __forceinline__ void pack_layer(float* __restrict__ img, const float* __restrict__ gl,
+                                           const NsfPlan& pl, const ShapeDesc& S, int tid, int nthreads) {
   const int hb = 16 * NSF_HT;
-  stage_linear(lds, gl, S.lin[0], hb, hb, hb, tid, nthreads);
+  pack_linear(img, gl, S.lin[0], hb, hb, hb, tid, nthreads);
   for (int b = 0; b < pl.NB; ++b) {
-    stage_linear(lds, gl, S.lin[1 + 3 * b], hb, hb, hb, tid, nthreads);
-    stage_linear(lds, gl, S.lin[2 + 3 * b], hb, hb, hb, tid, nthreads);
-    stage_linear(lds, gl, S.lin[3 + 3 * b], hb, hb, hb, tid, nthreads);
+    pack_linear(img, gl, S.lin[1 + 3 * b], hb, hb, hb, tid, nthreads);
+    pack_linear(img, gl, S.lin[2 + 3 * b], hb, hb, hb, tid, nthreads);
+    pack_linear(img, gl, S.lin[3 + 3 * b], hb, hb, hb, tid, nthreads);
   }
-  stage_linear(lds, gl, S.lin[1 + 3 * pl.NB], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
-  stage_lu(lds, gl, S, pl.D, pl.lu_eps, tid, nthreads);
+  pack_linear(img, gl, S.lin[1 + 3 * pl.NB], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
+  pack_lu(img, gl, S, pl.D, pl.lu_eps, tid, nthreads);
+  for (int idx = S.l_lub + pl.D + tid; idx < pl.img_floats; idx += nthreads) img[idx] = 0.f;
+}
+
+// stage one layer's image into LDS: coalesced 16-byte copies, all loads issued first
+__device__ __forceinline__ void stage_layer(float* __restrict__ lds, const float* __restrict__ img,
+                                            int img_floats, int tid, int nthreads) {
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(img);
+  float4* dst = reinterpret_cast<float4*>(lds);
+  const int n4 = img_floats >> 2;
+  for (int base = 0; base < n4; base += 4 * nthreads) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int idx = base + u * nthreads + tid;
+      if (idx < n4) v[u] = src[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int idx = base + u * nthreads + tid;
+      if (idx < n4) dst[idx] = v[u];
+    }
+  }
 }
 
 // ---- MFMA GEMM pieces ------------------------------------------------------
@@ -114,35 +138,49 @@ __device__ __forceinline__ void a_row_offsets(const LinDesc& L, const LaneId& id
   }
 }
 
-// acc += W * B, B operand read from a per-wave LDS row buffer (conditioner input)
+// acc += W * B, B operand read from a per-wave LDS row buffer (conditioner input).
+// L.ksteps is a multiple of 4 (zero padded on both operands).
 __device__ __forceinline__ void gemm_blds(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
                                           const float* __restrict__ brow /* &buf[j*stride + coff + g] */,
                                           f4 (&acc)[NSF_HT]) {
   int ro[NSF_HT];
   a_row_offsets(L, id, ro);
-  for (int s = 0; s < L.ksteps; ++s) {
-    float bv = brow[4 * s];
+  for (int s4 = 0; s4 < L.ksteps; s4 += 4) {
+    float bv[4], av[4][NSF_HT];
 #pragma unroll
-    for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(lds[ro[mt] + 4 * s], bv, acc[mt]);
+    for (int u = 0; u < 4; ++u) {
+      bv[u] = brow[4 * (s4 + u)];
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt) av[u][mt] = lds[ro[mt] + 4 * (s4 + u)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(av[u][mt], bv[u], acc[mt]);
   }
 }
 
-// acc += W * B, B operand = the previous layer's D fragments (registers)
+// acc += W * B, B operand = the previous layer's D fragments (registers); KSH K-steps,
+// fully unrolled so the LDS reads of step s+1 are in flight under the MFMAs of step s.
+template <int KSH>
 __device__ __forceinline__ void gemm_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
                                           const f4 (&b)[NSF_HT], f4 (&acc)[NSF_HT]) {
   int ro[NSF_HT];
   a_row_offsets(L, id, ro);
+  float a_cur[NSF_HT], a_nxt[NSF_HT];
 #pragma unroll
-  for (int kt = 0; kt < NSF_HT; ++kt) {
+  for (int mt = 0; mt < NSF_HT; ++mt) a_cur[mt] = lds[ro[mt]];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = 4 * kt + r;
-      if (s < L.ksteps) {
-        float bv = b[kt][r];
+  for (int s = 0; s < KSH; ++s) {
+    if (s + 1 < KSH) {
 #pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(lds[ro[mt] + 4 * s], bv, acc[mt]);
-      }
+      for (int mt = 0; mt < NSF_HT; ++mt) a_nxt[mt] = lds[ro[mt] + 4 * (s + 1)];
     }
+    const float bv = b[s >> 2][s & 3];
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(a_cur[mt], bv, acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt) a_cur[mt] = a_nxt[mt];
   }
 }
 
@@ -150,6 +188,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 
 // ResidualNet hidden stack (nflows nn/nets/resnet.py, configuration flow.py:411-419):
 // h = W0 [z_id; c] + b0;  per block: t = W2 relu(W1 relu(h) + b1) + b2; h += t * sigmoid(Wc c + bc)
+template <int KSH>
 __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds, const NsfPlan& pl,
                                                    const ShapeDesc& S, const LaneId& id,
                                                    const float* __restrict__ cin_row, f4 (&h)[NSF_HT]) {
@@ -164,13 +203,13 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
 #pragma unroll
       for (int r = 0; r < 4; ++r) t[mt][r] = fmaxf(h[mt][r], 0.f);
     acc_init_bias(lds, S.lin[2 + 3 * b], id, u);
-    gemm_breg(lds, S.lin[2 + 3 * b], id, t, u);
+    gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, t, u);
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[mt][r] = fmaxf(u[mt][r], 0.f);
     acc_init_bias(lds, S.lin[3 + 3 * b], id, t);
-    gemm_breg(lds, S.lin[3 + 3 * b], id, u, t);
+    gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, u, t);
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -179,7 +218,7 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
 }
 
 // final_layer for the spline dims [d0, d0+DCH) -> per-wave LDS staging pst[slot][row][param]
-template <int PT>
+template <int PT, int KSH>
 __device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds, float* __restrict__ pst,
                                                   const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
                                                   const f4 (&h)[NSF_HT], int d0) {
@@ -199,20 +238,17 @@ __device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds,
         acc[sl][pt][r] = on ? lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g] : 0.f;
     }
   }
+  // wave-uniform count of active dim slots in this chunk
+  int nact = S.d_tr - d0;
+  nact = nact < pl.DCH ? nact : pl.DCH;
 #pragma unroll
-  for (int kt = 0; kt < NSF_HT; ++kt) {
+  for (int s = 0; s < KSH; ++s) {
+    const float bv = h[s >> 2][s & 3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = 4 * kt + r;
-      if (s < L.ksteps) {
-        float bv = h[kt][r];
+    for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
+      if (sl < nact) {
 #pragma unroll
-        for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
-          if (sl < pl.DCH && d0 + sl < S.d_tr) {
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
-          }
-        }
+        for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
       }
     }
   }

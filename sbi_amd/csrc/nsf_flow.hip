@@ -9,9 +9,17 @@
 #include <hip/hip_runtime.h>
 #include "nsf_device.h"
 
-template <int K, bool INV>
+// one workgroup per transform: flat parameters -> packed MFMA weight image
 __global__ void __launch_bounds__(512)
-nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ params, const float* __restrict__ zstats,
+nsf_pack_kernel(const NsfPlan pl, const float* __restrict__ params, float* __restrict__ packed) {
+  const int t = blockIdx.x;
+  pack_layer(packed + (long long)t * pl.img_floats, params + pl.g_layer[t], pl, pl.shape[t & 1], threadIdx.x,
+             blockDim.x);
+}
+
+template <int K, int KSH, bool INV>
+__global__ void __launch_bounds__(512)
+nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash) {
   constexpr int PT = (3 * K - 1 + 15) / 16;
@@ -60,7 +68,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ params, const float*
     const int par = t & 1;
     const ShapeDesc& S = pl.shape[par];
     __syncthreads();   // every wave is done with the previous layer's weights
-    stage_layer(lds, params + pl.g_layer[t], pl, S, tid, nthreads);
+    stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
     __syncthreads();
 
     if (!INV && z_stash) {
@@ -74,10 +82,10 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ params, const float*
     build_cin(pl, S, par, id, zs, cs, cin);
 
     f4 h[NSF_HT];
-    conditioner_hidden(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
+    conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
 
     for (int d0 = 0; d0 < S.d_tr; d0 += pl.DCH) {
-      final_layer_chunk<PT>(lds, pst, pl, S, id, h, d0);
+      final_layer_chunk<PT, KSH>(lds, pst, pl, S, id, h, d0);
       wave_lds_fence();
       const int dd = d0 + id.g;
       if (id.g < pl.DCH && dd < S.d_tr) {
@@ -121,57 +129,82 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ params, const float*
 }
 
 // ------------------------------------------------------------------ host side
-template <int K, bool INV>
-static int launch_flow(const NsfPlan& pl, int nw, const float* params, const float* zstats, const float* in,
+template <int K, int KSH, bool INV>
+static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                        const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                        float* z_stash, hipStream_t stream) {
   const int64_t lds_bytes = nsf_lds_bytes(pl, nw);
-  auto kern = nsf_flow_kernel<K, INV>;
+  auto kern = nsf_flow_kernel<K, KSH, INV>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t rows_per_wg = 16 * nw;
   const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, params, zstats, in,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, packed, zstats, in,
                      x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash);
   return (int)hipGetLastError();
 }
 
+template <int K, bool INV>
+static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
+                           const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                           float* z_stash, hipStream_t st) {
+  if (pl.KSH == 13)
+    return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+  return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+}
+
 template <bool INV>
-static int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats, const float* in,
+static int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* in,
                          const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                          float* z_stash, void* stream) {
-  if (!cfg || !params || !zstats || !in || !x || !out_main || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
   if (n == 0) return 0;
+  if (!cfg || !packed || !zstats || !in || !x || !out_main || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
   NsfPlan pl;
   int nw = 0;
   int rc = nsf_plan_for_rows(cfg, n, &pl, &nw);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   switch (cfg->K) {
-    case 4: return launch_flow<4, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 5: return launch_flow<5, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 8: return launch_flow<8, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 10: return launch_flow<10, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 16: return launch_flow<16, INV>(pl, nw, params, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 4: return launch_flow_ksh<4, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 5: return launch_flow_ksh<5, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 8: return launch_flow_ksh<8, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 10: return launch_flow_ksh<10, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 16: return launch_flow_ksh<16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
     default: return SBI_AMD_E_UNSUPPORTED;
   }
 }
 
 // used by the training path (nsf_train.hip): forward with per-layer state stash
-int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats, const float* theta,
+int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
                        float* z_stash, void* stream) {
-  return dispatch_flow<false>(cfg, params, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, stream);
+  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, stream);
 }
 
-extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+extern "C" int64_t sbi_amd_nsf_packed_floats(const sbi_amd_nsf_config* cfg) {
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, 1, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return rc;
+  return nsf_packed_floats(pl);
+}
+
+extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream) {
+  if (!cfg || !params || !packed) return SBI_AMD_E_BADARG;
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, 1, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return rc;
+  hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T), dim3(512), 0, (hipStream_t)stream, pl, params, packed);
+  return (int)hipGetLastError();
+}
+
+extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                     const float* theta, const float* x, int64_t n, int64_t x_rows,
                                     float* logp_out, float* noise_out, void* stream) {
-  return dispatch_flow<false>(cfg, params, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, stream);
+  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, stream);
 }
 
-extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* params, const float* zstats,
+extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                   const float* noise, const float* x, int64_t n, int64_t x_rows,
                                   float* theta_out, float* logabsdet_out, void* stream) {
-  return dispatch_flow<true>(cfg, params, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, stream);
+  return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, stream);
 }

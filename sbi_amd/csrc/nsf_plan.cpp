@@ -4,12 +4,12 @@
 #include <math.h>
 #include <string.h>
 
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static int two_odd_at_least(int v) {   // smallest 2*odd >= v
   int x = (v + 1) / 2;                 // ceil(v/2)
   if ((x & 1) == 0) x += 1;
   return 2 * x;
 }
-static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static int supported_bins(int K) { return K == 4 || K == 5 || K == 8 || K == 10 || K == 16; }
 
@@ -23,10 +23,10 @@ static int check_cfg(const sbi_amd_nsf_config* c) {
   return 0;
 }
 
-static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad) {
+static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad, int ksteps_fixed) {
   L->out = out;
   L->in = in;
-  L->ksteps = (in + 3) / 4;
+  L->ksteps = ksteps_fixed > 0 ? ksteps_fixed : round_up((in + 3) / 4, 4);
   L->ldk = two_odd_at_least(4 * L->ksteps);
   L->g_w = *g;
   *g += out * in;
@@ -46,6 +46,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->D = D; pl->C = C; pl->H = H; pl->K = K; pl->T = T; pl->NB = NB;
   pl->P = 3 * K - 1;
   pl->PT = (pl->P + 15) / 16;
+  pl->KSH = ((H + 3) / 4 == 13) ? 13 : 16;   // kernels are instantiated for 13 (H=49..52) and 16
   pl->B = cfg->tail_bound;
   pl->min_w = cfg->min_bin_width; pl->min_h = cfg->min_bin_height; pl->min_d = cfg->min_derivative;
   pl->lu_eps = cfg->lu_eps;
@@ -64,22 +65,23 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     s->in0 = s->d_id + C;
     int g = 0, l = 0;
     const int hb = 16 * NSF_HT;
-    set_lin(&s->lin[0], &g, &l, H, s->in0, hb);
+    set_lin(&s->lin[0], &g, &l, H, s->in0, hb, 0);
     for (int b = 0; b < NB; ++b) {
-      set_lin(&s->lin[1 + 3 * b], &g, &l, H, C, hb);
-      set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb);
-      set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb);
+      set_lin(&s->lin[1 + 3 * b], &g, &l, H, C, hb, 0);
+      set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb, pl->KSH);
+      set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb, pl->KSH);
     }
-    set_lin(&s->lin[1 + 3 * NB], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT);
+    set_lin(&s->lin[1 + 3 * NB], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT, pl->KSH);
     s->g_lu = g;
     g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias
     s->n_params = g;
     s->l_U = l; l += D * D;
     s->l_L = l; l += D * D;
     s->l_lub = l; l += D;
-    s->lds_floats = round_up(l + 8, 4);   // slack: last K-step may read past a row end
+    s->lds_floats = round_up(l, 4);
     if (s->lds_floats > pl->lds_w_floats) pl->lds_w_floats = s->lds_floats;
   }
+  pl->img_floats = pl->lds_w_floats;
   int off = 0;
   for (int t = 0; t < T; ++t) {
     pl->g_layer[t] = off;
@@ -92,8 +94,8 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->ZW = two_odd_at_least(D);
   pl->CW = two_odd_at_least(C);
   int d_id_max = pl->shape[0].d_id > pl->shape[1].d_id ? pl->shape[0].d_id : pl->shape[1].d_id;
-  int need = d_id_max + round_up(C, 4);
-  int need2 = round_up(d_id_max + C, 4);
+  int need = d_id_max + 4 * round_up((C + 3) / 4, 4);       // context-layer K-steps read past C
+  int need2 = 4 * round_up((d_id_max + C + 3) / 4, 4);      // initial-layer K-steps
   pl->CINW = two_odd_at_least(need > need2 ? need : need2);
   pl->PSW = two_odd_at_least(16 * pl->PT);
   pl->DS = 16 * pl->PSW + 1;

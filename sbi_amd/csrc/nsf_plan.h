@@ -24,7 +24,9 @@ struct LinDesc {
   int l_w, l_b;   // float offsets inside the LDS weight image
   int out, in;    // natural dims of nn.Linear(in, out)
   int ldk;        // LDS row stride (floats), 2*odd, >= 4*ksteps
-  int ksteps;     // ceil(in / 4) MFMA K-steps
+  int ksteps;     // MFMA K-steps the kernels run: ceil(in/4), rounded up to a multiple of 4
+                  // for the layers whose B operand comes from LDS (initial / context layers)
+                  // and to the compile-time KSH for the hidden->* layers
 };
 
 struct ShapeDesc {   // one per mask parity (even / odd transform index)
@@ -38,6 +40,7 @@ struct ShapeDesc {   // one per mask parity (even / odd transform index)
 
 struct NsfPlan {
   int D, C, H, K, T, NB, P, PT;   // P = 3K-1, PT = ceil(P/16)
+  int KSH;                        // hidden-layer K-steps the kernel template is instantiated for (13 or 16)
   float B, min_w, min_h, min_d, lu_eps, sqrt_h;
   float one_minus_kw, one_minus_kh;   // 1 - min_w*K, 1 - min_h*K
   float d_const;                      // log(exp(1-min_d)-1): boundary derivative pre-activation
@@ -45,6 +48,7 @@ struct NsfPlan {
   ShapeDesc shape[2];
   int g_layer[NSF_MAX_T];
   int n_params;
+  int img_floats;               // floats per layer in the packed weight image (= lds_w_floats)
   int lds_w_floats;             // LDS weight image size (max over parities)
   // per-wave scratch (float offsets relative to the wave's scratch base)
   int ZW, CW, CINW, PSW, DS, DCH;
@@ -55,6 +59,9 @@ struct NsfPlan {
 int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl);
 // Largest nw in {8,4,2,1} (<= nw_max) whose LDS footprint fits 160 KiB.
 int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out);
+// Packed weight image: T consecutive LDS images (img_floats each), written by
+// nsf_pack_kernel from the flat parameters; kernels stage a layer with a float4 copy.
+static inline int64_t nsf_packed_floats(const NsfPlan& pl) { return (int64_t)pl.T * pl.img_floats; }
 static inline int64_t nsf_lds_bytes(const NsfPlan& pl, int nw) {
   return 4ll * ((int64_t)pl.lds_w_floats + (int64_t)nw * pl.sc_total);
 }

@@ -186,6 +186,29 @@ class NSFNet(nn.Module):
 
 
 # --------------------------------------------------------------------- kernel calls
+def packed_weights(net: NSFNet) -> Tensor:
+    """Kernel-side weight image of ``net.flat_params`` (re-packed lazily when the
+    parameter tensor was modified or moved; tracked through its version counter)."""
+    fp = net.flat_params
+    key = (fp.data_ptr(), fp._version, str(fp.device))
+    cache = net.__dict__.get("_packed_cache")
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    dev = _lib.require_device(fp)
+    lib = _lib.load()
+    cfg = net.hyper.c_config()
+    n = lib.sbi_amd_nsf_packed_floats(cfg)
+    if n < 0:
+        _lib.check(int(n), "nsf_packed_floats")
+    packed = cache[1] if (cache is not None and cache[1].device == dev and cache[1].numel() == n) else \
+        torch.empty(int(n), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbi_amd_nsf_pack(cfg, _lib.ptr(fp), _lib.ptr(packed), _lib.current_stream(dev))
+    _lib.check(rc, "nsf_pack")
+    net.__dict__["_packed_cache"] = (key, packed)
+    return packed
+
+
 def _log_prob_call(net: NSFNet, theta: Tensor, x: Tensor, want_noise: bool) -> Tuple[Tensor, Optional[Tensor]]:
     """theta (N,D), x (x_rows,C) -> logp (N,), noise (N,D)|None."""
     dev = _lib.require_device(theta, x, net.flat_params, net.zstats)
@@ -193,10 +216,13 @@ def _log_prob_call(net: NSFNet, theta: Tensor, x: Tensor, want_noise: bool) -> T
     n = theta.shape[0]
     logp = torch.empty(n, dtype=torch.float32, device=dev)
     noise = torch.empty_like(theta) if want_noise else None
+    if n == 0:
+        return logp, noise
+    packed = packed_weights(net)
     cfg = net.hyper.c_config()
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_log_prob(
-            cfg, _lib.ptr(net.flat_params), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
+            cfg, _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
             _lib.ptr(logp), _lib.ptr(noise), _lib.current_stream(dev),
         )
     _lib.check(rc, "nsf_log_prob")
@@ -209,10 +235,13 @@ def _sample_call(net: NSFNet, noise: Tensor, x: Tensor, want_ld: bool) -> Tuple[
     n = noise.shape[0]
     theta = torch.empty_like(noise)
     ld = torch.empty(n, dtype=torch.float32, device=dev) if want_ld else None
+    if n == 0:
+        return theta, ld
     cfg = net.hyper.c_config()
+    packed = packed_weights(net)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_sample(
-            cfg, _lib.ptr(net.flat_params), _lib.ptr(net.zstats), _lib.ptr(noise), _lib.ptr(x), n, x.shape[0],
+            cfg, _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(noise), _lib.ptr(x), n, x.shape[0],
             _lib.ptr(theta), _lib.ptr(ld), _lib.current_stream(dev),
         )
     _lib.check(rc, "nsf_sample")
@@ -233,9 +262,10 @@ def loss_fwd_bwd(net: NSFNet, theta: Tensor, x: Tensor, row_weight: Optional[Ten
         workspace = torch.empty(max(int(need), 1), dtype=torch.float32, device=dev)
     loss = torch.empty(n, dtype=torch.float32, device=dev)
     gtheta = torch.empty_like(theta) if want_grad_theta else None
+    packed = packed_weights(net)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_loss_fwd_bwd(
-            cfg, _lib.ptr(net.flat_params), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
+            cfg, _lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
             _lib.ptr(row_weight), float(uniform_weight), _lib.ptr(loss), _lib.ptr(grad_out), _lib.ptr(gtheta),
             _lib.ptr(workspace), _lib.current_stream(dev),
         )
@@ -292,9 +322,9 @@ class NSFFlow(ConditionalDensityEstimator):
         D = self.input_shape[0]
         theta = input.expand(S, B, D).reshape(S * B, D)
         if cond_has_sample:
-            x = condition.expand(S, B, *self.condition_shape).reshape(S * B, -1)
+            x = condition.expand(S, B, *self.condition_shape).reshape(S * B, self.condition_shape[0])
         else:
-            x = condition.reshape(condition.shape[0], -1)   # (1|B, C): n % x_rows does the broadcast
+            x = condition.reshape(condition.shape[0], self.condition_shape[0])   # (1|B, C): n % x_rows does the broadcast
         return theta.contiguous().float(), x.contiguous().float(), S, B
 
     # -- estimator surface -----------------------------------------------------------
@@ -323,7 +353,7 @@ class NSFFlow(ConditionalDensityEstimator):
         """theta = transform^{-1}(noise | condition); noise (N,D), condition (1|N, C)."""
         with torch.no_grad():
             theta, ld = _sample_call(self.net, noise.contiguous().float(),
-                                     condition.reshape(condition.shape[0], -1).contiguous().float(), with_logabsdet)
+                                     condition.reshape(condition.shape[0], self.condition_shape[0]).contiguous().float(), with_logabsdet)
         return (theta, ld) if with_logabsdet else theta
 
     def sample(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tensor:

@@ -35,7 +35,7 @@ def matched_pair(D=10, C=10, n=1000, perturb=0.05, seed=1, device="cuda", **kw):
     return oracle, est, theta, x
 
 
-def test_inputs(n, D, C, seed=3, spread=1.0):
+def make_inputs(n, D, C, seed=3, spread=1.0):
     """Rows that exercise the spline interior, the linear tails and exact +-bound hits."""
     g = torch.Generator().manual_seed(seed)
     theta = torch.randn(n, D, generator=g) * (0.1**0.5) * spread
