@@ -99,7 +99,7 @@ int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const
  * nflows_flow.py:99-109) and d(sum_n w_n * loss_n)/d params accumulated into
  * grad_out (P floats, OVERWRITTEN), w_n = row_weight[n] or `uniform_weight`
  * when row_weight is NULL (1/B gives the gradient of the batch mean,
- * trainers/base.py:1178-1181).  grad_theta_out (n,D) optional: d loss_n /
+ * trainers/base.py:1178-1181).  grad_theta_out (n,D) optional: w_n * d loss_n /
  * d theta_n (needed by MAP / gradient_ascent, base_posterior.py:216-323).
  * `workspace` must hold sbi_amd_nsf_train_workspace_floats(cfg, n) floats. */
 int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n);

@@ -105,19 +105,15 @@ __device__ __forceinline__ void stage_layer(float* __restrict__ lds, const float
   const float4* __restrict__ src = reinterpret_cast<const float4*>(img);
   float4* dst = reinterpret_cast<float4*>(lds);
   const int n4 = img_floats >> 2;
-  for (int base = 0; base < n4; base += 4 * nthreads) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int idx = base + u * nthreads + tid;
-      if (idx < n4) v[u] = src[idx];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int idx = base + u * nthreads + tid;
-      if (idx < n4) dst[idx] = v[u];
-    }
+  int idx = tid;
+  for (; idx + 3 * nthreads < n4; idx += 4 * nthreads) {
+    const float4 a = src[idx], b = src[idx + nthreads], c = src[idx + 2 * nthreads], d = src[idx + 3 * nthreads];
+    dst[idx] = a;
+    dst[idx + nthreads] = b;
+    dst[idx + 2 * nthreads] = c;
+    dst[idx + 3 * nthreads] = d;
   }
+  for (; idx < n4; idx += nthreads) dst[idx] = src[idx];
 }
 
 // ---- MFMA GEMM pieces ------------------------------------------------------
@@ -184,7 +180,20 @@ __device__ __forceinline__ void gemm_breg(const float* __restrict__ lds, const L
   }
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// ---- VALU math: the spline is issue-bound, so transcendental-heavy pieces use the
+// hardware v_exp_f32 / v_rcp_f32 (1 ulp) with the argument product carried in two
+// floats -- same accuracy class as libm's expf / a correctly rounded divide, a
+// fraction of the instructions.
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float exp_f(float x) {
+  const float L2E = 1.4426950408889634f, L2E_LO = 1.9259629911e-8f;   // log2(e) = hi + lo
+  const float t = x * L2E;
+  float tl = fmaf(x, L2E, -t);
+  tl = fmaf(x, L2E_LO, tl);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, tl * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return rcp_f(1.0f + exp_f(-x)); }
 
 // ResidualNet hidden stack (nflows nn/nets/resnet.py, configuration flow.py:411-419):
 // h = W0 [z_id; c] + b0;  per block: t = W2 relu(W1 relu(h) + b1) + b2; h += t * sigmoid(Wc c + bc)
@@ -258,7 +267,10 @@ __device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds,
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pst[sl * pl.DS + id.j * pl.PSW + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * pt + 4 * r + id.g;
+          if (p < pl.P) pst[sl * pl.DS + id.j * pl.PSW + p] = acc[sl][pt][r];
+        }
     }
   }
 }
@@ -286,16 +298,16 @@ __device__ __forceinline__ void rq_spline(const float* __restrict__ p, float x, 
   float mw = -INFINITY, mh = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    ew[k] = p[k] / pl.sqrt_h;       // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
-    eh[k] = p[K + k] / pl.sqrt_h;
+    ew[k] = p[k] * pl.inv_sqrt_h;   // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
+    eh[k] = p[K + k] * pl.inv_sqrt_h;
     mw = fmaxf(mw, ew[k]);
     mh = fmaxf(mh, eh[k]);
   }
   float sw = 0.f, sh = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    ew[k] = expf(ew[k] - mw);
-    eh[k] = expf(eh[k] - mh);
+    ew[k] = exp_f(ew[k] - mw);
+    eh[k] = exp_f(eh[k] - mh);
     sw += ew[k];
     sh += eh[k];
   }
@@ -304,10 +316,11 @@ __device__ __forceinline__ void rq_spline(const float* __restrict__ p, float x, 
   float cumw = 0.f, cumh = 0.f;
   cw[0] = -B;
   ch[0] = -B;
+  const float nw_ = pl.one_minus_kw * rcp_f(sw), nh_ = pl.one_minus_kh * rcp_f(sh);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    cumw += pl.min_w + pl.one_minus_kw * (ew[k] / sw);
-    cumh += pl.min_h + pl.one_minus_kh * (eh[k] / sh);
+    cumw += fmaf(ew[k], nw_, pl.min_w);
+    cumh += fmaf(eh[k], nh_, pl.min_h);
     cw[k + 1] = (2.f * B) * cumw + (-B);
     ch[k + 1] = (2.f * B) * cumh + (-B);
   }
@@ -335,14 +348,15 @@ __device__ __forceinline__ void rq_spline(const float* __restrict__ p, float x, 
   const float ud_n = (idx == K - 1) ? pl.d_const : p[2 * K + idx];
   const float d_i = pl.min_d + softplus_f(ud_i);
   const float d_n = pl.min_d + softplus_f(ud_n);
-  const float delta = h_i / w_i;
+  const float rw_i = rcp_f(w_i);
+  const float delta = h_i * rw_i;
   float yo, lo;
   if (!INV) {
-    const float th = (x - cw_i) / w_i;
+    const float th = (x - cw_i) * rw_i;
     const float tt = th * (1.f - th);
     const float num = h_i * (delta * (th * th) + d_i * tt);
     const float den = delta + ((d_i + d_n - 2.f * delta) * tt);
-    yo = ch_i + num / den;
+    yo = ch_i + num * rcp_f(den);
     const float omt = 1.f - th;
     const float dnum = (delta * delta) * (d_n * (th * th) + 2.f * delta * tt + d_i * (omt * omt));
     lo = logf(dnum) - 2.f * logf(den);
@@ -353,7 +367,7 @@ __device__ __forceinline__ void rq_spline(const float* __restrict__ p, float x, 
     const float b = h_i * d_i - xc * s;
     const float c = -delta * xc;
     const float disc = b * b - 4.f * a * c;
-    const float root = (2.f * c) / (-b - sqrtf(disc));
+    const float root = (2.f * c) * rcp_f(-b - sqrtf(disc));
     yo = root * w_i + cw_i;
     const float tt = root * (1.f - root);
     const float den = delta + s * tt;

@@ -27,7 +27,10 @@ static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad, i
   L->out = out;
   L->in = in;
   L->ksteps = ksteps_fixed > 0 ? ksteps_fixed : round_up((in + 3) / 4, 4);
-  L->ldk = two_odd_at_least(4 * L->ksteps);
+  // B-from-LDS layers: both operands are zero padded up to 4*ksteps columns.  Hidden-K
+  // layers (B = activation fragments, exact zeros beyond H via the zero row): the
+  // tail K-steps may run into the following row; those weights meet a zero B.
+  L->ldk = two_odd_at_least(ksteps_fixed > 0 ? in : 4 * L->ksteps);
   L->g_w = *g;
   *g += out * in;
   L->g_b = *g;
@@ -51,6 +54,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->min_w = cfg->min_bin_width; pl->min_h = cfg->min_bin_height; pl->min_d = cfg->min_derivative;
   pl->lu_eps = cfg->lu_eps;
   pl->sqrt_h = (float)sqrt((double)H);
+  pl->inv_sqrt_h = (float)(1.0 / sqrt((double)H));
   pl->one_minus_kw = (float)(1.0 - (double)cfg->min_bin_width * K);
   pl->one_minus_kh = (float)(1.0 - (double)cfg->min_bin_height * K);
   pl->d_const = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
@@ -78,7 +82,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     s->l_U = l; l += D * D;
     s->l_L = l; l += D * D;
     s->l_lub = l; l += D;
-    s->lds_floats = round_up(l, 4);
+    s->lds_floats = round_up(l + 64, 4);   // slack: tail K-steps of the last rows read past their row
     if (s->lds_floats > pl->lds_w_floats) pl->lds_w_floats = s->lds_floats;
   }
   pl->img_floats = pl->lds_w_floats;
@@ -97,13 +101,17 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   int need = d_id_max + 4 * round_up((C + 3) / 4, 4);       // context-layer K-steps read past C
   int need2 = 4 * round_up((d_id_max + C + 3) / 4, 4);      // initial-layer K-steps
   pl->CINW = two_odd_at_least(need > need2 ? need : need2);
-  pl->PSW = two_odd_at_least(16 * pl->PT);
-  pl->DS = 16 * pl->PSW + 1;
+  // spline-parameter staging: P (made odd) floats per row => conflict-free per-row reads;
+  // slot stride == 16 (mod 32) puts the second dim slot of a 32-lane half on the other banks
+  pl->PSW = pl->P | 1;
+  pl->DS = 16 * pl->PSW;
+  while ((pl->DS & 31) != 16) pl->DS += 1;
   int o = 0;
   pl->sc_zs = o; o += 16 * pl->ZW;
-  pl->sc_us = o; o += 16 * pl->ZW;
   pl->sc_cs = o; o += 16 * pl->CW;
   pl->sc_cin = o; o += 16 * pl->CINW;
+  pl->sc_us = pl->sc_cin;   // LU temporaries alias the conditioner-input rows (dead by then)
+  if (pl->ZW > pl->CINW) return SBI_AMD_E_UNSUPPORTED;
   pl->sc_pst = o;
   int fixed = o;
   int d_tr_max = pl->shape[0].d_tr;
@@ -111,7 +119,9 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   for (; dch >= 1; --dch) {
     int tot = round_up(fixed + dch * pl->DS, 4);
     if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * tot) <= NSF_LDS_LIMIT_BYTES) {
-      pl->DCH = dch;
+      // balance the chunks: e.g. 5 dims with room for 4 -> (3, 2) instead of (4, 1)
+      int nch = (d_tr_max + dch - 1) / dch;
+      pl->DCH = (d_tr_max + nch - 1) / nch;
       pl->sc_total = tot;
       return 0;
     }

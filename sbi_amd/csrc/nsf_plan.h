@@ -41,7 +41,7 @@ struct ShapeDesc {   // one per mask parity (even / odd transform index)
 struct NsfPlan {
   int D, C, H, K, T, NB, P, PT;   // P = 3K-1, PT = ceil(P/16)
   int KSH;                        // hidden-layer K-steps the kernel template is instantiated for (13 or 16)
-  float B, min_w, min_h, min_d, lu_eps, sqrt_h;
+  float B, min_w, min_h, min_d, lu_eps, sqrt_h, inv_sqrt_h;
   float one_minus_kw, one_minus_kh;   // 1 - min_w*K, 1 - min_h*K
   float d_const;                      // log(exp(1-min_d)-1): boundary derivative pre-activation
   float log_z;                        // 0.5*D*log(2*pi), fp32 (flow.py:1486-1487)

@@ -1,16 +1,858 @@
-// nsf_train.hip -- NPE training pass (loss + gradients); placeholder until the
-// backward kernels land (returns SBI_AMD_E_UNSUPPORTED, loudly, never a fallback).
+// nsf_train.hip -- NPE training pass for the NSF estimator on gfx950:
+//   loss_n = -log p(theta_n | x_n)                       (NFlowsFlow.loss, nflows_flow.py:99-109)
+//   grad   = d( sum_n w_n loss_n ) / d params            (what loss.mean().backward() produces,
+//                                                         trainers/base.py:1178-1181)
+// Structure (DESIGN.md "training pass"):
+//   1. forward flow kernel with the per-transform input state stashed (T*N*D floats);
+//   2. one backward launch per transform, last -> first.  Persistent workgroups of 4
+//      waves walk 64-row tiles: each wave recomputes its 16 rows' conditioner
+//      activations on MFMA (registers), back-propagates spline -> conditioner -> input
+//      on MFMA with the transposed weight image, and the four waves share their
+//      (activation, gradient) tiles through LDS so that every wave accumulates a fixed
+//      quarter of the layer's weight-gradient tiles in registers across all of the
+//      workgroup's rows;
+//   3. a deterministic reduction of the per-workgroup partial gradients (no atomics).
 #include <hip/hip_runtime.h>
-#include "nsf_plan.h"
+#include "nsf_device.h"
+
+#define TR_NW 4            // waves per workgroup
+#define TR_ROWS 64         // rows per tile
+#define TR_MAXCH 4         // spline chunks per transform the accumulators are sized for
+#define TR_GRID_MAX 256    // persistent workgroups (one per CU)
+
+struct TrainPlan {
+  int SA;                  // row stride of the shared staging tiles
+  int o_Ast, o_Bst;        // LDS float offsets of the staging tiles [64][SA]
+  int o_wave, w_total;     // per-wave scratch base / size
+  int w_zs, w_ys, w_gys, w_gxs, w_gzs, w_cs, w_cin, w_us, w_gus;
+  int DCHB, PTW;           // spline dims per chunk, floats per dim slot (16*PT)
+  int nch[2];              // chunks per mask parity
+  int PLP;                 // floats per (workgroup, transform) partial-gradient slab
+  int grid, ntiles;
+  int lds_floats;
+};
+
+static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
+  if (pl.D > 15 || pl.H > 63 || pl.NB < 1 || pl.NB > 2) return SBI_AMD_E_UNSUPPORTED;
+  const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
+  if (d_id_max + pl.C + 1 > 32 || pl.C + 1 > 32) return SBI_AMD_E_UNSUPPORTED;
+  tp->DCHB = 4 / pl.PT;
+  if (tp->DCHB < 1) return SBI_AMD_E_UNSUPPORTED;
+  tp->PTW = 16 * pl.PT;
+  for (int par = 0; par < 2; ++par) {
+    tp->nch[par] = (pl.shape[par].d_tr + tp->DCHB - 1) / tp->DCHB;
+    if (tp->nch[par] > TR_MAXCH) return SBI_AMD_E_UNSUPPORTED;
+  }
+  tp->SA = 68;
+  int o = pl.lds_w_floats;
+  tp->o_Ast = o; o += TR_ROWS * tp->SA;
+  tp->o_Bst = o; o += TR_ROWS * tp->SA;
+  tp->o_wave = o;
+  int w = 0;
+  tp->w_zs = w; w += 16 * pl.ZW;
+  tp->w_ys = w; w += 16 * pl.ZW;
+  tp->w_gys = w; w += 16 * pl.ZW;
+  tp->w_gxs = w; w += 16 * pl.ZW;
+  tp->w_gzs = w; w += 16 * pl.ZW;
+  tp->w_us = w; w += 16 * pl.ZW;
+  tp->w_gus = w; w += 16 * pl.ZW;
+  tp->w_cs = w; w += 16 * pl.CW;
+  tp->w_cin = w; w += 16 * pl.CINW;
+  tp->w_total = (w + 3) / 4 * 4;
+  tp->lds_floats = tp->o_wave + TR_NW * tp->w_total;
+  if (4ll * tp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
+  int pmax = pl.shape[0].n_params > pl.shape[1].n_params ? pl.shape[0].n_params : pl.shape[1].n_params;
+  tp->PLP = (pmax + 1 + 3) / 4 * 4;
+  tp->ntiles = (int)((n + TR_ROWS - 1) / TR_ROWS);
+  tp->grid = tp->ntiles < TR_GRID_MAX ? tp->ntiles : TR_GRID_MAX;
+  return 0;
+}
+
+// ------------------------------------------------------------------ device helpers
+// D-fragment (lane (g,j), tile mt, reg r = feature 16mt+4r+g of row j) -> row-major tile
+__device__ __forceinline__ void stage_D(float* __restrict__ st, int SA, int row, const LaneId& id,
+                                        const f4 (&v)[NSF_HT], bool relu) {
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = v[mt][r];
+      st[row * SA + 16 * mt + 4 * r + id.g] = relu ? fmaxf(a, 0.f) : a;
+    }
+}
+
+// weight-gradient tile(s): acc[nt] += sum_{rows of the 64-row tile} A[row][acol0+i] * B[row][bcol0+16nt+j]
+template <int NT>
+__device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst, int SA,
+                                        int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT) {
+#pragma unroll 4
+  for (int s = 0; s < TR_ROWS / 4; ++s) {
+    const int row = 4 * s + id.g;
+    const float a = Ast[row * SA + acol0 + id.j];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      if (nt < nt_on) acc[nt] = MFMA16(a, Bst[row * SA + bcol0 + 16 * nt + id.j], acc[nt]);
+  }
+}
+
+// row-wise backward through a linear layer: acc[mt] += sum_k W[k][feat(mt)] * g[k], g = D fragments
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                            const f4 (&gb)[NSF_HT], f4 (&acc)[MT]) {
+  int co[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int f = 16 * mt + id.iperm;
+    co[mt] = f < L.in ? f : -1;
+  }
+  const int zero_off = L.l_w + L.out * L.ldk;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + id.g;
+    const int ro = L.l_w + k * L.ldk;
+    const bool kin = k < L.out;
+    const float bv = gb[s >> 2][s & 3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int off = (kin && co[mt] >= 0) ? ro + co[mt] : zero_off;
+      acc[mt] = MFMA16(lds[off], bv, acc[mt]);
+    }
+  }
+}
+
+// final_layer output for the backward chunk -> this wave's rows of the shared A tile
+template <int PT, int KSH>
+__device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ lds, float* __restrict__ arow,
+                                                    const NsfPlan& pl, const TrainPlan& tp, const ShapeDesc& S,
+                                                    const LaneId& id, const f4 (&h)[NSF_HT], int d0) {
+  constexpr int DCHB = 4 / PT;
+  const LinDesc& L = S.lin[1 + 3 * pl.NB];
+  f4 acc[DCHB][PT];
+  int ro[DCHB][PT];
+#pragma unroll
+  for (int sl = 0; sl < DCHB; ++sl) {
+    const int dd = d0 + sl;
+    const bool on = dd < S.d_tr;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = 16 * pt + id.iperm;
+      ro[sl][pt] = L.l_w + ((on && p < pl.P) ? dd * pl.P + p : L.out) * L.ldk + id.g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[sl][pt][r] = on ? lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < KSH; ++s) {
+    const float bv = h[s >> 2][s & 3];
+#pragma unroll
+    for (int sl = 0; sl < DCHB; ++sl)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
+  }
+#pragma unroll
+  for (int sl = 0; sl < DCHB; ++sl)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) arow[id.j * tp.SA + sl * 16 * PT + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+}
+
+// RQ spline forward + reverse-mode gradient for one (row, dim).  `p` holds the 3K-1 raw
+// conditioner outputs on entry and d(gy*y + gl*logabsdet)/d(raw outputs) on exit
+// (entries [3K-1, plen) are zeroed).  Formulas: DESIGN.md "spline backward".
+template <int K>
+__device__ __forceinline__ void rq_spline_fwd_bwd(float* __restrict__ p, int plen, float x, float gy, float gl,
+                                                  const NsfPlan& pl, float& y, float& gx) {
+  const float B = pl.B;
+  const bool inside = (x >= -B) && (x <= B);
+  float ew[K], eh[K];
+  float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    ew[k] = p[k] * pl.inv_sqrt_h;
+    eh[k] = p[K + k] * pl.inv_sqrt_h;
+    mw = fmaxf(mw, ew[k]);
+    mh = fmaxf(mh, eh[k]);
+  }
+  float sw = 0.f, sh = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    ew[k] = exp_f(ew[k] - mw);
+    eh[k] = exp_f(eh[k] - mh);
+    sw += ew[k];
+    sh += eh[k];
+  }
+  const float isw = rcp_f(sw), ish = rcp_f(sh);
+  float cw[K + 1], ch[K + 1];
+  float cumw = 0.f, cumh = 0.f;
+  cw[0] = -B;
+  ch[0] = -B;
+  const float nw_ = pl.one_minus_kw * isw, nh_ = pl.one_minus_kh * ish;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    cumw += fmaf(ew[k], nw_, pl.min_w);
+    cumh += fmaf(eh[k], nh_, pl.min_h);
+    cw[k + 1] = (2.f * B) * cumw + (-B);
+    ch[k + 1] = (2.f * B) * cumh + (-B);
+  }
+  cw[K] = B;
+  ch[K] = B;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) cnt += (x >= cw[k]) ? 1 : 0;
+  cnt += (x >= (cw[K] + 1e-6f)) ? 1 : 0;
+  int idx = cnt - 1;
+  idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
+  float cw_i = cw[0], cw_n = cw[1], ch_i = ch[0], ch_n = ch[1];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const bool hit = (idx == k);
+    cw_i = hit ? cw[k] : cw_i;
+    cw_n = hit ? cw[k + 1] : cw_n;
+    ch_i = hit ? ch[k] : ch_i;
+    ch_n = hit ? ch[k + 1] : ch_n;
+  }
+  const float ud_i = (idx == 0) ? pl.d_const : p[2 * K + idx - 1];
+  const float ud_n = (idx == K - 1) ? pl.d_const : p[2 * K + idx];
+  const float d_i = pl.min_d + softplus_f(ud_i);
+  const float d_n = pl.min_d + softplus_f(ud_n);
+  // ---- forward
+  const float w = cw_n - cw_i, h = ch_n - ch_i;
+  const float rw = rcp_f(w);
+  const float delta = h * rw;
+  const float th = (x - cw_i) * rw;
+  const float omt = 1.f - th;
+  const float tt = th * omt;
+  const float q = delta * (th * th) + d_i * tt;
+  const float num = h * q;
+  const float s = d_i + d_n - 2.f * delta;
+  const float den = delta + s * tt;
+  const float rden = rcp_f(den);
+  const float r = d_n * (th * th) + 2.f * delta * tt + d_i * (omt * omt);
+  y = inside ? (ch_i + num * rden) : x;
+  // ---- reverse
+  float gc = gy;
+  const float gnum = gy * rden;
+  const float gden = -gy * num * rden * rden - 2.f * gl * rden;
+  const float gr = gl * rcp_f(r);
+  float gdelta = 2.f * gl * rcp_f(delta);
+  float gdn = gr * (th * th);
+  float gth = gr * 2.f * d_n * th;
+  gdelta += gr * 2.f * tt;
+  float gt = gr * 2.f * delta;
+  float gdi = gr * (omt * omt);
+  float gomt = gr * 2.f * d_i * omt;
+  gdelta += gden;
+  const float gs = gden * tt;
+  gt += gden * s;
+  gdi += gs;
+  gdn += gs;
+  gdelta -= 2.f * gs;
+  float gh = gnum * q;
+  const float gq = gnum * h;
+  gdelta += gq * (th * th);
+  gth += gq * 2.f * delta * th;
+  gdi += gq * tt;
+  gt += gq * d_i;
+  gth += gt * omt;
+  gomt += gt * th;
+  gth -= gomt;
+  const float gxi = gth * rw;
+  float ga = -gth * rw;
+  float gw = -gth * th * rw;
+  gh += gdelta * rw;
+  gw -= gdelta * delta * rw;
+  const float gf = gh;
+  gc -= gh;
+  const float ge = gw;
+  ga -= gw;
+  gx = inside ? gxi : gy;
+  // ---- knots -> softmax logits
+  const float Gi = (inside && idx >= 1) ? (2.f * B) * ga : 0.f;
+  const float Gn = (inside && idx <= K - 2) ? (2.f * B) * ge : 0.f;
+  const float Hi = (inside && idx >= 1) ? (2.f * B) * gc : 0.f;
+  const float Hn = (inside && idx <= K - 2) ? (2.f * B) * gf : 0.f;
+  float dotw = 0.f, doth = 0.f;
+  float gsw[K], gsh[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const float gwm = (m < idx) ? (Gi + Gn) : ((m == idx) ? Gn : 0.f);
+    const float ghm = (m < idx) ? (Hi + Hn) : ((m == idx) ? Hn : 0.f);
+    ew[m] *= isw;   // softmax probabilities
+    eh[m] *= ish;
+    gsw[m] = pl.one_minus_kw * gwm;
+    gsh[m] = pl.one_minus_kh * ghm;
+    dotw += gsw[m] * ew[m];
+    doth += gsh[m] * eh[m];
+  }
+  const float gudi = (inside && idx >= 1) ? gdi * sigmoid_f(ud_i) : 0.f;
+  const float gudn = (inside && idx <= K - 2) ? gdn * sigmoid_f(ud_n) : 0.f;
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    p[m] = ew[m] * (gsw[m] - dotw) * pl.inv_sqrt_h;
+    p[K + m] = eh[m] * (gsh[m] - doth) * pl.inv_sqrt_h;
+  }
+#pragma unroll
+  for (int k = 0; k < K - 1; ++k) p[2 * K + k] = (k + 1 == idx) ? gudi : ((k == idx) ? gudn : 0.f);
+  for (int k = 3 * K - 1; k < plen; ++k) p[k] = 0.f;
+}
+
+// partial-gradient write-out of one weight tile (lane (g,j), reg r: out = out0+4g+r, in = 16nt+j)
+__device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDesc& L, int out0, int nt,
+                                           const LaneId& id, const f4& acc) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int out = out0 + 4 * id.g + r;
+    const int in = 16 * nt + id.j;
+    if (out < L.out) {
+      if (in < L.in) part[L.g_w + out * L.in + in] = acc[r];
+      else if (in == L.in) part[L.g_b + out] = acc[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward kernel
+// Wave specialisation: waves 0-3 ("row" waves) own 16 rows each and run recompute +
+// row-wise backward; waves 4-7 ("grad" waves) own the weight-gradient accumulators
+// (m-tile = wave-4 of every linear layer) and consume the (gradient, activation) tiles
+// the row waves publish in LDS.  One wave of each kind shares a SIMD, so a row wave's
+// transposed GEMM overlaps its partner's weight-gradient GEMM; both stay under 256 VGPRs.
+template <int K, int KSH, int NB, int NCH>
+__global__ void __launch_bounds__(128 * TR_NW, 2)
+nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const float* __restrict__ packed,
+                     const float* __restrict__ zstats, const float* __restrict__ z_in,
+                     const float* __restrict__ x, const float* __restrict__ gz_up,
+                     const float* __restrict__ row_w, const float uni_w, long long n, long long x_rows,
+                     float* __restrict__ gz_dn, float* __restrict__ partial, float* __restrict__ grad_theta) {
+  constexpr int PT = (3 * K - 1 + 15) / 16;
+  constexpr int DCHB = 4 / PT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const LaneId id = make_lane();
+  const int par = t & 1;
+  const ShapeDesc& S = pl.shape[par];
+  const int D = pl.D, C = pl.C, SA = tp.SA;
+  const bool is_last = (t == pl.T - 1);
+  float* Ast = lds + tp.o_Ast;
+  float* Bst = lds + tp.o_Bst;
+  float* sc = lds + tp.o_wave + wave * tp.w_total;
+  float* zs = sc + tp.w_zs;
+  float* ys = sc + tp.w_ys;
+  float* gys = sc + tp.w_gys;
+  float* gxs = sc + tp.w_gxs;
+  float* gzs = sc + tp.w_gzs;
+  float* us = sc + tp.w_us;
+  float* gus = sc + tp.w_gus;
+  float* cs = sc + tp.w_cs;
+  float* cin = sc + tp.w_cin;
+  const int arow0 = 16 * wave;                 // this wave's rows inside the shared tiles
+  float* Arow = Ast + arow0 * SA;
+  float* Brow = Bst + arow0 * SA;
+  const float* x_mean = zstats + 2 * D;
+  const float* x_std = x_mean + C;
+
+  stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, blockDim.x);
+
+  const LinDesc& L0 = S.lin[0];
+  const LinDesc& LF = S.lin[1 + 3 * NB];
+  const int nch = tp.nch[par];
+  const int nt0 = (S.in0 + 1 + 15) / 16;        // n-tiles of d W0 (incl. the bias column)
+  const int ntc = (C + 1 + 15) / 16;
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  if (wave < TR_NW) {
+    // =========================== row waves ===========================
+    const LaneId id0 = id;
+    for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
+      // Re-materialise the lane coordinates per tile: otherwise LICM hoists every
+      // lane-dependent LDS address of the body out of the persistent loop and the
+      // kernel drowns in live registers (hundreds of spills).
+      LaneId id = id0;
+      asm volatile("" : "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
+      const long long row = (long long)tile * TR_ROWS + arow0 + id.j;
+      const bool valid = row < n;
+      const float wn = valid ? (row_w ? row_w[row] : uni_w) : 0.f;
+      const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
+      __syncthreads();                             // weights staged / previous tile's shared reads done
+      // ---- P0: load state, context, upstream gradient
+      {
+        const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
+        for (int d = id.g; d < D; d += 4) {
+          zs[id.j * pl.ZW + d] = valid ? z_in[row * D + d] : 0.f;
+          float gz = valid ? gz_up[row * D + d] : 0.f;
+          gzs[id.j * pl.ZW + d] = is_last ? wn * gz : gz;   // last transform: d/dz_T of w*(0.5|z|^2) = w z
+        }
+        for (int c = id.g; c < C; c += 4) {
+          float v = valid ? x[xr * C + c] : 0.f;
+          cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
+        }
+      }
+      wave_lds_fence();
+      // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
+      for (int k = id.g; k < D; k += 4) {
+        float a = 0.f;
+        for (int i = k; i < D; ++i) a += lds[S.l_L + i * D + k] * gzs[id.j * pl.ZW + i];
+        gus[id.j * pl.ZW + k] = a;
+      }
+      wave_lds_fence();
+      for (int k = id.g; k < D; k += 4) {
+        float a = 0.f;
+        for (int i = 0; i <= k; ++i) a += lds[S.l_U + i * D + k] * gus[id.j * pl.ZW + i];
+        gys[id.j * pl.ZW + k] = a;
+        gxs[id.j * pl.ZW + k] = a;                 // identity dims pass through (transformed dims overwritten)
+        ys[id.j * pl.ZW + k] = zs[id.j * pl.ZW + k];
+      }
+      build_cin(pl, S, par, id, zs, cs, cin);
+      const float* cin_row = cin + id.j * pl.CINW + id.g;
+
+      // ---- P1: recompute the conditioner's hidden stack; keep the block inputs h_0..h_NB
+      // (the per-block temporaries are recomputed again in P3 to stay inside 512 registers)
+      f4 hpre[NB + 1][NSF_HT];
+      acc_init_bias(lds, L0, id, hpre[0]);
+      gemm_blds(lds, L0, id, cin_row, hpre[0]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        f4 rl[NSF_HT], t1[NSF_HT], sg[NSF_HT];
+        acc_init_bias(lds, S.lin[1 + 3 * b], id, sg);
+        gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, sg);
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(hpre[b][mt][r], 0.f);
+        acc_init_bias(lds, S.lin[2 + 3 * b], id, t1);
+        gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(t1[mt][r], 0.f);
+        acc_init_bias(lds, S.lin[3 + 3 * b], id, t1);
+        gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t1);
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hpre[b + 1][mt][r] = hpre[b][mt][r] + t1[mt][r] * sigmoid_f(sg[mt][r]);
+      }
+
+      // ---- P2: final layer + spline, chunk by chunk; d Wf; g_h = Wf^T g_p
+      stage_D(Bst, SA, arow0 + id.j, id, hpre[NB], false);
+      if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;      // bias column
+      f4 gh[NSF_HT];
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c < nch) {
+          const int d0 = c * DCHB;
+          final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);
+          wave_lds_fence();
+          if (id.g < DCHB) {
+            const int dd = d0 + id.g;
+            float* pp = Arow + id.j * SA + id.g * tp.PTW;
+            if (dd < S.d_tr) {
+              const int zi = id.j * pl.ZW + 2 * dd + par;
+              float yv, gxv;
+              rq_spline_fwd_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, yv, gxv);
+              ys[zi] = yv;
+              gxs[zi] = gxv;
+            } else {
+              for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;
+            }
+          }
+          __syncthreads();
+          // g_h += Wf[chunk rows]^T g_p   (own rows; B operand from the shared A tile)
+          {
+            int co[NSF_HT];
+#pragma unroll
+            for (int mt = 0; mt < NSF_HT; ++mt) {
+              const int f = 16 * mt + id.iperm;
+              co[mt] = f < LF.in ? f : -1;
+            }
+            const int zero_off = LF.l_w + LF.out * LF.ldk;
+#pragma unroll
+            for (int sl = 0; sl < DCHB; ++sl) {
+              const int dd = d0 + sl;
+              if (dd < S.d_tr) {
+#pragma unroll
+                for (int s = 0; s < 4 * PT; ++s) {
+                  const int pq = 4 * s + id.g;
+                  const bool kin = pq < pl.P;
+                  const int ro = LF.l_w + (dd * pl.P + pq) * LF.ldk;
+                  const float bv = Arow[id.j * SA + sl * 16 * PT + pq];
+#pragma unroll
+                  for (int mt = 0; mt < NSF_HT; ++mt) {
+                    const int off = (kin && co[mt] >= 0) ? ro + co[mt] : zero_off;
+                    gh[mt] = MFMA16(lds[off], bv, gh[mt]);
+                  }
+                }
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+
+      // ---- P3: residual blocks, last -> first
+#pragma unroll
+      for (int b = NB - 1; b >= 0; --b) {
+        f4 ga[NSF_HT], gc[NSF_HT], gb[NSF_HT], t1[NSF_HT];
+        {
+          // recompute this block's temporaries from h_b: sg = sigmoid(Wc c + bc), t1, t2
+          f4 sg[NSF_HT], t2[NSF_HT], rl[NSF_HT];
+          acc_init_bias(lds, S.lin[1 + 3 * b], id, sg);
+          gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, sg);
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(hpre[b][mt][r], 0.f);
+          acc_init_bias(lds, S.lin[2 + 3 * b], id, t1);
+          gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(t1[mt][r], 0.f);
+          acc_init_bias(lds, S.lin[3 + 3 * b], id, t2);
+          gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t2);
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sgm = sigmoid_f(sg[mt][r]);
+              ga[mt][r] = gh[mt][r] * sgm;                                // d t2
+              gc[mt][r] = gh[mt][r] * t2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
+            }
+        }
+        // d W2 : A = g_t2, B = relu(t1)
+        stage_D(Ast, SA, arow0 + id.j, id, ga, false);
+        stage_D(Bst, SA, arow0 + id.j, id, t1, true);
+        if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb);       // d relu(t1)
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ga[mt][r] = t1[mt][r] > 0.f ? gb[mt][r] : 0.f;   // d t1
+        // d W1 : A = g_t1, B = relu(h_b)
+        stage_D(Ast, SA, arow0 + id.j, id, ga, false);
+        stage_D(Bst, SA, arow0 + id.j, id, hpre[b], true);
+        if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb);       // d relu(h_b)
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gh[mt][r] += hpre[b][mt][r] > 0.f ? gb[mt][r] : 0.f;
+        // d Wc : A = g_c, B = standardized context
+        stage_D(Ast, SA, arow0 + id.j, id, gc, false);
+        for (int k = id.g; k < 16 * ntc; k += 4)
+          Brow[id.j * SA + k] = k < C ? cs[id.j * pl.CW + k] : (k == C ? 1.f : 0.f);
+        __syncthreads();
+        __syncthreads();
+      }
+
+      // ---- P4: initial layer
+      stage_D(Ast, SA, arow0 + id.j, id, gh, false);
+      for (int k = id.g; k < 16 * nt0; k += 4)
+        Brow[id.j * SA + k] = k < S.in0 ? cin[id.j * pl.CINW + k] : (k == S.in0 ? 1.f : 0.f);
+      __syncthreads();
+      {
+        f4 gin[1];
+        gin[0] = zero4;
+        gemm_T_breg<KSH, 1>(lds, L0, id, gh, gin);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 4 * r + id.g;     // identity feature slot
+          if (k < S.d_id) gxs[id.j * pl.ZW + 2 * k + (1 - par)] += gin[0][r];
+        }
+      }
+      __syncthreads();
+
+      // ---- P5: LULinear parameter gradients as two more 16x16 tiles
+      for (int i = id.g; i < D; i += 4) {
+        float a = 0.f;
+        for (int k = i; k < D; ++k) a += lds[S.l_U + i * D + k] * ys[id.j * pl.ZW + k];
+        us[id.j * pl.ZW + i] = a;
+      }
+      wave_lds_fence();
+      for (int k = id.g; k < 16; k += 4) {
+        const int o = id.j * pl.ZW + k;
+        Arow[id.j * SA + k] = k < D ? gus[o] : (k == D ? gld : 0.f);
+        Arow[id.j * SA + 16 + k] = k < D ? gzs[o] : 0.f;
+        Brow[id.j * SA + k] = k < D ? ys[o] : (k == D ? 1.f : 0.f);
+        Brow[id.j * SA + 16 + k] = k < D ? us[o] : (k == D ? 1.f : 0.f);
+      }
+      __syncthreads();
+
+      // ---- P6: gradient wrt this transform's input
+      for (int d = id.g; d < D; d += 4) {
+        if (valid) {
+          const float g = gxs[id.j * pl.ZW + d];
+          if (t > 0) gz_dn[row * D + d] = g;
+          else if (grad_theta) grad_theta[row * D + d] = g * zstats[D + d];
+        }
+      }
+    }
+
+  } else {
+    // =========================== grad waves ==========================
+    const int gw = wave - TR_NW;
+    // weight-gradient accumulators owned by this wave (m-tile = wave) for the whole launch
+    f4 acc0[2], accC[NB][2], acc1[NB][4], acc2[NB][4], accF[NCH][4], accLU[1];
+  #pragma unroll
+    for (int i = 0; i < 2; ++i) acc0[i] = zero4;
+  #pragma unroll
+    for (int b = 0; b < NB; ++b) {
+  #pragma unroll
+      for (int i = 0; i < 2; ++i) accC[b][i] = zero4;
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) { acc1[b][i] = zero4; acc2[b][i] = zero4; }
+    }
+  #pragma unroll
+    for (int c = 0; c < NCH; ++c)
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) accF[c][i] = zero4;
+    accLU[0] = zero4;
+
+
+    const LaneId id0 = id;
+    for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
+      LaneId id = id0;
+      asm volatile("" : "+v"(id.j), "+v"(id.g));
+      // mirrors the row waves' barrier sequence exactly
+      __syncthreads();
+  #pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c < nch) {
+          __syncthreads();
+          dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, accF[c]);
+          __syncthreads();
+        }
+      }
+  #pragma unroll
+      for (int b = NB - 1; b >= 0; --b) {
+        __syncthreads();
+        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc2[b]);
+        __syncthreads();
+        __syncthreads();
+        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[b]);
+        __syncthreads();
+        __syncthreads();
+        dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc);
+        __syncthreads();
+      }
+      __syncthreads();
+      dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, acc0, nt0);
+      __syncthreads();
+      __syncthreads();
+      if (gw < 2) dw_gemm<1>(Ast, Bst, SA, 16 * gw, 16 * gw, id, accLU);
+    }
+
+    // ---- write this workgroup's partial gradients (natural parameter order)
+    float* part = partial + ((long long)t * gridDim.x + blockIdx.x) * tp.PLP;
+    const int out0 = 16 * gw;
+  #pragma unroll
+    for (int nt = 0; nt < 2; ++nt) write_tile(part, L0, out0, nt, id, acc0[nt]);
+  #pragma unroll
+    for (int b = 0; b < NB; ++b) {
+  #pragma unroll
+      for (int nt = 0; nt < 2; ++nt) write_tile(part, S.lin[1 + 3 * b], out0, nt, id, accC[b][nt]);
+  #pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        write_tile(part, S.lin[2 + 3 * b], out0, nt, id, acc1[b][nt]);
+        write_tile(part, S.lin[3 + 3 * b], out0, nt, id, acc2[b][nt]);
+      }
+    }
+  #pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c < nch) {
+        const int dd = c * DCHB + gw / PT;
+        const int pt = gw % PT;
+        if (gw < DCHB * PT && dd < S.d_tr) {
+  #pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p = 16 * pt + 4 * id.g + r;
+              const int in = 16 * nt + id.j;
+              if (p < pl.P) {
+                const int out = dd * pl.P + p;
+                if (in < LF.in) part[LF.g_w + out * LF.in + in] = accF[c][nt][r];
+                else if (in == LF.in) part[LF.g_b + out] = accF[c][nt][r];
+              }
+            }
+        }
+      }
+    }
+    {
+      const int ntri = D * (D - 1) / 2;
+      float* plow = part + S.g_lu;
+      float* pup = plow + ntri;
+      float* pdiag = pup + ntri;
+      float* pbias = pdiag + D;
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * id.g + r, k = id.j;
+        const float v = accLU[0][r];
+        if (gw == 0) {
+          if (i < D && k < D) {
+            if (k > i) pup[i * D - i * (i + 1) / 2 + (k - i - 1)] = v;
+            else if (k == i) pdiag[i] = v;          // dL/dU_ii; chain rule finished in the reduction
+          } else if (i == D && k == D) part[S.n_params] = v;   // sum_n d/d(logabsdet)
+        } else if (gw == 1) {
+          if (i < D) {
+            if (k < i) plow[i * (i - 1) / 2 + k] = v;
+            else if (k == D) pbias[i] = v;
+          }
+        }
+      }
+    }
+
+  }
+}
+
+// grad[p] = sum over workgroups of the partial slabs (fixed order => deterministic);
+// finishes LULinear's diagonal: d/d(unconstrained_upper_diag_i) =
+//   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i)
+__global__ void __launch_bounds__(256)
+nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __restrict__ params,
+                       const float* __restrict__ partial, float* __restrict__ grad) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pl.n_params) return;
+  int t = 0;
+  while (t + 1 < pl.T && idx >= pl.g_layer[t + 1]) ++t;
+  const ShapeDesc& S = pl.shape[t & 1];
+  const int li = idx - pl.g_layer[t];
+  const float* base = partial + (long long)t * tp.grid * tp.PLP;
+  float a = 0.f;
+  for (int w = 0; w < tp.grid; ++w) a += base[(long long)w * tp.PLP + li];
+  const int ntri = pl.D * (pl.D - 1) / 2;
+  const int d0 = S.g_lu + 2 * ntri;
+  if (li >= d0 && li < d0 + pl.D) {
+    float sgl = 0.f;
+    for (int w = 0; w < tp.grid; ++w) sgl += base[(long long)w * tp.PLP + S.n_params];
+    const float ud = params[idx];
+    const float uii = softplus_f(ud) + pl.lu_eps;
+    a = (a + sgl / uii) * (1.f / (1.f + expf(-ud)));
+  }
+  grad[idx] = a;
+}
+
+__global__ void neg_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = -in[i];
+}
+
+// ------------------------------------------------------------------ host side
+int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
+                       const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
+                       float* z_stash, void* stream);
+
+static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int64_t* o_stash, int64_t* o_noise,
+                         int64_t* o_logp, int64_t* o_gza, int64_t* o_gzb, int64_t* o_part) {
+  int64_t o = 0;
+  *o_stash = o; o += (int64_t)pl.T * n * pl.D;
+  *o_noise = o; o += n * pl.D;
+  *o_logp = o; o += (n + 3) / 4 * 4;
+  *o_gza = o; o += n * pl.D;
+  *o_gzb = o; o += n * pl.D;
+  o = (o + 3) / 4 * 4;
+  *o_part = o; o += (int64_t)pl.T * tp.grid * tp.PLP;
+  return o;
+}
 
 extern "C" int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n) {
-  (void)cfg; (void)n;
-  return SBI_AMD_E_UNSUPPORTED;
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, TR_NW, &pl);
+  if (rc) return rc;
+  TrainPlan tp;
+  rc = build_train_plan(pl, n > 0 ? n : 1, &tp);
+  if (rc) return rc;
+  int64_t a, b, c, d, e, f;
+  return ws_layout(pl, tp, n > 0 ? n : 1, &a, &b, &c, &d, &e, &f);
 }
+
+template <int K, int KSH, int NB, int NCH>
+static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
+                      const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
+                      int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta, hipStream_t st) {
+  auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH>;
+  const int lds_bytes = 4 * tp.lds_floats;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(tp.grid), dim3(128 * TR_NW), (size_t)lds_bytes, st, pl, tp, t, packed, zstats, z_in, x,
+                     gz_up, row_w, uni_w, (long long)n, (long long)x_rows, gz_dn, partial, grad_theta);
+  return (int)hipGetLastError();
+}
+
+template <int K>
+static int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
+                        const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
+                        int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
+                        hipStream_t st) {
+#define BWD_ARGS pl, tp, t, packed, zstats, z_in, x, gz_up, row_w, uni_w, n, x_rows, gz_dn, partial, grad_theta, st
+  const int nchmax = tp.nch[0] > tp.nch[1] ? tp.nch[0] : tp.nch[1];
+#define BWD_NCH(KS, NBV) \
+  switch (nchmax) { \
+    case 1: return launch_bwd<K, KS, NBV, 1>(BWD_ARGS); \
+    case 2: case 3: return launch_bwd<K, KS, NBV, 3>(BWD_ARGS); \
+    default: return launch_bwd<K, KS, NBV, 4>(BWD_ARGS); \
+  }
+  if (pl.KSH == 13) { if (pl.NB == 1) { BWD_NCH(13, 1) } else { BWD_NCH(13, 2) } }
+  if (pl.NB == 1) { BWD_NCH(16, 1) } else { BWD_NCH(16, 2) }
+#undef BWD_NCH
+#undef BWD_ARGS
+}
+
 extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
-                                        const float* zstats,
-                                        const float* theta, const float* x, int64_t n, int64_t x_rows,
-                                        const float* row_weight, float uniform_weight, float* loss_out,
-                                        float* grad_out, float* grad_theta_out, float* workspace, void* stream) {
-  return SBI_AMD_E_UNSUPPORTED;
+                                        const float* zstats, const float* theta, const float* x, int64_t n,
+                                        int64_t x_rows, const float* row_weight, float uniform_weight,
+                                        float* loss_out, float* grad_out, float* grad_theta_out, float* workspace,
+                                        void* stream) {
+  if (!cfg || !params || !packed || !zstats || !theta || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
+    return SBI_AMD_E_BADARG;
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, TR_NW, &pl);
+  if (rc) return rc;
+  TrainPlan tp;
+  rc = build_train_plan(pl, n, &tp);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part;
+  ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part);
+  float* stash = workspace + o_stash;
+  float* noise = workspace + o_noise;
+  float* logp = workspace + o_logp;
+  float* gz[2] = {workspace + o_gza, workspace + o_gzb};
+  float* partial = workspace + o_part;
+
+  rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, logp, noise, stash, stream);
+  if (rc) return rc;
+  if (loss_out) {
+    hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logp, loss_out,
+                       (long long)n);
+  }
+  for (int t = pl.T - 1; t >= 0; --t) {
+    const float* up = (t == pl.T - 1) ? noise : gz[(t + 1) & 1];
+    float* dn = gz[t & 1];
+    const float* z_in = stash + (int64_t)t * n * pl.D;
+    switch (cfg->K) {
+#define CASE_K(KK) \
+  case KK: rc = launch_bwd_k<KK>(pl, tp, t, packed, zstats, z_in, x, up, row_weight, uniform_weight, n, x_rows, dn, \
+                                 partial, grad_theta_out, st); break;
+      CASE_K(10)
+#undef CASE_K
+      default: rc = SBI_AMD_E_UNSUPPORTED;
+    }
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 255) / 256), dim3(256), 0, st, pl, tp, params,
+                     partial, grad_out);
+  return (int)hipGetLastError();
 }

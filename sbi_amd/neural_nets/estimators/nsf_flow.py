@@ -291,8 +291,7 @@ class _NSFLogProbFn(torch.autograd.Function):
         gparams = torch.empty_like(net.flat_params)
         w = (-grad_logp).contiguous().to(torch.float32)
         _, gtheta = loss_fwd_bwd(net, theta, x, w, 0.0, gparams, want_grad_theta=ctx.needs_input_grad[0])
-        if gtheta is not None:
-            gtheta = gtheta * w.unsqueeze(1)   # kernel returns d loss_n / d theta_n (unweighted)
+        # kernel gradients are already weighted by w_n = -dL/dlogp_n
         return gtheta, None, (gparams if ctx.needs_input_grad[2] else None), None
 
 
