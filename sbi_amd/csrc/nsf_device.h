@@ -85,6 +85,7 @@ __device__ __forceinline__ void pack_lu(float* __restrict__ img, const float* __
   for (int idx = tid; idx < D; idx += nthreads) img[S.l_lub + idx] = bias[idx];
 }
 
+// (tid, nthreads) may span several workgroups: tid = blockIdx.y*blockDim.x + threadIdx.x
 __device__ __forceinline__ void pack_layer(float* __restrict__ img, const float* __restrict__ gl,
                                            const NsfPlan& pl, const ShapeDesc& S, int tid, int nthreads) {
   const int hb = 16 * NSF_HT;
@@ -226,52 +227,57 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
   }
 }
 
-// final_layer for the spline dims [d0, d0+DCH) -> per-wave LDS staging pst[slot][row][param]
-template <int PT, int KSH>
-__device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds, float* __restrict__ pst,
-                                                  const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
-                                                  const f4 (&h)[NSF_HT], int d0) {
+// final_layer for the spline dims [d0, d0+NACT) -> per-wave LDS staging pst[slot][row][param].
+// NACT (active dim slots of this chunk) is a template parameter so the K loop is one
+// branch-free stream of MFMAs the scheduler can software-pipeline.
+template <int PT, int KSH, int NACT>
+__device__ __forceinline__ void final_layer_chunk_n(const float* __restrict__ lds, float* __restrict__ pst,
+                                                    const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
+                                                    const f4 (&h)[NSF_HT], int d0) {
   const LinDesc& L = S.lin[1 + 3 * pl.NB];
-  f4 acc[NSF_MAX_DCH][PT];
-  int ro[NSF_MAX_DCH][PT];
+  f4 acc[NACT][PT];
+  int ro[NACT][PT];
 #pragma unroll
-  for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
+  for (int sl = 0; sl < NACT; ++sl) {
     const int dd = d0 + sl;
-    const bool on = (sl < pl.DCH) && (dd < S.d_tr);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int p = 16 * pt + id.iperm;
-      ro[sl][pt] = L.l_w + ((on && p < pl.P) ? dd * pl.P + p : L.out) * L.ldk + id.g;
+      ro[sl][pt] = L.l_w + ((p < pl.P) ? dd * pl.P + p : L.out) * L.ldk + id.g;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[sl][pt][r] = on ? lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g] : 0.f;
+      for (int r = 0; r < 4; ++r) acc[sl][pt][r] = lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g];
     }
   }
-  // wave-uniform count of active dim slots in this chunk
-  int nact = S.d_tr - d0;
-  nact = nact < pl.DCH ? nact : pl.DCH;
 #pragma unroll
   for (int s = 0; s < KSH; ++s) {
     const float bv = h[s >> 2][s & 3];
 #pragma unroll
-    for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
-      if (sl < nact) {
+    for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
-      }
-    }
+      for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
   }
 #pragma unroll
-  for (int sl = 0; sl < NSF_MAX_DCH; ++sl) {
-    if (sl < pl.DCH && d0 + sl < S.d_tr) {
+  for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = 16 * pt + 4 * r + id.g;
-          if (p < pl.P) pst[sl * pl.DS + id.j * pl.PSW + p] = acc[sl][pt][r];
-        }
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int p = 16 * pt + 4 * r + id.g;
+        if (p < pl.P) pst[sl * pl.DS + id.j * pl.PSW + p] = acc[sl][pt][r];
+      }
+}
+
+template <int PT, int KSH>
+__device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds, float* __restrict__ pst,
+                                                  const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
+                                                  const f4 (&h)[NSF_HT], int d0) {
+  int nact = S.d_tr - d0;
+  nact = nact < pl.DCH ? nact : pl.DCH;
+  switch (nact) {   // wave-uniform
+    case 1: final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, d0); break;
+    case 2: final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, d0); break;
+    case 3: final_layer_chunk_n<PT, KSH, 3>(lds, pst, pl, S, id, h, d0); break;
+    default: final_layer_chunk_n<PT, KSH, 4>(lds, pst, pl, S, id, h, d0); break;
   }
 }
 

@@ -13,8 +13,8 @@
 __global__ void __launch_bounds__(512)
 nsf_pack_kernel(const NsfPlan pl, const float* __restrict__ params, float* __restrict__ packed) {
   const int t = blockIdx.x;
-  pack_layer(packed + (long long)t * pl.img_floats, params + pl.g_layer[t], pl, pl.shape[t & 1], threadIdx.x,
-             blockDim.x);
+  pack_layer(packed + (long long)t * pl.img_floats, params + pl.g_layer[t], pl, pl.shape[t & 1],
+             blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
 }
 
 template <int K, int KSH, bool INV>
@@ -68,27 +68,29 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     const int par = t & 1;
     const ShapeDesc& S = pl.shape[par];
     __syncthreads();   // every wave is done with the previous layer's weights
-    stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
+    if (!(pl.ablate & 16) || li == 0)
+      stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
     __syncthreads();
 
     if (!INV && z_stash) {
       for (int d = id.g; d < D; d += 4)
         if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
     }
-    if (INV) {
+    if (INV && !(pl.ablate & 8)) {
       lu_inverse(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
     build_cin(pl, S, par, id, zs, cs, cin);
 
     f4 h[NSF_HT];
-    conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
+    if (!(pl.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
+    else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
     for (int d0 = 0; d0 < S.d_tr; d0 += pl.DCH) {
-      final_layer_chunk<PT, KSH>(lds, pst, pl, S, id, h, d0);
+      if (!(pl.ablate & 2)) final_layer_chunk<PT, KSH>(lds, pst, pl, S, id, h, d0);
       wave_lds_fence();
       const int dd = d0 + id.g;
-      if (id.g < pl.DCH && dd < S.d_tr) {
+      if (id.g < pl.DCH && dd < S.d_tr && !(pl.ablate & 1)) {
         const int zi = id.j * pl.ZW + 2 * dd + par;
         float y, ld;
         rq_spline<K, INV>(pst + id.g * pl.DS + id.j * pl.PSW, zs[zi], pl, y, ld);
@@ -97,7 +99,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       }
       wave_lds_fence();
     }
-    if (!INV) {
+    if (!INV && !(pl.ablate & 8)) {
       lu_forward(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
     }
@@ -193,7 +195,7 @@ extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* para
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, 1, &pl);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
-  hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T), dim3(512), 0, (hipStream_t)stream, pl, params, packed);
+  hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
   return (int)hipGetLastError();
 }
 

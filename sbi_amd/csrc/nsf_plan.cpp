@@ -2,6 +2,7 @@
 #include "nsf_plan.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -59,6 +60,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->one_minus_kh = (float)(1.0 - (double)cfg->min_bin_height * K);
   pl->d_const = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
   pl->log_z = (float)(0.5 * D * log(2.0 * M_PI));
+  { const char* a = getenv("SBI_AMD_ABLATE"); pl->ablate = a ? atoi(a) : 0; }
 
   for (int par = 0; par < 2; ++par) {
     ShapeDesc* s = &pl->shape[par];

@@ -53,6 +53,7 @@ struct NsfPlan {
   // per-wave scratch (float offsets relative to the wave's scratch base)
   int ZW, CW, CINW, PSW, DS, DCH;
   int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_total;
+  int ablate;                   // debug/timing only (env SBI_AMD_ABLATE): skip phases, results invalid
 };
 
 // Builds the plan for nw waves per workgroup; returns 0 or SBI_AMD_E_*.

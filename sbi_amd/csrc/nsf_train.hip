@@ -84,7 +84,9 @@ __device__ __forceinline__ void stage_D(float* __restrict__ st, int SA, int row,
 // weight-gradient tile(s): acc[nt] += sum_{rows of the 64-row tile} A[row][acol0+i] * B[row][bcol0+16nt+j]
 template <int NT>
 __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst, int SA,
-                                        int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT) {
+                                        int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT,
+                                        int abl = 0) {
+  if (abl & 1) return;
 #pragma unroll 4
   for (int s = 0; s < TR_ROWS / 4; ++s) {
     const int row = 4 * s + id.g;
@@ -98,7 +100,8 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
 // row-wise backward through a linear layer: acc[mt] += sum_k W[k][feat(mt)] * g[k], g = D fragments
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
-                                            const f4 (&gb)[NSF_HT], f4 (&acc)[MT]) {
+                                            const f4 (&gb)[NSF_HT], f4 (&acc)[MT], int abl = 0) {
+  if (abl & 2) return;
   int co[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -422,13 +425,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(hpre[b][mt][r], 0.f);
         acc_init_bias(lds, S.lin[2 + 3 * b], id, t1);
-        gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
+        if (!(pl.ablate & 16)) gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(t1[mt][r], 0.f);
         acc_init_bias(lds, S.lin[3 + 3 * b], id, t1);
-        gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t1);
+        if (!(pl.ablate & 16)) gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t1);
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -445,12 +448,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       for (int c = 0; c < NCH; ++c) {
         if (c < nch) {
           const int d0 = c * DCHB;
-          final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);
+          if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);
           wave_lds_fence();
           if (id.g < DCHB) {
             const int dd = d0 + id.g;
             float* pp = Arow + id.j * SA + id.g * tp.PTW;
-            if (dd < S.d_tr) {
+            if (dd < S.d_tr && !(pl.ablate & 4)) {
               const int zi = id.j * pl.ZW + 2 * dd + par;
               float yv, gxv;
               rq_spline_fwd_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, yv, gxv);
@@ -462,7 +465,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           }
           __syncthreads();
           // g_h += Wf[chunk rows]^T g_p   (own rows; B operand from the shared A tile)
-          {
+          if (!(pl.ablate & 2)) {
             int co[NSF_HT];
 #pragma unroll
             for (int mt = 0; mt < NSF_HT; ++mt) {
@@ -501,19 +504,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           // recompute this block's temporaries from h_b: sg = sigmoid(Wc c + bc), t1, t2
           f4 sg[NSF_HT], t2[NSF_HT], rl[NSF_HT];
           acc_init_bias(lds, S.lin[1 + 3 * b], id, sg);
-          gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, sg);
+          if (!(pl.ablate & 8)) gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, sg);
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(hpre[b][mt][r], 0.f);
           acc_init_bias(lds, S.lin[2 + 3 * b], id, t1);
-          gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
+          if (!(pl.ablate & 8)) gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(t1[mt][r], 0.f);
           acc_init_bias(lds, S.lin[3 + 3 * b], id, t2);
-          gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t2);
+          if (!(pl.ablate & 8)) gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t2);
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -530,7 +533,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb);       // d relu(t1)
+        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb, pl.ablate);       // d relu(t1)
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
@@ -543,7 +546,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb);       // d relu(h_b)
+        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb, pl.ablate);       // d relu(h_b)
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
@@ -565,7 +568,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       {
         f4 gin[1];
         gin[0] = zero4;
-        gemm_T_breg<KSH, 1>(lds, L0, id, gh, gin);
+        gemm_T_breg<KSH, 1>(lds, L0, id, gh, gin, pl.ablate);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 4 * r + id.g;     // identity feature slot
@@ -631,24 +634,24 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       for (int c = 0; c < NCH; ++c) {
         if (c < nch) {
           __syncthreads();
-          dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, accF[c]);
+          dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, accF[c], 4, pl.ablate);
           __syncthreads();
         }
       }
   #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
         __syncthreads();
-        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc2[b]);
+        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
         __syncthreads();
         __syncthreads();
-        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[b]);
+        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
         __syncthreads();
         __syncthreads();
-        dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc);
+        dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc, pl.ablate);
         __syncthreads();
       }
       __syncthreads();
-      dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, acc0, nt0);
+      dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       __syncthreads();
       __syncthreads();
       if (gw < 2) dw_gemm<1>(Ast, Bst, SA, 16 * gw, 16 * gw, id, accLU);
@@ -720,7 +723,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 // grad[p] = sum over workgroups of the partial slabs (fixed order => deterministic);
 // finishes LULinear's diagonal: d/d(unconstrained_upper_diag_i) =
 //   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __restrict__ params,
                        const float* __restrict__ partial, float* __restrict__ grad) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -730,8 +733,15 @@ nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __rest
   const ShapeDesc& S = pl.shape[t & 1];
   const int li = idx - pl.g_layer[t];
   const float* base = partial + (long long)t * tp.grid * tp.PLP;
-  float a = 0.f;
-  for (int w = 0; w < tp.grid; ++w) a += base[(long long)w * tp.PLP + li];
+  // 8 independent partial sums keep 8 loads in flight (fixed association => deterministic)
+  float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int w = 0;
+  for (; w + 8 <= tp.grid; w += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] += base[(long long)(w + u) * tp.PLP + li];
+  }
+  for (; w < tp.grid; ++w) acc8[0] += base[(long long)w * tp.PLP + li];
+  float a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
   const int ntri = pl.D * (pl.D - 1) / 2;
   const int d0 = S.g_lu + 2 * ntri;
   if (li >= d0 && li < d0 + pl.D) {
@@ -852,7 +862,7 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 255) / 256), dim3(256), 0, st, pl, tp, params,
+  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64), 0, st, pl, tp, params,
                      partial, grad_out);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,246 @@
+"""``DirectPosterior`` -- sample / evaluate the NPE posterior through the estimator.
+
+Mirror of sbi/inference/posteriors/direct_posterior.py:44-523 (+ the x handling of
+base_posterior.py:170-214): ``sample`` rejects draws outside the prior support via
+``accept_reject_sample``; ``log_prob`` is the estimator log-prob, -inf outside the
+support, minus log(acceptance rate) (``leakage_correction``, cached per x);
+batched variants for many x_o.
+"""
+
+from __future__ import annotations
+
+import warnings
+from typing import Optional, Union
+
+import torch
+from torch import Tensor
+from torch.distributions import Distribution
+
+from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+from sbi_amd.neural_nets.estimators.base import ConditionalDensityEstimator
+from sbi_amd.neural_nets.estimators.shape_handling import reshape_to_batch_event, reshape_to_sample_batch_event
+from sbi_amd.samplers.rejection import rejection
+from sbi_amd.utils.sbiutils import warn_if_outside_prior_support, within_support
+from sbi_amd.utils.torchutils import ensure_theta_batched, process_device
+
+
+class DirectPosterior:
+    def __init__(self, posterior_estimator: ConditionalDensityEstimator, prior: Distribution,
+                 max_sampling_batch_size: int = 10_000, device: Optional[Union[str, torch.device]] = None,
+                 x_shape: Optional[torch.Size] = None, enable_transform: bool = True,
+                 check_finite_x: bool = True):
+        self.posterior_estimator = posterior_estimator
+        self.prior = prior
+        self.max_sampling_batch_size = max_sampling_batch_size
+        self.enable_transform = enable_transform
+        self._check_finite_x = check_finite_x
+        if device is None:
+            device = str(next(posterior_estimator.parameters()).device)
+        self._device = process_device(device)
+        self.posterior_estimator.to(self._device)
+        self.potential_fn, self.theta_transform = posterior_estimator_based_potential(
+            posterior_estimator, prior, x_o=None, enable_transform=enable_transform)
+        self._x: Optional[Tensor] = None
+        self._x_shape = x_shape
+        self._leakage_density_correction_factor = None
+        self._leakage_x = None
+        self._purpose = "It samples the posterior network and rejects samples that lie outside of the prior bounds."
+
+    # -- x handling ---------------------------------------------------------------------
+    @property
+    def default_x(self) -> Optional[Tensor]:
+        return self._x
+
+    def set_default_x(self, x: Tensor) -> "DirectPosterior":
+        x = torch.as_tensor(x, dtype=torch.float32)
+        if self._check_finite_x and not torch.isfinite(x).all():
+            raise ValueError("x_o contains NaN or Inf values.")
+        x = reshape_to_batch_event(x, self.posterior_estimator.condition_shape) if x.dim() <= len(
+            self.posterior_estimator.condition_shape) + 1 else x
+        self._x = x.to(self._device)
+        return self
+
+    def _x_else_default_x(self, x: Optional[Tensor]) -> Tensor:
+        if x is not None:
+            x = torch.as_tensor(x, dtype=torch.float32)
+            if self._check_finite_x and not torch.isfinite(x).all():
+                raise ValueError("x_o contains NaN or Inf values.")
+            return x.to(self._device)
+        if self._x is None:
+            raise ValueError(
+                "Context `x` needed when a default has not been set. If you'd like to have a default, use the "
+                "`.set_default_x()` method."
+            )
+        return self._x
+
+    def to(self, device: Union[str, torch.device]) -> "DirectPosterior":
+        self._device = process_device(device)
+        self.posterior_estimator.to(self._device)
+        if hasattr(self.prior, "to"):
+            self.prior = self.prior.to(self._device)
+        self.potential_fn.to(self._device)
+        if self._x is not None:
+            self._x = self._x.to(self._device)
+        self._leakage_density_correction_factor = None
+        return self
+
+    # -- sampling -----------------------------------------------------------------------
+    def sample(self, sample_shape=torch.Size(), x: Optional[Tensor] = None, max_sampling_batch_size: int = 10_000,
+               show_progress_bars: bool = True, reject_outside_prior: bool = True,
+               max_sampling_time: Optional[float] = None, return_partial_on_timeout: bool = False) -> Tensor:
+        num_samples = torch.Size(sample_shape).numel()
+        x = self._x_else_default_x(x)
+        x = reshape_to_batch_event(x, event_shape=self.posterior_estimator.condition_shape)
+        if x.shape[0] > 1:
+            raise ValueError(
+                ".sample() supports only `batchsize == 1`. If you intend to sample multiple observations, use "
+                "`.sample_batched()`. If you intend to sample i.i.d. observations, set up the posterior density "
+                "estimator with an appropriate permutation invariant embedding net."
+            )
+        max_sampling_batch_size = (self.max_sampling_batch_size if max_sampling_batch_size is None
+                                   else max_sampling_batch_size)
+        if reject_outside_prior:
+            samples = rejection.accept_reject_sample(
+                proposal=self.posterior_estimator.sample,
+                accept_reject_fn=lambda theta: within_support(self.prior, theta),
+                num_samples=num_samples, show_progress_bars=show_progress_bars,
+                max_sampling_batch_size=max_sampling_batch_size,
+                proposal_sampling_kwargs={"condition": x},
+                alternative_method="build_posterior(..., sample_with='mcmc')",
+                max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout,
+            )[0]
+        else:
+            samples = self.posterior_estimator.sample(torch.Size([num_samples]), condition=x)
+            warn_if_outside_prior_support(self.prior, samples[:, 0])
+        samples = samples[:, 0]
+        if samples.shape[0] == num_samples:
+            samples = samples.reshape((*torch.Size(sample_shape), *samples.shape[1:]))
+        return samples
+
+    def sample_batched(self, sample_shape, x: Tensor, max_sampling_batch_size: int = 10_000,
+                       show_progress_bars: bool = True, reject_outside_prior: bool = True,
+                       max_sampling_time: Optional[float] = None, return_partial_on_timeout: bool = False) -> Tensor:
+        num_samples = torch.Size(sample_shape).numel()
+        x = reshape_to_batch_event(self._x_else_default_x(x), self.posterior_estimator.condition_shape)
+        num_xos = x.shape[0]
+        if num_xos * num_samples > 2**21:
+            warnings.warn(
+                f"Note that for batched sampling, the direct posterior sampling generates {num_xos} * "
+                f"{num_samples} = {num_xos * num_samples} samples. This can be slow and memory-intensive.",
+                stacklevel=2,
+            )
+        max_sampling_batch_size = (self.max_sampling_batch_size if max_sampling_batch_size is None
+                                   else max_sampling_batch_size)
+        if max_sampling_batch_size * num_xos > 100_000:
+            capped = max(1, 100_000 // num_xos)
+            warnings.warn(f"Capping max_sampling_batch_size from {max_sampling_batch_size} to {capped} to avoid "
+                          "excessive memory usage.", stacklevel=2)
+            max_sampling_batch_size = capped
+        if reject_outside_prior:
+            samples = rejection.accept_reject_sample(
+                proposal=self.posterior_estimator.sample,
+                accept_reject_fn=lambda theta: within_support(self.prior, theta),
+                num_samples=num_samples, show_progress_bars=show_progress_bars,
+                max_sampling_batch_size=max_sampling_batch_size,
+                proposal_sampling_kwargs={"condition": x},
+                alternative_method="build_posterior(..., sample_with='mcmc')",
+                max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout,
+            )[0]
+        else:
+            samples = self.posterior_estimator.sample(torch.Size([num_samples]), condition=x)
+        return samples.reshape((*torch.Size(sample_shape), num_xos, *samples.shape[2:]))
+
+    # -- density ------------------------------------------------------------------------
+    def log_prob(self, theta: Tensor, x: Optional[Tensor] = None, norm_posterior: bool = True,
+                 track_gradients: bool = False,
+                 leakage_correction_params: Optional[dict] = None) -> Tensor:
+        x = self._x_else_default_x(x)
+        theta = ensure_theta_batched(torch.as_tensor(theta)).to(self._device)
+        est = self.posterior_estimator
+        theta_sbe = reshape_to_sample_batch_event(theta, event_shape=theta.shape[1:], leading_is_sample=True)
+        x_be = reshape_to_batch_event(x, event_shape=est.condition_shape)
+        if x_be.shape[0] > 1:
+            raise ValueError(".log_prob() supports only `batchsize == 1`. Use `.log_prob_batched()` for many "
+                             "observations.")
+        with torch.set_grad_enabled(track_gradients):
+            unnorm = est.log_prob(theta_sbe, condition=x_be).squeeze(1)
+            in_support = within_support(self.prior, theta)
+            masked = torch.where(in_support, unnorm,
+                                 torch.tensor(float("-inf"), dtype=torch.float32, device=self._device))
+            if leakage_correction_params is None:
+                leakage_correction_params = {}
+            log_factor = (torch.log(self.leakage_correction(x=x, **leakage_correction_params))
+                          if norm_posterior else 0)
+            return masked - log_factor
+
+    def log_prob_batched(self, theta: Tensor, x: Tensor, norm_posterior: bool = True, track_gradients: bool = False,
+                         leakage_correction_params: Optional[dict] = None) -> Tensor:
+        """theta (S, B, D) (or (B,D)), x (B, C) -> (S, B)."""
+        est = self.posterior_estimator
+        theta = torch.as_tensor(theta).to(self._device)
+        theta = reshape_to_sample_batch_event(theta, event_shape=est.input_shape, leading_is_sample=True) \
+            if theta.dim() == len(est.input_shape) + 2 else theta.unsqueeze(0)
+        x = reshape_to_batch_event(self._x_else_default_x(x), event_shape=est.condition_shape)
+        with torch.set_grad_enabled(track_gradients):
+            unnorm = est.log_prob(theta, condition=x)
+            in_support = within_support(self.prior, theta)
+            masked = torch.where(in_support, unnorm,
+                                 torch.tensor(float("-inf"), dtype=torch.float32, device=self._device))
+            if leakage_correction_params is None:
+                leakage_correction_params = {}
+            log_factor = (torch.log(self.leakage_correction(x=x, **leakage_correction_params))
+                          if norm_posterior else 0)
+            return masked - log_factor
+
+    @torch.no_grad()
+    def leakage_correction(self, x: Tensor, num_rejection_samples: int = 10_000, force_update: bool = False,
+                           show_progress_bars: bool = False, rejection_sampling_batch_size: int = 10_000) -> Tensor:
+        """Acceptance probability of estimator draws under the prior support, estimated by
+        rejection sampling once per x and cached (direct_posterior.py:466-523)."""
+        x = reshape_to_batch_event(x, self.posterior_estimator.condition_shape)
+
+        def acceptance_at(x_: Tensor) -> Tensor:
+            return rejection.accept_reject_sample(
+                proposal=self.posterior_estimator.sample,
+                accept_reject_fn=lambda theta: within_support(self.prior, theta),
+                num_samples=num_rejection_samples, show_progress_bars=show_progress_bars,
+                sample_for_correction_factor=True, max_sampling_batch_size=rejection_sampling_batch_size,
+                proposal_sampling_kwargs={"condition": x_},
+            )[1]
+
+        is_new_x = self._leakage_x is None or self._leakage_x.shape != x.shape or not torch.equal(self._leakage_x, x)
+        if self._leakage_density_correction_factor is None or is_new_x or force_update:
+            self._leakage_density_correction_factor = acceptance_at(x).to(self._device)
+            self._leakage_x = x.clone()
+        return self._leakage_density_correction_factor
+
+    def potential(self, theta: Tensor, x: Optional[Tensor] = None, track_gradients: bool = False) -> Tensor:
+        self.potential_fn.set_x(self._x_else_default_x(x))
+        return self.potential_fn(ensure_theta_batched(torch.as_tensor(theta)).to(self._device),
+                                 track_gradients=track_gradients)
+
+    def map(self, x: Optional[Tensor] = None, num_iter: int = 1_000, num_to_optimize: int = 100,
+            learning_rate: float = 0.01, num_init_samples: int = 1_000, show_progress_bars: bool = False) -> Tensor:
+        """Maximum-a-posteriori estimate by Adam ascent on the potential from the best of
+        ``num_init_samples`` posterior draws (base_posterior.py:216-323; sbiutils.py:1160-1286).
+        Needs d log_prob / d theta, which the fused backward kernel provides."""
+        x = self._x_else_default_x(x)
+        self.potential_fn.set_x(x)
+        inits = self.sample((num_init_samples,), x=x, show_progress_bars=False)
+        with torch.no_grad():
+            p0 = self.potential_fn(inits, track_gradients=False)
+        top = inits[torch.topk(p0, min(num_to_optimize, num_init_samples)).indices].clone().requires_grad_(True)
+        opt = torch.optim.Adam([top], lr=learning_rate)
+        best, best_val = top.detach()[0].clone(), torch.tensor(float("-inf"), device=top.device)
+        for _ in range(num_iter):
+            opt.zero_grad()
+            pot = self.potential_fn(top, track_gradients=True)
+            finite = torch.isfinite(pot)
+            (-(pot[finite]).sum()).backward()
+            opt.step()
+            with torch.no_grad():
+                v, i = torch.max(torch.where(finite, pot, torch.full_like(pot, float("-inf"))), dim=0)
+                if v > best_val:
+                    best_val, best = v.clone(), top.detach()[i].clone()
+        self._map = best
+        return best

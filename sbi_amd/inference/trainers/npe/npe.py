@@ -1,0 +1,418 @@
+"""Single-round Neural Posterior Estimation with a device-resident training loop.
+
+API mirror of sbi's ``NPE`` (= ``NPE_C``) for the first-round / maximum-likelihood
+case: ``NPE(prior, density_estimator, device).append_simulations(theta, x).train(...)``
+then ``build_posterior()``  (sbi/inference/trainers/npe/npe_base.py:81-163, 188-299,
+301-418, 420-511; loop semantics of sbi/inference/trainers/base.py:499-563,
+1060-1284: Adam(lr 5e-4), batch 200, 10 % validation split, global-norm clip 5.0,
+early stopping after 20 non-improving epochs, best-weights restore, drop_last).
+
+MI355X-first: theta/x live in HBM, minibatches are device-side index gathers over a
+per-epoch ``randperm`` (no DataLoader, no per-row Python), every step is the fused
+HIP forward+backward + clip/Adam (``FusedTrainStep``), losses accumulate on the
+device and the host reads ONE pair of scalars per epoch (the reference syncs every
+minibatch, base.py:1179,1218).  Under ``torch.distributed`` every rank takes a
+contiguous slice of each global batch and gradients are summed with one flat
+all-reduce over RCCL.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+import warnings
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import torch
+from torch import Tensor, nn
+from torch.distributions import Distribution
+
+from sbi_amd.neural_nets.estimators.base import ConditionalDensityEstimator
+from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow
+from sbi_amd.neural_nets.factory import posterior_nn
+from sbi_amd.neural_nets.net_builders.estimator_configs import NSFConfig
+from sbi_amd.utils.sbiutils import handle_invalid_x, warn_on_invalid_x
+from sbi_amd.utils.torchutils import check_if_prior_on_device, process_device
+
+
+@dataclass(frozen=True)
+class TrainConfig:
+    """Validated training hyper-parameters (sbi/inference/trainers/_contracts.py:48-92)."""
+
+    training_batch_size: int = 200
+    learning_rate: float = 5e-4
+    validation_fraction: float = 0.1
+    stop_after_epochs: int = 20
+    max_num_epochs: int = 2**31 - 1
+    clip_max_norm: Optional[float] = 5.0
+    resume_training: bool = False
+    retrain_from_scratch: bool = False
+    show_train_summary: bool = False
+
+    def __post_init__(self):
+        if self.training_batch_size < 1:
+            raise ValueError("training_batch_size must be a positive integer")
+        if not (0.0 < self.validation_fraction < 1.0):
+            raise ValueError("validation_fraction must be in (0, 1)")
+        if self.learning_rate <= 0:
+            raise ValueError("learning_rate must be positive")
+        if self.stop_after_epochs < 1 or self.max_num_epochs < 0:
+            raise ValueError("stop_after_epochs must be >= 1 and max_num_epochs >= 0")
+        if self.clip_max_norm is not None and self.clip_max_norm <= 0:
+            raise ValueError("clip_max_norm must be positive or None")
+
+
+def check_estimator_arg(estimator) -> None:
+    """Same rejections as sbi/utils/user_input_checks.py:678-705."""
+    if isinstance(estimator, nn.Module):
+        raise TypeError(
+            "The `density_estimator` must be a string, a config object or a function that builds the network "
+            "from (theta, x) -- not an already-built nn.Module."
+        )
+    if isinstance(estimator, type):
+        raise TypeError("Pass a config *instance* (e.g. NSFConfig()), not the config class.")
+    if not (isinstance(estimator, (str, NSFConfig)) or callable(estimator)):
+        raise TypeError(f"Unsupported density_estimator argument of type {type(estimator).__name__}")
+
+
+def validate_theta_and_x(theta: Any, x: Any, data_device: str = "cpu", training_device: str = "cpu"):
+    """fp32 tensors with equal batch size, moved to the data device (user_input_checks.py:708-764)."""
+    if not isinstance(theta, Tensor) or not isinstance(x, Tensor):
+        raise AssertionError("Parameters theta and simulation outputs x must be `torch.Tensor`s.")
+    if theta.shape[0] != x.shape[0]:
+        raise AssertionError(f"Number of parameter sets (={theta.shape[0]}) must match the number of simulation "
+                             f"outputs (={x.shape[0]})")
+    if theta.dtype != torch.float32 or x.dtype != torch.float32:
+        raise AssertionError("Type of parameters and simulation outputs must be float32.")
+    if str(data_device) != str(training_device) and data_device != "cpu":
+        warnings.warn(f"Data on '{data_device}' but training on '{training_device}'.", stacklevel=2)
+    return theta.to(data_device), x.to(data_device)
+
+
+class ImproperEmpirical:
+    """Stand-in prior when none was given: support = everything (sbiutils.py:1012-1117)."""
+
+    def __init__(self, values: Tensor):
+        self._values = values
+
+    def sample(self, sample_shape=torch.Size()):
+        n = torch.Size(sample_shape).numel()
+        idx = torch.randint(0, self._values.shape[0], (n,), device=self._values.device)
+        return self._values[idx].reshape(*sample_shape, *self._values.shape[1:])
+
+    def log_prob(self, value: Tensor) -> Tensor:
+        return torch.zeros(value.shape[:-1], device=value.device)
+
+
+class PosteriorEstimatorTrainer:
+    def __init__(self, prior: Optional[Distribution] = None,
+                 density_estimator: Union[str, NSFConfig, Callable, None] = None, device: str = "cpu",
+                 logging_level: Union[int, str] = "WARNING", summary_writer=None, tracker=None,
+                 show_progress_bars: bool = True):
+        self._device = process_device(device)
+        check_if_prior_on_device(self._device, prior)
+        self._prior = prior
+        self._show_progress_bars = show_progress_bars
+        self._tracker = tracker
+        logging.getLogger().setLevel(logging_level if isinstance(logging_level, int) else logging_level.upper())
+        if density_estimator is not None:
+            check_estimator_arg(density_estimator)
+        if density_estimator is None:
+            # The reference defaults to MAF; this package implements the NSF path only.
+            self._build_neural_net = NSFConfig().build
+        elif isinstance(density_estimator, str):
+            warnings.warn(
+                "Passing a string for `density_estimator` is deprecated. Use a per-model config instead, e.g. "
+                "`from sbi_amd.neural_nets import NSFConfig`.", FutureWarning, stacklevel=3,
+            )
+            self._build_neural_net = posterior_nn(model=density_estimator)
+        elif isinstance(density_estimator, NSFConfig):
+            self._build_neural_net = density_estimator.build
+        else:
+            self._build_neural_net = density_estimator
+
+        self._neural_net: Optional[ConditionalDensityEstimator] = None
+        self._theta_roundwise: List[Tensor] = []
+        self._x_roundwise: List[Tensor] = []
+        self._prior_masks: List[Tensor] = []
+        self._data_round_index: List[int] = []
+        self._proposal_roundwise: List[Any] = []
+        self._round = 0
+        self._val_loss = float("Inf")
+        self._best_val_loss = float("Inf")
+        self._epochs_since_last_improvement = 0
+        self._best_model_state_dict = None
+        self.epoch = 0
+        self.optimizer = None
+        self._stepper = None
+        self.train_indices: Optional[Tensor] = None
+        self.val_indices: Optional[Tensor] = None
+        self._summary: Dict[str, list] = dict(epochs_trained=[], best_validation_loss=[], validation_loss=[],
+                                              training_loss=[], epoch_durations_sec=[])
+
+    # ------------------------------------------------------------------ data
+    def append_simulations(self, theta: Tensor, x: Tensor, proposal=None, exclude_invalid_x: Optional[bool] = None,
+                           data_device: Optional[str] = None) -> "PosteriorEstimatorTrainer":
+        if proposal is not None and proposal is not self._prior:
+            raise NotImplementedError(
+                "Multi-round NPE (proposal-corrected atomic loss, npe_c.py:356-440) is a 'next' row of the "
+                "accelerated path; pass proposal=None for single-round NPE."
+            )
+        if exclude_invalid_x is None:
+            exclude_invalid_x = True
+        if data_device is None:
+            data_device = self._device
+        theta, x = validate_theta_and_x(theta, x, data_device=data_device, training_device=self._device)
+        is_valid_x, num_nans, num_infs = handle_invalid_x(x, exclude_invalid_x=exclude_invalid_x)
+        warn_on_invalid_x(num_nans, num_infs, exclude_invalid_x)
+        x, theta = x[is_valid_x], theta[is_valid_x]
+        self._data_round_index.append(0)
+        self._theta_roundwise.append(theta)
+        self._x_roundwise.append(x)
+        self._prior_masks.append(torch.zeros(theta.shape[0], 1, dtype=torch.bool))
+        self._proposal_roundwise.append(proposal)
+        if self._prior is None or isinstance(self._prior, ImproperEmpirical):
+            self._prior = ImproperEmpirical(self.get_simulations()[0].to(self._device))
+        return self
+
+    def get_simulations(self, starting_round: int = 0):
+        th = torch.cat([t for t, r in zip(self._theta_roundwise, self._data_round_index) if r >= starting_round])
+        xx = torch.cat([t for t, r in zip(self._x_roundwise, self._data_round_index) if r >= starting_round])
+        mk = torch.cat([t for t, r in zip(self._prior_masks, self._data_round_index) if r >= starting_round])
+        return th, xx, mk
+
+    # ------------------------------------------------------------------ distributed helpers
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+
+        return dist if (dist.is_available() and dist.is_initialized()) else None
+
+    def _rank_world(self):
+        d = self._dist()
+        return (d.get_rank(), d.get_world_size()) if d is not None else (0, 1)
+
+    def _bcast(self, t: Tensor) -> Tensor:
+        d = self._dist()
+        if d is not None:
+            backend_dev = self._device if d.get_backend() == "nccl" else "cpu"
+            buf = t.to(backend_dev)
+            d.broadcast(buf, src=0)
+            t = buf.to(t.device)
+        return t
+
+    # ------------------------------------------------------------------ training
+    def train(self, training_batch_size: int = 200, learning_rate: float = 5e-4, validation_fraction: float = 0.1,
+              stop_after_epochs: int = 20, max_num_epochs: int = 2**31 - 1, clip_max_norm: Optional[float] = 5.0,
+              calibration_kernel: Optional[Callable] = None, resume_training: bool = False,
+              force_first_round_loss: bool = False, discard_prior_samples: bool = False,
+              retrain_from_scratch: bool = False, show_train_summary: bool = False,
+              dataloader_kwargs: Optional[dict] = None) -> ConditionalDensityEstimator:
+        if len(self._data_round_index) == 0:
+            raise RuntimeError("No simulations found. You must call .append_simulations() before calling .train().")
+        if dataloader_kwargs:
+            raise NotImplementedError("The device-resident loop has no DataLoader; dataloader_kwargs is unsupported.")
+        cfg = TrainConfig(training_batch_size=training_batch_size, learning_rate=learning_rate,
+                          validation_fraction=validation_fraction, stop_after_epochs=stop_after_epochs,
+                          max_num_epochs=max_num_epochs, clip_max_norm=clip_max_norm,
+                          resume_training=resume_training, retrain_from_scratch=retrain_from_scratch,
+                          show_train_summary=show_train_summary)
+        theta, x, _ = self.get_simulations(0)
+        n = theta.shape[0]
+        n_train = int((1 - cfg.validation_fraction) * n)
+        n_val = n - n_train
+        if not cfg.resume_training or self.train_indices is None:
+            perm = self._bcast(torch.randperm(n))       # identical split on every rank
+            self.train_indices, self.val_indices = perm[:n_train], perm[n_train:]
+
+        # build the network from the TRAINING split on the CPU (npe_base.py:674-708)
+        if self._neural_net is None or cfg.retrain_from_scratch:
+            self._neural_net = self._build_neural_net(theta[self.train_indices.to(theta.device)].cpu(),
+                                                      x[self.train_indices.to(x.device)].cpu())
+            if not isinstance(self._neural_net, nn.Module) or not hasattr(self._neural_net, "loss"):
+                raise TypeError("The density_estimator builder must return a ConditionalDensityEstimator.")
+            self._stepper = None
+        net = self._neural_net.to(self._device)
+        params = [p for p in net.parameters() if p.requires_grad]
+        if not params:
+            raise TypeError(f"{type(self).__name__} cannot train {type(net).__name__}: it has no trainable "
+                            "parameters.")
+        d = self._dist()
+        if d is not None:   # replicas start identical
+            for p in list(net.parameters()) + list(net.buffers()):
+                p.data.copy_(self._bcast(p.data))
+
+        theta_d = theta.to(self._device)
+        x_d = x.to(self._device)
+        train_idx = self.train_indices.to(self._device)
+        val_idx = self.val_indices.to(self._device)
+        rank, world = self._rank_world()
+
+        fused = (isinstance(net, NSFFlow) and torch.device(self._device).type == "cuda" and calibration_kernel is None)
+        if not cfg.resume_training or (fused and self._stepper is None) or (not fused and self.optimizer is None):
+            if fused:
+                from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+                self._stepper = FusedTrainStep(net, lr=cfg.learning_rate, clip_max_norm=cfg.clip_max_norm,
+                                               distributed=d is not None)
+            else:
+                self.optimizer = torch.optim.Adam(params, lr=cfg.learning_rate)
+            self.epoch, self._val_loss = 0, float("Inf")
+
+        B = min(cfg.training_batch_size, n_train)
+        Bv = min(cfg.training_batch_size, n_val)
+        n_train_batches = n_train // B
+        n_val_batches = n_val // Bv if Bv > 0 else 0
+        if n_train_batches == 0 or n_val_batches == 0:
+            raise ValueError("Not enough simulations for one training and one validation batch.")
+
+        def my_slice(idx: Tensor) -> Tensor:   # this rank's contiguous share of a global batch
+            if world == 1:
+                return idx
+            per = (idx.numel() + world - 1) // world
+            return idx[rank * per : min((rank + 1) * per, idx.numel())]
+
+        def batch_losses(idx: Tensor, train: bool, global_batch: int) -> Tensor:
+            th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)
+            if fused:
+                if train:
+                    return self._stepper.step(th, xx, global_batch=global_batch)
+                with torch.no_grad():
+                    return net.loss(th, xx)
+            if train:
+                self.optimizer.zero_grad()
+                losses = net.loss(th, xx)
+                if not torch.isfinite(losses).all():
+                    raise AssertionError("NaN/Inf present in NPE loss.")
+                if calibration_kernel is not None:
+                    losses = losses * calibration_kernel(xx)
+                (losses.sum() / global_batch).backward()
+                if d is not None:
+                    for p in params:
+                        d.all_reduce(p.grad, op=d.ReduceOp.SUM)
+                if cfg.clip_max_norm is not None:
+                    torch.nn.utils.clip_grad_norm_(params, max_norm=cfg.clip_max_norm)
+                self.optimizer.step()
+                return losses.detach()
+            with torch.no_grad():
+                losses = net.loss(th, xx)
+                return losses * calibration_kernel(xx) if calibration_kernel is not None else losses
+
+        while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
+            t0 = time.time()
+            net.train()
+            order = self._bcast(torch.randperm(n_train)).to(self._device)   # SubsetRandomSampler
+            epoch_idx = train_idx[order]
+            sums = torch.zeros(2, device=self._device)
+            for b in range(n_train_batches):
+                idx = my_slice(epoch_idx[b * B : (b + 1) * B])
+                sums[0] += batch_losses(idx, True, B).sum()
+            net.eval()
+            vorder = self._bcast(torch.randperm(n_val)).to(self._device)
+            for b in range(n_val_batches):
+                idx = my_slice(val_idx[vorder][b * Bv : (b + 1) * Bv])
+                sums[1] += batch_losses(idx, False, Bv).sum()
+            if d is not None:
+                d.all_reduce(sums, op=d.ReduceOp.SUM)
+            host = sums.cpu()                                   # the one sync of the epoch
+            if not torch.isfinite(host).all():
+                raise AssertionError("NaN/Inf present in NPE loss.")
+            train_loss = float(host[0]) / (n_train_batches * B)
+            self._val_loss = float(host[1]) / (n_val_batches * Bv)
+            self._summary["training_loss"].append(train_loss)
+            self._summary["validation_loss"].append(self._val_loss)
+            self._summary["epoch_durations_sec"].append(time.time() - t0)
+            self.epoch += 1
+            if self._show_progress_bars and rank == 0:
+                print("\r", f"Training neural network. Epochs trained: {self.epoch}", end="")
+
+        if self.epoch > cfg.max_num_epochs:
+            # the final epoch was never scored by `_converged` (base.py:1122-1129)
+            if self._val_loss < self._best_val_loss:
+                self._best_val_loss = self._val_loss
+                self._best_model_state_dict = deepcopy(net.state_dict())
+            elif self._best_model_state_dict is not None:
+                self._load_state(net, self._best_model_state_dict)
+            warnings.warn("Maximum number of epochs `max_num_epochs={}` reached, but network has not yet fully "
+                          "converged. Consider increasing it.".format(cfg.max_num_epochs), stacklevel=2)
+        elif self._show_progress_bars and rank == 0:
+            print(f"\n Neural network successfully converged after {self.epoch} epochs.")
+        self._summary["epochs_trained"].append(self.epoch)
+        self._summary["best_validation_loss"].append(self._best_val_loss)
+        if cfg.show_train_summary and rank == 0:
+            print(self._describe_round())
+        net.zero_grad(set_to_none=True)
+        return deepcopy(net)
+
+    @staticmethod
+    def _load_state(net: nn.Module, sd) -> None:
+        net.load_state_dict(sd)
+        inner = getattr(net, "net", None)
+        if inner is not None:
+            inner.__dict__.pop("_packed_cache", None)
+
+    def _converged(self, epoch: int, stop_after_epochs: int) -> bool:
+        """Early stopping with best-weights bookkeeping (base.py:1254-1284)."""
+        converged = False
+        net = self._neural_net
+        if epoch == 0 or self._val_loss < self._best_val_loss:
+            self._best_val_loss = self._val_loss
+            self._epochs_since_last_improvement = 0
+            self._best_model_state_dict = deepcopy(net.state_dict())
+        else:
+            self._epochs_since_last_improvement += 1
+        if self._epochs_since_last_improvement > stop_after_epochs - 1:
+            self._load_state(net, self._best_model_state_dict)
+            converged = True
+        return converged
+
+    def _describe_round(self) -> str:
+        s = self._summary
+        return (f"\n -------------------------\n ||||| ROUND 1 STATS |||||:\n -------------------------\n"
+                f" Epochs trained: {s['epochs_trained'][-1]}\n"
+                f" Best validation performance: {-s['best_validation_loss'][-1]:.4f}\n"
+                " -------------------------\n")
+
+    @property
+    def summary(self):
+        return self._summary
+
+    # ------------------------------------------------------------------ posterior
+    def build_posterior(self, density_estimator: Optional[ConditionalDensityEstimator] = None,
+                        prior: Optional[Distribution] = None, sample_with: str = "direct",
+                        direct_sampling_parameters: Optional[Dict[str, Any]] = None, **kwargs):
+        from sbi_amd.inference.posteriors.direct_posterior import DirectPosterior
+
+        if sample_with != "direct":
+            raise NotImplementedError(
+                f"sample_with={sample_with!r}: MCMC / VI / importance posteriors are callers of the batched "
+                "log_prob kernel outside this round's scope (SURVEY.md section 8f-3); use 'direct'."
+            )
+        if prior is None:
+            if self._prior is None:
+                raise ValueError("You did not pass a prior. You have to pass the prior either at initialization "
+                                 "`inference = NPE(prior)` or to `.build_posterior(prior=prior)`.")
+            prior = self._prior
+        else:
+            check_if_prior_on_device(self._device, prior)
+        if density_estimator is None:
+            if self._neural_net is None:
+                raise ValueError("No trained estimator: call .train() first or pass density_estimator=...")
+            estimator = deepcopy(self._neural_net)
+            device = self._device
+        else:
+            estimator = density_estimator
+            device = str(next(density_estimator.parameters()).device)
+        self._posterior = DirectPosterior(posterior_estimator=estimator, prior=prior, device=device,
+                                          **(direct_sampling_parameters or {}))
+        return deepcopy(self._posterior)
+
+
+class NPE_C(PosteriorEstimatorTrainer):
+    """Single-round NPE-C == maximum-likelihood NPE (npe_c.py:91-223 without the multi-round losses)."""
+
+
+NPE = NPE_C   # sbi/inference/__init__.py:22
+SNPE = NPE_C

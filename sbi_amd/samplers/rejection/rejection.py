@@ -1,0 +1,140 @@
+"""Accept/reject sampling from the estimator inside the prior support.
+
+Same contract as sbi/samplers/rejection/rejection.py:230-457
+(``accept_reject_sample``): draws ``sampling_batch_size`` candidates from
+``proposal``, keeps those ``accept_reject_fn`` accepts, adapts the batch size
+from the running acceptance rate (:406-409), warns once below
+``warn_acceptance``, honours ``max_sampling_time`` / ``return_partial_on_timeout``
+and returns ``(samples (num_samples, num_xos, *event), acceptance_rate (num_xos,))``.
+
+MI355X-first differences (results are the same set of samples in the same order):
+accepted candidates are compacted ON THE DEVICE into a preallocated output buffer
+with a stable prefix-sum scatter (no boolean-mask gathers, no per-condition Python
+loop, no list/cat), and the loop reads back ONE small tensor per iteration (the
+per-condition accept counts the batch-size rule needs) instead of 2+ syncs.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+import warnings
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+
+@torch.no_grad()
+def accept_reject_sample(
+    proposal: Callable,
+    accept_reject_fn: Callable[[Tensor], Tensor],
+    num_samples: int,
+    num_xos: int = 1,
+    show_progress_bars: bool = False,
+    warn_acceptance: float = 0.01,
+    sample_for_correction_factor: bool = False,
+    max_sampling_batch_size: int = 10_000,
+    proposal_sampling_kwargs: Optional[Dict] = None,
+    alternative_method: Optional[str] = None,
+    max_sampling_time: Optional[float] = None,
+    return_partial_on_timeout: bool = False,
+    **kwargs,
+) -> Tuple[Tensor, Tensor]:
+    if kwargs:
+        logging.warning(
+            "You passed arguments to `rejection_sampling_parameters` that are unused when you do not "
+            f"specify a `proposal` in the same dictionary. The unused arguments are: {kwargs}"
+        )
+    if proposal_sampling_kwargs is None:
+        proposal_sampling_kwargs = {}
+    if "condition" in proposal_sampling_kwargs:
+        num_xos = proposal_sampling_kwargs["condition"].shape[0]
+
+    out: Optional[Tensor] = None            # (num_samples, num_xos, *event)
+    filled: Optional[Tensor] = None         # (num_xos,) int64, on device
+    acceptance_rate = torch.full((num_xos,), float("nan"))
+    num_remaining = num_samples
+    sampling_batch_size = min(num_samples, max_sampling_batch_size)
+    num_samples_possible = 0
+    leakage_warning_raised = False
+    start_time = time.time()
+    candidates = None
+
+    while num_remaining > 0:
+        if max_sampling_time is not None and (time.time() - start_time) > max_sampling_time:
+            num_collected = 0 if filled is None else int(filled.min().item())
+            if return_partial_on_timeout and num_collected > 0:
+                warnings.warn(
+                    f"Timeout exceeded after collecting {num_collected}/{num_samples} samples. "
+                    "Returning partial results.", stacklevel=2,
+                )
+                return out[:num_collected], acceptance_rate.to(out.device)
+            raise RuntimeError(
+                "Sampling aborted early because rejection sampling exceeded max_sampling_time. This is "
+                "likely due to extremely low acceptance. You can disable rejection sampling using "
+                "`reject_outside_prior=False` to draw samples directly from the trained estimator. "
+                "Consider switching to MCMC or VI, or checking for model misspecification."
+            )
+
+        candidates = proposal(torch.Size((sampling_batch_size,)), **proposal_sampling_kwargs)
+        are_accepted = accept_reject_fn(candidates).reshape(sampling_batch_size, num_xos)
+        cand = candidates.reshape(sampling_batch_size, num_xos, *candidates.shape[candidates.ndim - 1 :])
+        if out is None:
+            # one extra row: the dump slot rejected / surplus candidates are scattered to
+            buf = torch.empty((num_samples + 1, num_xos, *cand.shape[2:]), dtype=cand.dtype, device=cand.device)
+            out = buf[:num_samples]
+            flat = buf.view(-1, *cand.shape[2:])
+            filled = torch.zeros(num_xos, dtype=torch.long, device=cand.device)
+            total_accepted = torch.zeros(num_xos, dtype=torch.long, device=cand.device)
+            xo_idx = torch.arange(num_xos, device=cand.device).unsqueeze(0)
+
+        # stable compaction: destination row of every accepted candidate, per condition
+        acc_i = are_accepted.to(torch.long)
+        dest = torch.cumsum(acc_i, dim=0) - 1 + filled.unsqueeze(0)              # (bs, num_xos)
+        keep = are_accepted & (dest < num_samples)
+        dest = torch.where(keep, dest, torch.full_like(dest, num_samples))      # overflow row
+        flat.index_copy_(0, (dest * num_xos + xo_idx).reshape(-1), cand.reshape(-1, *cand.shape[2:]))
+        num_accepted = acc_i.sum(dim=0)
+        filled = torch.clamp(filled + num_accepted, max=num_samples)
+        total_accepted += num_accepted
+        num_samples_possible += sampling_batch_size
+
+        # the ONE host read-back of the iteration
+        stats = torch.stack([num_accepted, total_accepted]).cpu()
+        min_num_accepted = int(stats[0].min())
+        num_remaining -= min_num_accepted
+        acceptance_rate = stats[1].to(torch.float32) / num_samples_possible
+        min_acceptance_rate = float(acceptance_rate.min())
+
+        sampling_batch_size = min(
+            max_sampling_batch_size,
+            max(int(1.5 * num_remaining / max(min_acceptance_rate, 1e-12)), 100),
+        )
+        if (
+            num_samples_possible > (sampling_batch_size - 1)
+            and min_acceptance_rate < warn_acceptance
+            and not leakage_warning_raised
+        ):
+            if sample_for_correction_factor:
+                logging.warning(
+                    f"Drawing samples from posterior to estimate the normalizing constant for `log_prob()`. "
+                    f"However, only {min_acceptance_rate:.3%} posterior samples are within the prior support "
+                    f"(for condition {int(acceptance_rate.argmin())}). It may take a long time to collect the "
+                    f"remaining {num_remaining} samples. Consider `log_prob(..., norm_posterior=False)`."
+                )
+            else:
+                msg = (
+                    f"Only {min_acceptance_rate:.3%} proposal samples are accepted. It may take a long time "
+                    f"to collect the remaining {num_remaining} samples. You can prevent very long runtimes by "
+                    "setting `max_sampling_time`, or disabling rejection sampling "
+                    "(`reject_outside_prior=False`)."
+                )
+                if alternative_method is not None:
+                    msg += f" Alternatively, consider switching to `{alternative_method}`."
+                logging.warning(msg)
+            leakage_warning_raised = True
+
+    assert out is not None
+    samples = out.reshape(num_samples, *candidates.shape[1:])
+    return samples, acceptance_rate.to(samples.device)

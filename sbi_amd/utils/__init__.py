@@ -1,0 +1,1 @@
+from sbi_amd.utils.torchutils import BoxUniform  # noqa: F401

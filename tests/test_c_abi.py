@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/sbi_amd_nsf.h declares (no
+compute calls here: those need a GPU).  Host-only entry points are exercised."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from sbi_amd import _build, _lib
+from sbi_amd.neural_nets.estimators.nsf_flow import NSFHyper
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sbi_amd_nsf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sbi_amd_\w+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _build.build()
+    lib = ctypes.CDLL(str(_build.LIB_PATH))
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/sbi_amd_nsf.h but not exported"
+    assert set(syms) == set(_lib.exported_symbols()), "ctypes binding and header disagree"
+
+
+def test_version_arch_and_layout_helpers():
+    lib = _lib.load()
+    assert lib.sbi_amd_nsf_abi_version() >= 100
+    assert lib.sbi_amd_nsf_arch() == b"gfx950"
+    for kw in [dict(D=10, C=10), dict(D=2, C=2), dict(D=3, C=5, hidden_features=32, num_transforms=3, num_bins=8,
+                                                       num_blocks=1), dict(D=7, C=4, num_bins=4)]:
+        h = NSFHyper(**kw)
+        cfg = h.c_config()
+        assert lib.sbi_amd_nsf_param_count(cfg) == h.param_count()
+        off = 0
+        for t in range(h.num_transforms):
+            assert lib.sbi_amd_nsf_layer_offset(cfg, t) == off
+            n_layer = sum(int(__import__("numpy").prod(s)) for _, s in h.layer_entries(t))
+            assert lib.sbi_amd_nsf_lu_offset(cfg, t) == off + n_layer
+            off += n_layer + h.D * (h.D - 1) + 2 * h.D
+        assert lib.sbi_amd_nsf_packed_floats(cfg) > h.param_count()
+    assert NSFHyper(D=10, C=10).param_count() == 98025
+
+
+def test_unsupported_configs_are_refused_not_degraded():
+    lib = _lib.load()
+    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, hidden_features=128).c_config()) == _lib.E_UNSUPPORTED
+    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, num_bins=7).c_config()) == _lib.E_UNSUPPORTED
+    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=1, C=10).c_config()) == _lib.E_BADARG
+    # null pointers never reach a launch
+    cfg = NSFHyper(D=10, C=10).c_config()
+    assert lib.sbi_amd_nsf_log_prob(cfg, None, None, None, None, 4, 4, None, None, None) == _lib.E_BADARG
+    assert lib.sbi_amd_adam_clip_step(None, None, None, None, 4, 1, 1e-3, 0.9, 0.999, 1e-8, 5.0, None, None) == \
+        _lib.E_BADARG
+    with pytest.raises(RuntimeError, match="unsupported|not supported"):
+        _lib.check(_lib.E_UNSUPPORTED, "x")
