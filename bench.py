@@ -87,12 +87,45 @@ def cpu_baseline(mode, budget_s=12.0):
                       f"torch {torch.__version__} CPU fp32"}
 
 
+def timed(step, steps, warmup, device, dist=None):
+    """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)     # HIP events on the stream the kernels are launched on
+    t = torch.tensor([wall], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), dev_ms
+
+
+def roofline(flop_per_unit, units_per_step, steps, dev_ms):
+    achieved = flop_per_unit * units_per_step * steps / (dev_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "device_ms_per_step": dev_ms / steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["train", "log_prob"], default=os.environ.get("SBI_AMD_BENCH_MODE", "train"))
+    ap.add_argument("--mode", choices=["both", "train", "log_prob"],
+                    default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -104,6 +137,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = None
     if distributed:
         import torch.distributed as dist
 
@@ -116,63 +150,50 @@ def main():
     if distributed:
         dist.broadcast(est.net.flat_params.data, src=0)
 
-    if args.mode == "train":
-        from sbi_amd.inference.trainers.fused import FusedTrainStep
-
-        stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
-
-        def step():
-            stepper.step(theta, x)
-    else:
-        def step():
+    results = {}
+    if args.mode in ("both", "log_prob"):
+        def lp_step():
             with torch.no_grad():
                 est.log_prob(theta, x)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    t = torch.tensor([wall], device=device, dtype=torch.float64)
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+        wall, dev_ms = timed(lp_step, args.steps, args.warmup, device, dist)
+        results["log_prob"] = {"value": B * world * args.steps / wall, "unit": "evals/s",
+                               "ms_per_step": wall / args.steps * 1e3,
+                               "roofline": roofline(F_EVAL, B, args.steps, dev_ms)}
+    if args.mode in ("both", "train"):
+        from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+        stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+        wall, dev_ms = timed(lambda: stepper.step(theta, x), args.steps, args.warmup, device, dist)
+        results["train"] = {"value": B * world * args.steps / wall, "unit": "pairs/s",
+                            "ms_per_step": wall / args.steps * 1e3,
+                            "roofline": roofline(F_TRAIN, B, args.steps, dev_ms)}
 
     if rank == 0:
-        units = B * world * args.steps
-        value = units / wall
-        flop_per_unit = F_TRAIN if args.mode == "train" else F_EVAL
-        # dominant kernel(s): per-launch duration measured with HIP events on the launch stream
-        achieved = flop_per_unit * B * args.steps / (dev_ms * 1e-3) / 1e12
+        head = "train" if "train" in results else "log_prob"
+        r = results[head]
         out = {
-            "metric": "NPE train (theta,x)-pairs/sec" if args.mode == "train" else "NSF log_prob evals/sec",
-            "value": value,
-            "unit": "pairs/s" if args.mode == "train" else "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
+            "metric": "NPE train (theta,x)-pairs/sec" if head == "train" else "NSF log_prob evals/sec",
+            "value": r["value"], "unit": r["unit"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"NPE+NSF theta-dim {D}, x-dim {C}, batch {B}/GPU, linear-Gaussian, "
-                                   f"mode={args.mode}", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "device_ms_per_step": dev_ms / args.steps},
+            "config": {"workload": f"BASELINE configs[1]: NPE + NSF theta-dim {D}, x-dim {C}, batch {B} per GPU, "
+                                   f"synthetic linear-Gaussian; step = one fused NPE training step"
+                       if head == "train" else
+                       f"NSF log_prob, theta-dim {D}, x-dim {C}, batch {B} per GPU", "parallelism": f"dp{world}"},
+            # whole step (forward + T backward launches + reduce + clip/Adam) against dense fp32 MFMA;
+            # per-kernel durations: profiles/*kernel_stats.csv
+            "roofline": r["roofline"],
         }
+        if "log_prob" in results and head == "train":
+            lp = results["log_prob"]
+            out["log_prob"] = {"metric": "NSF log_prob evals/sec", "value": lp["value"], "unit": lp["unit"],
+                               "ms_per_step": lp["ms_per_step"], "roofline": lp["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.mode)
+            out["cpu_baseline"] = cpu_baseline(head)
+            if "log_prob" in results and head == "train":
+                out["log_prob"]["cpu_baseline"] = cpu_baseline("log_prob", budget_s=8.0)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
