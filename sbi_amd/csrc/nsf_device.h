@@ -46,7 +46,7 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log
 __device__ __forceinline__ void pack_linear(float* __restrict__ img, const float* __restrict__ gl,
                                             const LinDesc& L, int bias_pad, int bias_group, int bias_group_pad,
                                             int tid, int nthreads) {
-  const int total = (L.out + 1) * L.ldk;
+  const int total = L.rows * L.ldk;
   for (int idx = tid; idx < total; idx += nthreads) {
     int r = idx / L.ldk;
     int c = idx - r * L.ldk;

@@ -24,7 +24,8 @@ static int check_cfg(const sbi_amd_nsf_config* c) {
   return 0;
 }
 
-static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad, int ksteps_fixed) {
+static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad, int ksteps_fixed,
+                    int min_rows = 0) {
   L->out = out;
   L->in = in;
   L->ksteps = ksteps_fixed > 0 ? ksteps_fixed : round_up((in + 3) / 4, 4);
@@ -37,7 +38,12 @@ static void set_lin(LinDesc* L, int* g, int* l, int out, int in, int bias_pad, i
   L->g_b = *g;
   *g += out;
   L->l_w = *l;
-  *l += (out + 1) * L->ldk;   // +1: all-zero row that out-of-range MFMA rows read
+  // rows [out, rows_alloc) are all-zero: row `out` is what out-of-range MFMA A rows read, and the
+  // backward's transposed K loop walks rows 0 .. 4*KSH-1 of the hidden x hidden layers unpredicated
+  int rows_alloc = out + 1;
+  if (min_rows > rows_alloc) rows_alloc = min_rows;
+  L->rows = rows_alloc;
+  *l += rows_alloc * L->ldk;
   L->l_b = *l;
   *l += bias_pad;
 }
@@ -71,11 +77,12 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     s->in0 = s->d_id + C;
     int g = 0, l = 0;
     const int hb = 16 * NSF_HT;
-    set_lin(&s->lin[0], &g, &l, H, s->in0, hb, 0);
+    const int tr_rows = 4 * pl->KSH + 1;   // transposed (backward) K loops walk 4*KSH rows
+    set_lin(&s->lin[0], &g, &l, H, s->in0, hb, 0, tr_rows);
     for (int b = 0; b < NB; ++b) {
       set_lin(&s->lin[1 + 3 * b], &g, &l, H, C, hb, 0);
-      set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb, pl->KSH);
-      set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb, pl->KSH);
+      set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb, pl->KSH, tr_rows);
+      set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb, pl->KSH, tr_rows);
     }
     set_lin(&s->lin[1 + 3 * NB], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT, pl->KSH);
     s->g_lu = g;

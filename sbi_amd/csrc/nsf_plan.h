@@ -23,6 +23,7 @@ struct LinDesc {
   int g_w, g_b;   // float offsets relative to the layer's block in the flat buffer
   int l_w, l_b;   // float offsets inside the LDS weight image
   int out, in;    // natural dims of nn.Linear(in, out)
+  int rows;       // rows stored in the image (>= out+1; rows >= out are zero)
   int ldk;        // LDS row stride (floats), 2*odd, >= 4*ksteps
   int ksteps;     // MFMA K-steps the kernels run: ceil(in/4), rounded up to a multiple of 4
                   // for the layers whose B operand comes from LDS (initial / context layers)

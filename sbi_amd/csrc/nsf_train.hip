@@ -97,29 +97,37 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
   }
 }
 
-// row-wise backward through a linear layer: acc[mt] += sum_k W[k][feat(mt)] * g[k], g = D fragments
+// row-wise backward through a linear layer: acc[mt] += sum_k W[k][feat(mt)] * g[k], g = D fragments.
+// The image keeps rows [out, 4*KS) zero (nsf_plan.cpp: rows_alloc), so K-steps past `out` need no
+// predicate; lanes that supply an A row for an in-feature slot >= in load a neighbouring (finite)
+// weight and replace it by zero with one v_cndmask.
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
                                             const f4 (&gb)[NSF_HT], f4 (&acc)[MT], int abl = 0) {
   if (abl & 2) return;
-  int co[MT];
+  const float* base[MT];
+  bool ok[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int f = 16 * mt + id.iperm;
-    co[mt] = f < L.in ? f : -1;
+    ok[mt] = f < L.in;
+    base[mt] = lds + L.l_w + id.g * L.ldk + (ok[mt] ? f : 0);
   }
-  const int zero_off = L.l_w + L.out * L.ldk;
+  const int kstride = 4 * L.ldk;
+  float a_cur[MT], a_nxt[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a_cur[mt] = ok[mt] ? base[mt][0] : 0.f;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    const int k = 4 * s + id.g;
-    const int ro = L.l_w + k * L.ldk;
-    const bool kin = k < L.out;
+    if (s + 1 < KS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = ok[mt] ? base[mt][(s + 1) * kstride] : 0.f;
+    }
     const float bv = gb[s >> 2][s & 3];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int off = (kin && co[mt] >= 0) ? ro + co[mt] : zero_off;
-      acc[mt] = MFMA16(lds[off], bv, acc[mt]);
-    }
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(a_cur[mt], bv, acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
   }
 }
 
@@ -394,6 +402,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       wave_lds_fence();
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
+      if (!(pl.ablate & 64))
       for (int k = id.g; k < D; k += 4) {
         float a = 0.f;
         for (int i = k; i < D; ++i) a += lds[S.l_L + i * D + k] * gzs[id.j * pl.ZW + i];
@@ -578,6 +587,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       __syncthreads();
 
       // ---- P5: LULinear parameter gradients as two more 16x16 tiles
+      if (!(pl.ablate & 64))
       for (int i = id.g; i < D; i += 4) {
         float a = 0.f;
         for (int k = i; k < D; ++k) a += lds[S.l_U + i * D + k] * ys[id.j * pl.ZW + k];
@@ -720,38 +730,54 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   }
 }
 
-// grad[p] = sum over workgroups of the partial slabs (fixed order => deterministic);
+// grad[p] = sum over workgroups of the partial slabs (fixed association => deterministic);
 // finishes LULinear's diagonal: d/d(unconstrained_upper_diag_i) =
 //   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i)
-__global__ void __launch_bounds__(64)
+// block = 64 params x 8 slab groups: enough loads in flight to stream the ~100 MB of partials.
+#define RED_GROUPS 8
+__global__ void __launch_bounds__(64 * RED_GROUPS)
 nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __restrict__ params,
                        const float* __restrict__ partial, float* __restrict__ grad) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= pl.n_params) return;
+  __shared__ float red[RED_GROUPS][64];
+  __shared__ float red_sgl[RED_GROUPS][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const bool live = idx < pl.n_params;
   int t = 0;
-  while (t + 1 < pl.T && idx >= pl.g_layer[t + 1]) ++t;
+  if (live) while (t + 1 < pl.T && idx >= pl.g_layer[t + 1]) ++t;
   const ShapeDesc& S = pl.shape[t & 1];
   const int li = idx - pl.g_layer[t];
   const float* base = partial + (long long)t * tp.grid * tp.PLP;
-  // 8 independent partial sums keep 8 loads in flight (fixed association => deterministic)
-  float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int w = 0;
-  for (; w + 8 <= tp.grid; w += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc8[u] += base[(long long)(w + u) * tp.PLP + li];
-  }
-  for (; w < tp.grid; ++w) acc8[0] += base[(long long)w * tp.PLP + li];
-  float a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
   const int ntri = pl.D * (pl.D - 1) / 2;
   const int d0 = S.g_lu + 2 * ntri;
-  if (li >= d0 && li < d0 + pl.D) {
-    float sgl = 0.f;
-    for (int w = 0; w < tp.grid; ++w) sgl += base[(long long)w * tp.PLP + S.n_params];
-    const float ud = params[idx];
-    const float uii = softplus_f(ud) + pl.lu_eps;
-    a = (a + sgl / uii) * (1.f / (1.f + expf(-ud)));
+  const bool is_diag = live && li >= d0 && li < d0 + pl.D;
+  float a = 0.f, sgl = 0.f;
+  if (live) {
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    int w = grp;
+    for (; w + 3 * RED_GROUPS < tp.grid; w += 4 * RED_GROUPS) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] += base[(long long)(w + u * RED_GROUPS) * tp.PLP + li];
+    }
+    for (; w < tp.grid; w += RED_GROUPS) acc4[0] += base[(long long)w * tp.PLP + li];
+    a = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    if (is_diag)
+      for (int w2 = grp; w2 < tp.grid; w2 += RED_GROUPS) sgl += base[(long long)w2 * tp.PLP + S.n_params];
   }
-  grad[idx] = a;
+  red[grp][lane] = a;
+  red_sgl[grp][lane] = sgl;
+  __syncthreads();
+  if (grp == 0 && live) {
+    float tot = 0.f, tsg = 0.f;
+#pragma unroll
+    for (int g = 0; g < RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g][lane]; }
+    if (is_diag) {
+      const float ud = params[idx];
+      const float uii = softplus_f(ud) + pl.lu_eps;
+      tot = (tot + tsg / uii) * (1.f / (1.f + expf(-ud)));
+    }
+    grad[idx] = tot;
+  }
 }
 
 __global__ void neg_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long long n) {
@@ -862,7 +888,7 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64), 0, st, pl, tp, params,
+  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64 * RED_GROUPS), 0, st, pl, tp, params,
                      partial, grad_out);
   return (int)hipGetLastError();
 }
