@@ -73,16 +73,26 @@ __device__ __forceinline__ void pack_lu(float* __restrict__ img, const float* __
   const float* upper = lower + ntri;
   const float* udiag = upper + ntri;
   const float* bias = udiag + D;
-  for (int idx = tid; idx < D * D; idx += nthreads) {
-    int i = idx / D, k = idx - i * D;
+  // dense U, L stored [LUS][LUS] (LUS = 16 for D <= 16: zero padded so the mat-vec helpers need
+  // no bounds checks; LUS = D otherwise)
+  const int LUS = D <= 16 ? 16 : D;
+  for (int idx = tid; idx < LUS * LUS; idx += nthreads) {
+    int i = idx / LUS, k = idx - i * LUS;
     float u = 0.f, l = 0.f;
-    if (k > i) u = upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
-    else if (k == i) { u = softplus_f(udiag[i]) + eps; l = 1.f; }
-    else l = lower[i * (i - 1) / 2 + k];
+    if (i < D && k < D) {
+      if (k > i) u = upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
+      else if (k == i) { u = softplus_f(udiag[i]) + eps; l = 1.f; }
+      else l = lower[i * (i - 1) / 2 + k];
+    }
     img[S.l_U + idx] = u;
     img[S.l_L + idx] = l;
   }
   for (int idx = tid; idx < D; idx += nthreads) img[S.l_lub + idx] = bias[idx];
+  if (tid == 0) {   // logabsdet of the LULinear = sum_i log(softplus(u_i) + eps)
+    float a = 0.f;
+    for (int i = 0; i < D; ++i) a += logf(softplus_f(udiag[i]) + eps);
+    img[S.l_lub + D] = a;
+  }
 }
 
 // (tid, nthreads) may span several workgroups: tid = blockIdx.y*blockDim.x + threadIdx.x
@@ -97,7 +107,7 @@ __device__ __forceinline__ void pack_layer(float* __restrict__ img, const float*
   }
   pack_linear(img, gl, S.lin[1 + 3 * pl.NB], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
   pack_lu(img, gl, S, pl.D, pl.lu_eps, tid, nthreads);
-  for (int idx = S.l_lub + pl.D + tid; idx < pl.img_floats; idx += nthreads) img[idx] = 0.f;
+  for (int idx = S.l_lub + pl.D + 1 + tid; idx < pl.img_floats; idx += nthreads) img[idx] = 0.f;
 }
 
 // stage one layer's image into LDS: coalesced 16-byte copies, all loads issued first
@@ -276,135 +286,202 @@ __device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds,
   switch (nact) {   // wave-uniform
     case 1: final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, d0); break;
     case 2: final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, d0); break;
-    case 3: final_layer_chunk_n<PT, KSH, 3>(lds, pst, pl, S, id, h, d0); break;
-    default: final_layer_chunk_n<PT, KSH, 4>(lds, pst, pl, S, id, h, d0); break;
+    default: break;
   }
 }
 
-// ---- rational-quadratic spline, one (row, dim) per lane ---------------------
+// ---- rational-quadratic spline: one (row, dim) task per LANE PAIR (lane, lane^32) -------
 // Restates nflows 0.14 transforms/splines/rational_quadratic.py
-// (unconstrained_rational_quadratic_spline, tails="linear") with the constants
-// sbi passes (flow.py:425-432; estimator_configs.py:49-51).  `p` points at the
-// 3K-1 raw conditioner outputs of this (row, dim).  Forward returns logabsdet,
-// inverse returns -logabsdet (as nflows does).  Optionally exports the selected
-// bin quantities for the backward pass.
-struct SplineBin {
+// (unconstrained_rational_quadratic_spline, tails="linear") with the constants sbi passes
+// (flow.py:425-432; estimator_configs.py:49-51).  `p` points at the 3K-1 raw conditioner
+// outputs of the task.  The two lanes of a pair split the work: part 0 (lanes 0-31) owns the
+// bin WIDTHS (softmax, knot cumsum, the forward bin search, derivative d_i), part 1 (lanes
+// 32-63) the bin HEIGHTS (softmax, knots, the inverse bin search, d_{i+1}); the handful of
+// selected scalars is exchanged with v_permlane32_swap and both lanes evaluate the rational-
+// quadratic core.  This halves the longest dependency chains of a VALU-latency-bound phase.
+__device__ __forceinline__ float xchg32(float x) {   // value held by lane ^ 32
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const unsigned u = __float_as_uint(x);
+  const u2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r.x : r.y);
+}
+__device__ __forceinline__ int xchg32i(int x) { return __float_as_int(xchg32(__int_as_float(x))); }
+
+template <int K>
+struct SplineSide {
+  float e[K];       // exp(logit - max); softmax probabilities after normalise()
+  float inv_s;      // 1 / sum(e)
+  float c[K + 1];   // knots of this side in [-B, B]
+};
+
+template <int K>
+__device__ __forceinline__ void spline_side(const float* __restrict__ q, const NsfPlan& pl, int part,
+                                            SplineSide<K>& S) {
+  const float B = pl.B;
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    S.e[k] = q[k] * pl.inv_sqrt_h;   // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
+    m = fmaxf(m, S.e[k]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    S.e[k] = exp_f(S.e[k] - m);
+    s += S.e[k];
+  }
+  S.inv_s = rcp_f(s);
+  const float n_ = (part ? pl.one_minus_kh : pl.one_minus_kw) * S.inv_s;
+  const float mn = part ? pl.min_h : pl.min_w;
+  // knots: cumsum -> pad -> affine to [-B,B] -> overwrite ends
+  float cum = 0.f;
+  S.c[0] = -B;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    cum += fmaf(S.e[k], n_, mn);
+    S.c[k + 1] = (2.f * B) * cum + (-B);
+  }
+  S.c[K] = B;
+}
+
+struct SplineSel {   // per-task scalars both lanes hold after the exchange
   int idx;
-  float cw_i, w_i, ch_i, h_i, d_i, d_ip1, ud_i, ud_ip1;
-  float sw, sh;   // softmax denominators (after max subtraction)
-  float mw, mh;   // softmax maxima
+  bool inside;
+  float cw_i, cw_n, ch_i, ch_n, d_i, d_n, ud_mine;
 };
 
 template <int K, bool INV>
-__device__ __forceinline__ void rq_spline(const float* __restrict__ p, float x, const NsfPlan& pl, float& y,
-                                          float& ld, SplineBin* bin = nullptr) {
+__device__ __forceinline__ void spline_select(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
+                                              const SplineSide<K>& S, SplineSel& o) {
   const float B = pl.B;
-  const bool inside = (x >= -B) && (x <= B);
-  float ew[K], eh[K];
-  float mw = -INFINITY, mh = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    ew[k] = p[k] * pl.inv_sqrt_h;   // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
-    eh[k] = p[K + k] * pl.inv_sqrt_h;
-    mw = fmaxf(mw, ew[k]);
-    mh = fmaxf(mh, eh[k]);
-  }
-  float sw = 0.f, sh = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    ew[k] = exp_f(ew[k] - mw);
-    eh[k] = exp_f(eh[k] - mh);
-    sw += ew[k];
-    sh += eh[k];
-  }
-  // knots: cumsum -> pad -> affine to [-B,B] -> overwrite ends
-  float cw[K + 1], ch[K + 1];
-  float cumw = 0.f, cumh = 0.f;
-  cw[0] = -B;
-  ch[0] = -B;
-  const float nw_ = pl.one_minus_kw * rcp_f(sw), nh_ = pl.one_minus_kh * rcp_f(sh);
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    cumw += fmaf(ew[k], nw_, pl.min_w);
-    cumh += fmaf(eh[k], nh_, pl.min_h);
-    cw[k + 1] = (2.f * B) * cumw + (-B);
-    ch[k + 1] = (2.f * B) * cumh + (-B);
-  }
-  cw[K] = B;
-  ch[K] = B;
-  // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6
+  o.inside = (x >= -B) && (x <= B);
+  // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6; done by the
+  // side that owns the searched knots (widths forward, heights inverse)
   int cnt = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) cnt += (x >= (INV ? ch[k] : cw[k])) ? 1 : 0;
-  cnt += (x >= ((INV ? ch[K] : cw[K]) + 1e-6f)) ? 1 : 0;
+  for (int k = 0; k < K; ++k) cnt += (x >= S.c[k]) ? 1 : 0;
+  cnt += (x >= (S.c[K] + 1e-6f)) ? 1 : 0;
   int idx = cnt - 1;
   idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
-  float cw_i = cw[0], cw_n = cw[1], ch_i = ch[0], ch_n = ch[1];
+  const int idx_o = xchg32i(idx);
+  idx = (part == (INV ? 1 : 0)) ? idx : idx_o;
+  float c_i = S.c[0], c_n = S.c[1];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     const bool hit = (idx == k);
-    cw_i = hit ? cw[k] : cw_i;
-    cw_n = hit ? cw[k + 1] : cw_n;
-    ch_i = hit ? ch[k] : ch_i;
-    ch_n = hit ? ch[k + 1] : ch_n;
+    c_i = hit ? S.c[k] : c_i;
+    c_n = hit ? S.c[k + 1] : c_n;
   }
-  const float w_i = cw_n - cw_i;
-  const float h_i = ch_n - ch_i;
-  const float ud_i = (idx == 0) ? pl.d_const : p[2 * K + idx - 1];
-  const float ud_n = (idx == K - 1) ? pl.d_const : p[2 * K + idx];
-  const float d_i = pl.min_d + softplus_f(ud_i);
-  const float d_n = pl.min_d + softplus_f(ud_n);
+  const float o_i = xchg32(c_i), o_n = xchg32(c_n);
+  o.idx = idx;
+  o.cw_i = part ? o_i : c_i;
+  o.cw_n = part ? o_n : c_n;
+  o.ch_i = part ? c_i : o_i;
+  o.ch_n = part ? c_n : o_n;
+  // derivatives: part 0 evaluates knot idx, part 1 knot idx+1; boundary knots use the constant
+  const int kd = idx + part;
+  o.ud_mine = (kd == 0 || kd == K) ? pl.d_const : p[2 * K + kd - 1];
+  const float d_mine = pl.min_d + softplus_f(o.ud_mine);
+  const float d_oth = xchg32(d_mine);
+  o.d_i = part ? d_oth : d_mine;
+  o.d_n = part ? d_mine : d_oth;
+}
+
+// forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
+// receive y and ld.
+template <int K, bool INV>
+__device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
+                                               float& y, float& ld) {
+  SplineSide<K> S;
+  spline_side<K>(p + part * K, pl, part, S);
+  SplineSel o;
+  spline_select<K, INV>(p, x, pl, part, S, o);
+  const float w_i = o.cw_n - o.cw_i;
+  const float h_i = o.ch_n - o.ch_i;
   const float rw_i = rcp_f(w_i);
   const float delta = h_i * rw_i;
   float yo, lo;
   if (!INV) {
-    const float th = (x - cw_i) * rw_i;
+    const float th = (x - o.cw_i) * rw_i;
     const float tt = th * (1.f - th);
-    const float num = h_i * (delta * (th * th) + d_i * tt);
-    const float den = delta + ((d_i + d_n - 2.f * delta) * tt);
-    yo = ch_i + num * rcp_f(den);
+    const float num = h_i * (delta * (th * th) + o.d_i * tt);
+    const float den = delta + ((o.d_i + o.d_n - 2.f * delta) * tt);
+    yo = o.ch_i + num * rcp_f(den);
     const float omt = 1.f - th;
-    const float dnum = (delta * delta) * (d_n * (th * th) + 2.f * delta * tt + d_i * (omt * omt));
+    const float dnum = (delta * delta) * (o.d_n * (th * th) + 2.f * delta * tt + o.d_i * (omt * omt));
     lo = logf(dnum) - 2.f * logf(den);
   } else {
-    const float s = d_i + d_n - 2.f * delta;
-    const float xc = x - ch_i;
-    const float a = xc * s + h_i * (delta - d_i);
-    const float b = h_i * d_i - xc * s;
+    const float s = o.d_i + o.d_n - 2.f * delta;
+    const float xc = x - o.ch_i;
+    const float a = xc * s + h_i * (delta - o.d_i);
+    const float b = h_i * o.d_i - xc * s;
     const float c = -delta * xc;
     const float disc = b * b - 4.f * a * c;
     const float root = (2.f * c) * rcp_f(-b - sqrtf(disc));
-    yo = root * w_i + cw_i;
+    yo = root * w_i + o.cw_i;
     const float tt = root * (1.f - root);
     const float den = delta + s * tt;
     const float omr = 1.f - root;
-    const float dnum = (delta * delta) * (d_n * (root * root) + 2.f * delta * tt + d_i * (omr * omr));
+    const float dnum = (delta * delta) * (o.d_n * (root * root) + 2.f * delta * tt + o.d_i * (omr * omr));
     lo = -(logf(dnum) - 2.f * logf(den));
   }
-  y = inside ? yo : x;
-  ld = inside ? lo : 0.f;
-  if (bin) {
-    bin->idx = inside ? idx : -1;
-    bin->cw_i = cw_i; bin->w_i = w_i; bin->ch_i = ch_i; bin->h_i = h_i;
-    bin->d_i = d_i; bin->d_ip1 = d_n; bin->ud_i = ud_i; bin->ud_ip1 = ud_n;
-    bin->sw = sw; bin->sh = sh; bin->mw = mw; bin->mh = mh;
-  }
+  y = o.inside ? yo : x;
+  ld = o.inside ? lo : 0.f;
 }
 
 // ---- LULinear on the per-wave state rows (nflows transforms/lu.py) ----------
+// dense D x D mat-vec on a per-wave row buffer for D <= 16: the row is pulled into registers
+// first and every LDS read is independent, so the loads pipeline instead of forming one
+// latency-bound chain per element.  out[ii] = sum_k M[i][k] v[k], i = g + 4 ii.
+// The per-wave row buffers are followed by further finite scratch, and M is zero padded to
+// 16 x 16, so neither needs a bounds check: entries past D meet a zero.
+__device__ __forceinline__ void row_to_regs16(const float* __restrict__ row, int D, float (&v)[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = row[k];
+}
+template <bool TRANSPOSED>
+__device__ __forceinline__ void dense_mv16(const float* __restrict__ M, int D, const float (&v)[16], int g,
+                                           float (&out)[4]) {
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int i = g + 4 * ii;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = fmaf(TRANSPOSED ? M[k * 16 + i] : M[i * 16 + k], v[k], a);
+    out[ii] = a;
+  }
+}
+
 // forward: y = L (U z) + b           (F.linear(F.linear(x, U), L, bias))
 __device__ __forceinline__ void lu_forward(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S,
                                            const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
   const int D = pl.D;
+  const int LUS = D <= 16 ? 16 : D;
+  if (D <= 16) {
+    float v[16], o[4];
+    row_to_regs16(zs + id.j * pl.ZW, D, v);
+    dense_mv16<false>(lds + S.l_U, D, v, id.g, o);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+      if (id.g + 4 * ii < D) us[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+    wave_lds_fence();
+    row_to_regs16(us + id.j * pl.ZW, D, v);
+    dense_mv16<false>(lds + S.l_L, D, v, id.g, o);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+      if (id.g + 4 * ii < D) zs[id.j * pl.ZW + id.g + 4 * ii] = o[ii] + lds[S.l_lub + id.g + 4 * ii];
+    wave_lds_fence();
+    return;
+  }
   for (int i = id.g; i < D; i += 4) {
     float a = 0.f;
-    for (int k = i; k < D; ++k) a += lds[S.l_U + i * D + k] * zs[id.j * pl.ZW + k];
+    for (int k = i; k < D; ++k) a += lds[S.l_U + i * LUS + k] * zs[id.j * pl.ZW + k];
     us[id.j * pl.ZW + i] = a;
   }
   wave_lds_fence();
   for (int i = id.g; i < D; i += 4) {
     float a = lds[S.l_lub + i];
-    for (int k = 0; k <= i; ++k) a += lds[S.l_L + i * D + k] * us[id.j * pl.ZW + k];
+    for (int k = 0; k <= i; ++k) a += lds[S.l_L + i * LUS + k] * us[id.j * pl.ZW + k];
     zs[id.j * pl.ZW + i] = a;
   }
   wave_lds_fence();
@@ -413,26 +490,26 @@ __device__ __forceinline__ void lu_forward(const float* __restrict__ lds, const 
 __device__ __forceinline__ void lu_inverse(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S,
                                            const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
   const int D = pl.D;
+  const int LUS = D <= 16 ? 16 : D;
   if (id.g == 0) {
     float* z = zs + id.j * pl.ZW;
     float* u = us + id.j * pl.ZW;
     for (int i = 0; i < D; ++i) {
       float a = z[i] - lds[S.l_lub + i];
-      for (int k = 0; k < i; ++k) a -= lds[S.l_L + i * D + k] * u[k];
+      for (int k = 0; k < i; ++k) a -= lds[S.l_L + i * LUS + k] * u[k];
       u[i] = a;
     }
     for (int i = D - 1; i >= 0; --i) {
       float a = u[i];
-      for (int k = i + 1; k < D; ++k) a -= lds[S.l_U + i * D + k] * z[k];
-      z[i] = a / lds[S.l_U + i * D + i];
+      for (int k = i + 1; k < D; ++k) a -= lds[S.l_U + i * LUS + k] * z[k];
+      z[i] = a / lds[S.l_U + i * LUS + i];
     }
   }
   wave_lds_fence();
 }
+// sum_i log U_ii, precomputed by the pack kernel (slot right behind the LU bias)
 __device__ __forceinline__ float lu_logabsdet(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S) {
-  float a = 0.f;
-  for (int i = 0; i < pl.D; ++i) a += logf(lds[S.l_U + i * pl.D + i]);
-  return a;
+  return lds[S.l_lub + pl.D];
 }
 
 // conditioner input rows: cin[j] = [ z[identity dims] ; standardized context ; 0 pad ]

@@ -7,6 +7,7 @@
 // Reference path replaced: nflows_flow.py:77-128 -> nflows Flow/CompositeTransform
 // (SURVEY.md 3.2, Appendix A).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "nsf_device.h"
 
 // one workgroup per transform: flat parameters -> packed MFMA weight image
@@ -21,7 +22,10 @@ template <int K, int KSH, bool INV>
 __global__ void __launch_bounds__(512)
 nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
-                float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash) {
+                float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
+                long long* __restrict__ dbg) {
+#define TSF(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && li == 1) \
+    dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -45,6 +49,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
   const float* x_std = x_mean + C;
 
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
+  for (int i = id.lane; i < pl.sc_total; i += 64) sc[i] = 0.f;   // no uninitialised LDS behind short rows
   // ---- load + z-score (PointwiseAffineTransform fwd / Standardize) ----
   {
     const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
@@ -67,10 +72,14 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     const int t = INV ? (pl.T - 1 - li) : li;
     const int par = t & 1;
     const ShapeDesc& S = pl.shape[par];
+    TSF(0);
     __syncthreads();   // every wave is done with the previous layer's weights
+    TSF(1);
     if (!(pl.ablate & 16) || li == 0)
       stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
+    TSF(2);
     __syncthreads();
+    TSF(3);
 
     if (!INV && z_stash) {
       for (int d = id.g; d < D; d += 4)
@@ -81,28 +90,38 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
     build_cin(pl, S, par, id, zs, cs, cin);
+    TSF(4);
 
     f4 h[NSF_HT];
     if (!(pl.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
+    TSF(5);
     for (int d0 = 0; d0 < S.d_tr; d0 += pl.DCH) {
+      TSF(6 + 2 * (d0 / pl.DCH));
       if (!(pl.ablate & 2)) final_layer_chunk<PT, KSH>(lds, pst, pl, S, id, h, d0);
       wave_lds_fence();
-      const int dd = d0 + id.g;
-      if (id.g < pl.DCH && dd < S.d_tr && !(pl.ablate & 1)) {
+      TSF(7 + 2 * (d0 / pl.DCH));
+      // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id
+      const int slot = id.g & 1, part = id.g >> 1;
+      const int dd = d0 + slot;
+      if (slot < pl.DCH && dd < S.d_tr && !(pl.ablate & 1)) {
         const int zi = id.j * pl.ZW + 2 * dd + par;
         float y, ld;
-        rq_spline<K, INV>(pst + id.g * pl.DS + id.j * pl.PSW, zs[zi], pl, y, ld);
-        zs[zi] = y;
-        ld_acc += ld;
+        rq_spline_pair<K, INV>(pst + slot * pl.DS + id.j * pl.PSW, zs[zi], pl, part, y, ld);
+        if (part == 0) {
+          zs[zi] = y;
+          ld_acc += ld;
+        }
       }
       wave_lds_fence();
     }
+    TSF(20);
     if (!INV && !(pl.ablate & 8)) {
       lu_forward(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
     }
+    TSF(21);
   }
 
   // ---- epilogue ----
@@ -111,7 +130,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     for (int d = id.g; d < D; d += 4) {
       float z = zs[id.j * pl.ZW + d];
       part += z * z;
-      if (out_aux && valid) out_aux[row * D + d] = z;
+      if (out_aux && valid && !dbg) out_aux[row * D + d] = z;
     }
     float v = -0.5f * part + ld_acc;
     v += __shfl_xor(v, 16);
@@ -142,7 +161,8 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
   const int64_t rows_per_wg = 16 * nw;
   const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, packed, zstats, in,
-                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash);
+                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash,
+                     getenv("SBI_AMD_TIMELINE") ? (long long*)out_aux : nullptr);
   return (int)hipGetLastError();
 }
 

@@ -88,9 +88,10 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     s->g_lu = g;
     g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias
     s->n_params = g;
-    s->l_U = l; l += D * D;
-    s->l_L = l; l += D * D;
-    s->l_lub = l; l += D;
+    { const int lus = D <= 16 ? 16 : D;   // dense U, L padded to 16 x 16 for D <= 16
+      s->l_U = l; l += lus * lus;
+      s->l_L = l; l += lus * lus; }
+    s->l_lub = l; l += D + 1;   // bias, then sum_i log U_ii
     s->lds_floats = round_up(l + 64, 4);   // slack: tail K-steps of the last rows read past their row
     if (s->lds_floats > pl->lds_w_floats) pl->lds_w_floats = s->lds_floats;
   }
@@ -124,7 +125,8 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->sc_pst = o;
   int fixed = o;
   int d_tr_max = pl->shape[0].d_tr;
-  int dch = NSF_MAX_DCH < d_tr_max ? NSF_MAX_DCH : d_tr_max;
+  // a spline task occupies a lane PAIR, so a 64-lane wave evaluates 16 rows x 2 dims per pass
+  int dch = 2 < d_tr_max ? 2 : d_tr_max;
   for (; dch >= 1; --dch) {
     int tot = round_up(fixed + dch * pl->DS, 4);
     if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * tot) <= NSF_LDS_LIMIT_BYTES) {

@@ -16,7 +16,7 @@
 #define NSF_MAX_NB 4
 #define NSF_MAX_LIN (2 + 3 * NSF_MAX_NB)
 #define NSF_HT 4          // hidden tiles of 16 -> H <= 64
-#define NSF_MAX_DCH 4     // spline dims processed per chunk (one per 16-lane group)
+#define NSF_MAX_DCH 2     // spline dims per chunk: one (row, dim) task per lane pair (lane, lane^32)
 #define NSF_LDS_LIMIT_BYTES (160 * 1024)
 
 struct LinDesc {

@@ -13,6 +13,7 @@
 //      workgroup's rows;
 //   3. a deterministic reduction of the per-workgroup partial gradients (no atomics).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "nsf_device.h"
 
 #define TR_NW 4            // waves per workgroup
@@ -38,6 +39,7 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   if (d_id_max + pl.C + 1 > 32 || pl.C + 1 > 32) return SBI_AMD_E_UNSUPPORTED;
   tp->DCHB = 4 / pl.PT;
   if (tp->DCHB < 1) return SBI_AMD_E_UNSUPPORTED;
+  if (tp->DCHB > 2) tp->DCHB = 2;   // a spline task occupies a lane pair
   tp->PTW = 16 * pl.PT;
   for (int par = 0; par < 2; ++par) {
     tp->nch[par] = (pl.shape[par].d_tr + tp->DCHB - 1) / tp->DCHB;
@@ -136,7 +138,7 @@ template <int PT, int KSH>
 __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ lds, float* __restrict__ arow,
                                                     const NsfPlan& pl, const TrainPlan& tp, const ShapeDesc& S,
                                                     const LaneId& id, const f4 (&h)[NSF_HT], int d0) {
-  constexpr int DCHB = 4 / PT;
+  constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
   const LinDesc& L = S.lin[1 + 3 * pl.NB];
   f4 acc[DCHB][PT];
   int ro[DCHB][PT];
@@ -169,70 +171,27 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
       for (int r = 0; r < 4; ++r) arow[id.j * tp.SA + sl * 16 * PT + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
 }
 
-// RQ spline forward + reverse-mode gradient for one (row, dim).  `p` holds the 3K-1 raw
-// conditioner outputs on entry and d(gy*y + gl*logabsdet)/d(raw outputs) on exit
-// (entries [3K-1, plen) are zeroed).  Formulas: DESIGN.md "spline backward".
+// RQ spline forward + reverse-mode gradient for one (row, dim) task on a lane pair (see
+// rq_spline_pair).  `p` holds the 3K-1 raw conditioner outputs on entry and
+// d(gy*y + gl*logabsdet)/d(raw outputs) on exit (entries [3K-1, plen) zeroed): part 0 writes the
+// width logits and all derivative slots but one, part 1 the height logits, its own derivative
+// slot and the padding.  Formulas: DESIGN.md "spline backward".
 template <int K>
-__device__ __forceinline__ void rq_spline_fwd_bwd(float* __restrict__ p, int plen, float x, float gy, float gl,
-                                                  const NsfPlan& pl, float& y, float& gx) {
+__device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int plen, float x, float gy, float gl,
+                                                   const NsfPlan& pl, int part, float& y, float& gx) {
   const float B = pl.B;
-  const bool inside = (x >= -B) && (x <= B);
-  float ew[K], eh[K];
-  float mw = -INFINITY, mh = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    ew[k] = p[k] * pl.inv_sqrt_h;
-    eh[k] = p[K + k] * pl.inv_sqrt_h;
-    mw = fmaxf(mw, ew[k]);
-    mh = fmaxf(mh, eh[k]);
-  }
-  float sw = 0.f, sh = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    ew[k] = exp_f(ew[k] - mw);
-    eh[k] = exp_f(eh[k] - mh);
-    sw += ew[k];
-    sh += eh[k];
-  }
-  const float isw = rcp_f(sw), ish = rcp_f(sh);
-  float cw[K + 1], ch[K + 1];
-  float cumw = 0.f, cumh = 0.f;
-  cw[0] = -B;
-  ch[0] = -B;
-  const float nw_ = pl.one_minus_kw * isw, nh_ = pl.one_minus_kh * ish;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    cumw += fmaf(ew[k], nw_, pl.min_w);
-    cumh += fmaf(eh[k], nh_, pl.min_h);
-    cw[k + 1] = (2.f * B) * cumw + (-B);
-    ch[k + 1] = (2.f * B) * cumh + (-B);
-  }
-  cw[K] = B;
-  ch[K] = B;
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < K; ++k) cnt += (x >= cw[k]) ? 1 : 0;
-  cnt += (x >= (cw[K] + 1e-6f)) ? 1 : 0;
-  int idx = cnt - 1;
-  idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
-  float cw_i = cw[0], cw_n = cw[1], ch_i = ch[0], ch_n = ch[1];
-#pragma unroll
-  for (int k = 1; k < K; ++k) {
-    const bool hit = (idx == k);
-    cw_i = hit ? cw[k] : cw_i;
-    cw_n = hit ? cw[k + 1] : cw_n;
-    ch_i = hit ? ch[k] : ch_i;
-    ch_n = hit ? ch[k + 1] : ch_n;
-  }
-  const float ud_i = (idx == 0) ? pl.d_const : p[2 * K + idx - 1];
-  const float ud_n = (idx == K - 1) ? pl.d_const : p[2 * K + idx];
-  const float d_i = pl.min_d + softplus_f(ud_i);
-  const float d_n = pl.min_d + softplus_f(ud_n);
+  SplineSide<K> S;
+  spline_side<K>(p + part * K, pl, part, S);
+  SplineSel o;
+  spline_select<K, false>(p, x, pl, part, S, o);
+  const bool inside = o.inside;
+  const int idx = o.idx;
+  const float d_i = o.d_i, d_n = o.d_n;
   // ---- forward
-  const float w = cw_n - cw_i, h = ch_n - ch_i;
+  const float w = o.cw_n - o.cw_i, h = o.ch_n - o.ch_i;
   const float rw = rcp_f(w);
   const float delta = h * rw;
-  const float th = (x - cw_i) * rw;
+  const float th = (x - o.cw_i) * rw;
   const float omt = 1.f - th;
   const float tt = th * omt;
   const float q = delta * (th * th) + d_i * tt;
@@ -241,7 +200,7 @@ __device__ __forceinline__ void rq_spline_fwd_bwd(float* __restrict__ p, int ple
   const float den = delta + s * tt;
   const float rden = rcp_f(den);
   const float r = d_n * (th * th) + 2.f * delta * tt + d_i * (omt * omt);
-  y = inside ? (ch_i + num * rden) : x;
+  y = inside ? (o.ch_i + num * rden) : x;
   // ---- reverse
   float gc = gy;
   const float gnum = gy * rden;
@@ -279,34 +238,34 @@ __device__ __forceinline__ void rq_spline_fwd_bwd(float* __restrict__ p, int ple
   const float ge = gw;
   ga -= gw;
   gx = inside ? gxi : gy;
-  // ---- knots -> softmax logits
-  const float Gi = (inside && idx >= 1) ? (2.f * B) * ga : 0.f;
-  const float Gn = (inside && idx <= K - 2) ? (2.f * B) * ge : 0.f;
-  const float Hi = (inside && idx >= 1) ? (2.f * B) * gc : 0.f;
-  const float Hn = (inside && idx <= K - 2) ? (2.f * B) * gf : 0.f;
-  float dotw = 0.f, doth = 0.f;
-  float gsw[K], gsh[K];
+  // ---- my side: knots -> softmax logits
+  const float g_lo = part ? gc : ga, g_hi = part ? gf : ge;
+  const float Gi = (inside && idx >= 1) ? (2.f * B) * g_lo : 0.f;
+  const float Gn = (inside && idx <= K - 2) ? (2.f * B) * g_hi : 0.f;
+  const float omk = part ? pl.one_minus_kh : pl.one_minus_kw;
+  float dot = 0.f;
+  float gsm[K];
 #pragma unroll
   for (int m = 0; m < K; ++m) {
     const float gwm = (m < idx) ? (Gi + Gn) : ((m == idx) ? Gn : 0.f);
-    const float ghm = (m < idx) ? (Hi + Hn) : ((m == idx) ? Hn : 0.f);
-    ew[m] *= isw;   // softmax probabilities
-    eh[m] *= ish;
-    gsw[m] = pl.one_minus_kw * gwm;
-    gsh[m] = pl.one_minus_kh * ghm;
-    dotw += gsw[m] * ew[m];
-    doth += gsh[m] * eh[m];
+    S.e[m] *= S.inv_s;   // softmax probabilities
+    gsm[m] = omk * gwm;
+    dot += gsm[m] * S.e[m];
   }
-  const float gudi = (inside && idx >= 1) ? gdi * sigmoid_f(ud_i) : 0.f;
-  const float gudn = (inside && idx <= K - 2) ? gdn * sigmoid_f(ud_n) : 0.f;
+  float* q_out = p + part * K;
 #pragma unroll
-  for (int m = 0; m < K; ++m) {
-    p[m] = ew[m] * (gsw[m] - dotw) * pl.inv_sqrt_h;
-    p[K + m] = eh[m] * (gsh[m] - doth) * pl.inv_sqrt_h;
+  for (int m = 0; m < K; ++m) q_out[m] = S.e[m] * (gsm[m] - dot) * pl.inv_sqrt_h;
+  // ---- derivative slots: knot kd = idx + part is mine (interior knots only)
+  const int kd = idx + part;
+  const float gud = (inside && kd >= 1 && kd <= K - 1) ? (part ? gdn : gdi) * sigmoid_f(o.ud_mine) : 0.f;
+  if (part == 0) {
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k)
+      if (k != idx) p[2 * K + k] = (k + 1 == idx) ? gud : 0.f;
+  } else {
+    if (idx <= K - 2) p[2 * K + idx] = gud;
+    for (int k = 3 * K - 1; k < plen; ++k) p[k] = 0.f;
   }
-#pragma unroll
-  for (int k = 0; k < K - 1; ++k) p[2 * K + k] = (k + 1 == idx) ? gudi : ((k == idx) ? gudn : 0.f);
-  for (int k = 3 * K - 1; k < plen; ++k) p[k] = 0.f;
 }
 
 // partial-gradient write-out of one weight tile (lane (g,j), reg r: out = out0+4g+r, in = 16nt+j)
@@ -335,9 +294,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
                      const float* __restrict__ zstats, const float* __restrict__ z_in,
                      const float* __restrict__ x, const float* __restrict__ gz_up,
                      const float* __restrict__ row_w, const float uni_w, long long n, long long x_rows,
-                     float* __restrict__ gz_dn, float* __restrict__ partial, float* __restrict__ grad_theta) {
+                     float* __restrict__ gz_dn, float* __restrict__ partial, float* __restrict__ grad_theta,
+                     long long* __restrict__ dbg) {
+#define TS(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tile == (int)blockIdx.x) \
+    dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
-  constexpr int DCHB = 4 / PT;
+  constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);   // dim slots per chunk (lane pairs: <= 2)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
@@ -375,6 +337,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 
   if (wave < TR_NW) {
     // =========================== row waves ===========================
+    // the guard-free mat-vec helpers read up to 6 floats past a 10-float row: make sure that
+    // never is uninitialised LDS (NaN x 0 = NaN)
+    for (int i = id.lane; i < tp.w_total; i += 64) sc[i] = 0.f;
     const LaneId id0 = id;
     for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
       // Re-materialise the lane coordinates per tile: otherwise LICM hoists every
@@ -387,6 +352,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const float wn = valid ? (row_w ? row_w[row] : uni_w) : 0.f;
       const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
       __syncthreads();                             // weights staged / previous tile's shared reads done
+      TS(0);
       // ---- P0: load state, context, upstream gradient
       {
         const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
@@ -402,22 +368,29 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       wave_lds_fence();
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
-      if (!(pl.ablate & 64))
-      for (int k = id.g; k < D; k += 4) {
-        float a = 0.f;
-        for (int i = k; i < D; ++i) a += lds[S.l_L + i * D + k] * gzs[id.j * pl.ZW + i];
-        gus[id.j * pl.ZW + k] = a;
-      }
-      wave_lds_fence();
-      for (int k = id.g; k < D; k += 4) {
-        float a = 0.f;
-        for (int i = 0; i <= k; ++i) a += lds[S.l_U + i * D + k] * gus[id.j * pl.ZW + i];
-        gys[id.j * pl.ZW + k] = a;
-        gxs[id.j * pl.ZW + k] = a;                 // identity dims pass through (transformed dims overwritten)
-        ys[id.j * pl.ZW + k] = zs[id.j * pl.ZW + k];
+      if (!(pl.ablate & 64)) {
+        float v[16], o[4];
+        row_to_regs16(gzs + id.j * pl.ZW, D, v);
+        dense_mv16<true>(lds + S.l_L, D, v, id.g, o);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+          if (id.g + 4 * ii < D) gus[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+        wave_lds_fence();
+        row_to_regs16(gus + id.j * pl.ZW, D, v);
+        dense_mv16<true>(lds + S.l_U, D, v, id.g, o);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int k = id.g + 4 * ii;
+          if (k < D) {
+            gys[id.j * pl.ZW + k] = o[ii];
+            gxs[id.j * pl.ZW + k] = o[ii];             // identity dims pass through (transformed dims overwritten)
+            ys[id.j * pl.ZW + k] = zs[id.j * pl.ZW + k];
+          }
+        }
       }
       build_cin(pl, S, par, id, zs, cs, cin);
       const float* cin_row = cin + id.j * pl.CINW + id.g;
+      TS(1);
 
       // ---- P1: recompute the conditioner's hidden stack; keep the block inputs h_0..h_NB
       // (the per-block temporaries are recomputed again in P3 to stay inside 512 registers)
@@ -447,6 +420,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           for (int r = 0; r < 4; ++r) hpre[b + 1][mt][r] = hpre[b][mt][r] + t1[mt][r] * sigmoid_f(sg[mt][r]);
       }
 
+      TS(2);
       // ---- P2: final layer + spline, chunk by chunk; d Wf; g_h = Wf^T g_p
       stage_D(Bst, SA, arow0 + id.j, id, hpre[NB], false);
       if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;      // bias column
@@ -457,22 +431,32 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       for (int c = 0; c < NCH; ++c) {
         if (c < nch) {
           const int d0 = c * DCHB;
+          TS(3 + 4 * c);
           if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);
           wave_lds_fence();
-          if (id.g < DCHB) {
-            const int dd = d0 + id.g;
-            float* pp = Arow + id.j * SA + id.g * tp.PTW;
-            if (dd < S.d_tr && !(pl.ablate & 4)) {
-              const int zi = id.j * pl.ZW + 2 * dd + par;
-              float yv, gxv;
-              rq_spline_fwd_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, yv, gxv);
-              ys[zi] = yv;
-              gxs[zi] = gxv;
-            } else {
-              for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;
+          TS(4 + 4 * c);
+          {
+            // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id
+            const int slot = id.g & 1, part = id.g >> 1;
+            const int dd = d0 + slot;
+            float* pp = Arow + id.j * SA + slot * tp.PTW;
+            if (slot < DCHB) {
+              if (dd < S.d_tr && !(pl.ablate & 4)) {
+                const int zi = id.j * pl.ZW + 2 * dd + par;
+                float yv, gxv;
+                rq_spline_pair_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);
+                if (part == 0) {
+                  ys[zi] = yv;
+                  gxs[zi] = gxv;
+                }
+              } else if (part == 0) {
+                for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;
+              }
             }
           }
+          TS(5 + 4 * c);
           __syncthreads();
+          TS(6 + 4 * c);
           // g_h += Wf[chunk rows]^T g_p   (own rows; B operand from the shared A tile)
           if (!(pl.ablate & 2)) {
             int co[NSF_HT];
@@ -505,6 +489,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         }
       }
 
+      TS(19);
       // ---- P3: residual blocks, last -> first
 #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
@@ -535,6 +520,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
               gc[mt][r] = gh[mt][r] * t2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
             }
         }
+        TS(20 + 8 * b);
         // d W2 : A = g_t2, B = relu(t1)
         stage_D(Ast, SA, arow0 + id.j, id, ga, false);
         stage_D(Bst, SA, arow0 + id.j, id, t1, true);
@@ -542,8 +528,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+        TS(21 + 8 * b);
         gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb, pl.ablate);       // d relu(t1)
+        TS(22 + 8 * b);
         __syncthreads();
+        TS(23 + 8 * b);
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -555,8 +544,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+        TS(24 + 8 * b);
         gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb, pl.ablate);       // d relu(h_b)
+        TS(25 + 8 * b);
         __syncthreads();
+        TS(26 + 8 * b);
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -569,6 +561,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         __syncthreads();
       }
 
+      TS(40);
       // ---- P4: initial layer
       stage_D(Ast, SA, arow0 + id.j, id, gh, false);
       for (int k = id.g; k < 16 * nt0; k += 4)
@@ -586,12 +579,15 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       __syncthreads();
 
+      TS(41);
       // ---- P5: LULinear parameter gradients as two more 16x16 tiles
-      if (!(pl.ablate & 64))
-      for (int i = id.g; i < D; i += 4) {
-        float a = 0.f;
-        for (int k = i; k < D; ++k) a += lds[S.l_U + i * D + k] * ys[id.j * pl.ZW + k];
-        us[id.j * pl.ZW + i] = a;
+      if (!(pl.ablate & 64)) {
+        float v[16], o[4];
+        row_to_regs16(ys + id.j * pl.ZW, D, v);
+        dense_mv16<false>(lds + S.l_U, D, v, id.g, o);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+          if (id.g + 4 * ii < D) us[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
       }
       wave_lds_fence();
       for (int k = id.g; k < 16; k += 4) {
@@ -603,6 +599,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       __syncthreads();
 
+      TS(42);
       // ---- P6: gradient wrt this transform's input
       for (int d = id.g; d < D; d += 4) {
         if (valid) {
@@ -611,6 +608,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           else if (grad_theta) grad_theta[row * D + d] = g * zstats[D + d];
         }
       }
+      TS(43);
     }
 
   } else {
@@ -640,21 +638,28 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       asm volatile("" : "+v"(id.j), "+v"(id.g));
       // mirrors the row waves' barrier sequence exactly
       __syncthreads();
+      TS(0);
   #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         if (c < nch) {
           __syncthreads();
+          TS(6 + 4 * c);
           dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, accF[c], 4, pl.ablate);
+          TS(7 + 4 * c);
           __syncthreads();
         }
       }
   #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
         __syncthreads();
+        TS(21 + 8 * b);
         dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
+        TS(22 + 8 * b);
         __syncthreads();
         __syncthreads();
+        TS(24 + 8 * b);
         dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
+        TS(25 + 8 * b);
         __syncthreads();
         __syncthreads();
         dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc, pl.ablate);
@@ -800,6 +805,8 @@ static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int6
   *o_gzb = o; o += n * pl.D;
   o = (o + 3) / 4 * 4;
   *o_part = o; o += (int64_t)pl.T * tp.grid * tp.PLP;
+  o = (o + 3) / 4 * 4;
+  o += 2048;   // debug timeline (SBI_AMD_TIMELINE): last 1024 int64 of the workspace
   return o;
 }
 
@@ -817,13 +824,14 @@ extern "C" int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* 
 template <int K, int KSH, int NB, int NCH>
 static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
                       const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
-                      int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta, hipStream_t st) {
+                      int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta, long long* dbg,
+                      hipStream_t st) {
   auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH>;
   const int lds_bytes = 4 * tp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(tp.grid), dim3(128 * TR_NW), (size_t)lds_bytes, st, pl, tp, t, packed, zstats, z_in, x,
-                     gz_up, row_w, uni_w, (long long)n, (long long)x_rows, gz_dn, partial, grad_theta);
+                     gz_up, row_w, uni_w, (long long)n, (long long)x_rows, gz_dn, partial, grad_theta, dbg);
   return (int)hipGetLastError();
 }
 
@@ -831,8 +839,9 @@ template <int K>
 static int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
                         const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
                         int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
-                        hipStream_t st) {
-#define BWD_ARGS pl, tp, t, packed, zstats, z_in, x, gz_up, row_w, uni_w, n, x_rows, gz_dn, partial, grad_theta, st
+                        long long* dbg, hipStream_t st) {
+#define BWD_ARGS pl, tp, t, packed, zstats, z_in, x, gz_up, row_w, uni_w, n, x_rows, gz_dn, partial, grad_theta, \
+                 dbg, st
   const int nchmax = tp.nch[0] > tp.nch[1] ? tp.nch[0] : tp.nch[1];
 #define BWD_NCH(KS, NBV) \
   switch (nchmax) { \
@@ -867,6 +876,7 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
   float* logp = workspace + o_logp;
   float* gz[2] = {workspace + o_gza, workspace + o_gzb};
   float* partial = workspace + o_part;
+  long long* dbg = (long long*)(workspace + (o_part + (int64_t)pl.T * tp.grid * tp.PLP + 3) / 4 * 4);
 
   rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, logp, noise, stash, stream);
   if (rc) return rc;
@@ -881,7 +891,7 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
     switch (cfg->K) {
 #define CASE_K(KK) \
   case KK: rc = launch_bwd_k<KK>(pl, tp, t, packed, zstats, z_in, x, up, row_weight, uniform_weight, n, x_rows, dn, \
-                                 partial, grad_theta_out, st); break;
+                                 partial, grad_theta_out, (t == 0 && getenv("SBI_AMD_TIMELINE")) ? dbg : nullptr, st); break;
       CASE_K(10)
 #undef CASE_K
       default: rc = SBI_AMD_E_UNSUPPORTED;
