@@ -205,6 +205,15 @@ __device__ __forceinline__ float exp_f(float x) {
   return fmaf(e, tl * 0.6931471805599453f, e);
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return rcp_f(1.0f + exp_f(-x)); }
+// natural log on the hardware v_log_f32 (1 ulp log2): branch-free, ~3 instructions
+__device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+// softplus(x) = max(x,0) + log1p(exp(-|x|)), branch-free; log1p via the (1+t) compensation trick
+__device__ __forceinline__ float softplus_bf(float x) {
+  const float t = exp_f(-fabsf(x));
+  const float u = 1.0f + t;
+  const float l1p = log_f(u) - ((u - 1.0f) - t) * rcp_f(u);
+  return fmaxf(x, 0.f) + l1p;
+}
 
 // ResidualNet hidden stack (nflows nn/nets/resnet.py, configuration flow.py:411-419):
 // h = W0 [z_id; c] + b0;  per block: t = W2 relu(W1 relu(h) + b1) + b2; h += t * sigmoid(Wc c + bc)
@@ -271,10 +280,8 @@ __device__ __forceinline__ void final_layer_chunk_n(const float* __restrict__ ld
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = 16 * pt + 4 * r + id.g;
-        if (p < pl.P) pst[sl * pl.DS + id.j * pl.PSW + p] = acc[sl][pt][r];
-      }
+      for (int r = 0; r < 4; ++r)   // rows are 16*PT+1 wide: padding outputs (zeros) are stored too, no branch
+        pst[sl * pl.DS + id.j * pl.PSW + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
 }
 
 template <int PT, int KSH>
@@ -380,8 +387,10 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
   o.ch_n = part ? c_n : o_n;
   // derivatives: part 0 evaluates knot idx, part 1 knot idx+1; boundary knots use the constant
   const int kd = idx + part;
-  o.ud_mine = (kd == 0 || kd == K) ? pl.d_const : p[2 * K + kd - 1];
-  const float d_mine = pl.min_d + softplus_f(o.ud_mine);
+  const int kc = kd - 1 < 0 ? 0 : (kd - 1 > K - 2 ? K - 2 : kd - 1);   // always a valid slot: no branch
+  const float ud_ld = p[2 * K + kc];
+  o.ud_mine = (kd == 0 || kd == K) ? pl.d_const : ud_ld;
+  const float d_mine = pl.min_d + softplus_bf(o.ud_mine);
   const float d_oth = xchg32(d_mine);
   o.d_i = part ? d_oth : d_mine;
   o.d_n = part ? d_mine : d_oth;
@@ -409,7 +418,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
     yo = o.ch_i + num * rcp_f(den);
     const float omt = 1.f - th;
     const float dnum = (delta * delta) * (o.d_n * (th * th) + 2.f * delta * tt + o.d_i * (omt * omt));
-    lo = logf(dnum) - 2.f * logf(den);
+    lo = log_f(dnum) - 2.f * log_f(den);
   } else {
     const float s = o.d_i + o.d_n - 2.f * delta;
     const float xc = x - o.ch_i;
@@ -423,7 +432,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
     const float den = delta + s * tt;
     const float omr = 1.f - root;
     const float dnum = (delta * delta) * (o.d_n * (root * root) + 2.f * delta * tt + o.d_i * (omr * omr));
-    lo = -(logf(dnum) - 2.f * logf(den));
+    lo = -(log_f(dnum) - 2.f * log_f(den));
   }
   y = o.inside ? yo : x;
   ld = o.inside ? lo : 0.f;
@@ -512,15 +521,26 @@ __device__ __forceinline__ float lu_logabsdet(const float* __restrict__ lds, con
   return lds[S.l_lub + pl.D];
 }
 
-// conditioner input rows: cin[j] = [ z[identity dims] ; standardized context ; 0 pad ]
+// conditioner input rows: cin[j] = [ z[identity dims] ; standardized context ; 0 pad ].
+// For C <= 16 the context of lane (j,g) is held in registers: cr[u] = c[g + 4u].
 __device__ __forceinline__ void build_cin(const NsfPlan& pl, const ShapeDesc& S, int parity, const LaneId& id,
                                           const float* __restrict__ zs, const float* __restrict__ cs,
-                                          float* __restrict__ cin) {
-  for (int k = id.g; k < pl.CINW; k += 4) {
-    float v = 0.f;
-    if (k < S.d_id) v = zs[id.j * pl.ZW + 2 * k + (1 - parity)];
-    else if (k < S.in0) v = cs[id.j * pl.CW + (k - S.d_id)];
-    cin[id.j * pl.CINW + k] = v;
+                                          const float (&cr)[4], float* __restrict__ cin) {
+  if (pl.C <= 16) {
+    for (int k = id.g; k < pl.CINW; k += 4)
+      if (k < S.d_id || k >= S.in0) cin[id.j * pl.CINW + k] = k < S.d_id ? zs[id.j * pl.ZW + 2 * k + (1 - parity)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = id.g + 4 * u;
+      if (c < pl.C) cin[id.j * pl.CINW + S.d_id + c] = cr[u];
+    }
+  } else {
+    for (int k = id.g; k < pl.CINW; k += 4) {
+      float v = 0.f;
+      if (k < S.d_id) v = zs[id.j * pl.ZW + 2 * k + (1 - parity)];
+      else if (k < S.in0) v = cs[id.j * pl.CW + (k - S.d_id)];
+      cin[id.j * pl.CINW + k] = v;
+    }
   }
   wave_lds_fence();
 }

@@ -39,6 +39,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
   float* cs = sc + pl.sc_cs;
   float* cin = sc + pl.sc_cin;
   float* pst = sc + pl.sc_pst;
+  float* pst2 = sc + pl.sc_pst2;
 
   const long long row = (long long)blockIdx.x * (16 * nw) + 16 * wave + id.j;
   const bool valid = row < n;
@@ -49,6 +50,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
   const float* x_std = x_mean + C;
 
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
+  float cr[4] = {0.f, 0.f, 0.f, 0.f};   // standardized context of this lane (C <= 16)
   for (int i = id.lane; i < pl.sc_total; i += 64) sc[i] = 0.f;   // no uninitialised LDS behind short rows
   // ---- load + z-score (PointwiseAffineTransform fwd / Standardize) ----
   {
@@ -61,9 +63,17 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       }
       zs[id.j * pl.ZW + d] = v;
     }
-    for (int c = id.g; c < C; c += 4) {
-      float v = valid ? x[xr * C + c] : 0.f;
-      cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
+    if (C <= 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = id.g + 4 * u;
+        cr[u] = (c < C) ? ((valid ? x[xr * C + c] : 0.f) - x_mean[c]) / x_std[c] : 0.f;
+      }
+    } else {
+      for (int c = id.g; c < C; c += 4) {
+        float v = valid ? x[xr * C + c] : 0.f;
+        cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
+      }
     }
   }
   wave_lds_fence();
@@ -89,7 +99,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       lu_inverse(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
-    build_cin(pl, S, par, id, zs, cs, cin);
+    build_cin(pl, S, par, id, zs, cs, cr, cin);
     TSF(4);
 
     f4 h[NSF_HT];
@@ -97,24 +107,70 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
     TSF(5);
-    for (int d0 = 0; d0 < S.d_tr; d0 += pl.DCH) {
-      TSF(6 + 2 * (d0 / pl.DCH));
-      if (!(pl.ablate & 2)) final_layer_chunk<PT, KSH>(lds, pst, pl, S, id, h, d0);
-      wave_lds_fence();
-      TSF(7 + 2 * (d0 / pl.DCH));
-      // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id
-      const int slot = id.g & 1, part = id.g >> 1;
-      const int dd = d0 + slot;
-      if (slot < pl.DCH && dd < S.d_tr && !(pl.ablate & 1)) {
+    // ---- final layer + spline, software-pipelined over chunks of DCH dims: the MFMA stream of
+    // chunk c+1 (into the other staging buffer) is issued in the same basic block as the VALU-only
+    // spline of chunk c, so the matrix pipe works under the spline's latency chains.
+    {
+      const int nchunks = (S.d_tr + pl.DCH - 1) / pl.DCH;
+      const int dch_ = pl.DCH, dtr_ = S.d_tr;
+      const bool spl_on = !(pl.ablate & 1);
+      // integer offsets (not a pointer array): keeps the accesses in the LDS address space
+      auto spline_chunk = [&](int c) {
+        // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id.
+        // Executed by every lane (idle slots recompute a valid task and drop the result) to keep
+        // the block branch-free.
+        const int slot = id.g & 1, part = id.g >> 1;
+        const int dd_raw = c * pl.DCH + slot;
+        const bool live = (slot < dch_) & (dd_raw < dtr_) & spl_on;   // bitwise: no short-circuit branches
+        const int sl = live ? slot : 0;
+        const int dd = live ? dd_raw : c * pl.DCH;
         const int zi = id.j * pl.ZW + 2 * dd + par;
         float y, ld;
-        rq_spline_pair<K, INV>(pst + slot * pl.DS + id.j * pl.PSW, zs[zi], pl, part, y, ld);
-        if (part == 0) {
-          zs[zi] = y;
-          ld_acc += ld;
-        }
+        rq_spline_pair<K, INV>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part,
+                               y, ld);
+        // every lane stores: partner / idle lanes hold the same y for the same zi (idempotent)
+        zs[zi] = y;
+        ld_acc += (live && part == 0) ? ld : 0.f;
+      };
+      {
+        const int n0 = S.d_tr < pl.DCH ? S.d_tr : pl.DCH;
+        if (n0 == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 0);
+        else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, 0);
       }
       wave_lds_fence();
+      for (int c = 0; c < nchunks; ++c) {
+        TSF(6 + 2 * c);
+        const int dnext = (c + 1) * pl.DCH;
+        int nnext = S.d_tr - dnext;
+        nnext = nnext < 0 ? 0 : (nnext < pl.DCH ? nnext : pl.DCH);
+        if (nnext == 2) {
+          final_layer_chunk_n<PT, KSH, 2>(lds, sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst), pl, S, id, h, dnext);
+          spline_chunk(c);
+          // an in-order wave only overlaps its VALU with its own MFMAs if they alternate in program
+          // order: ask the scheduler for 1 MFMA : 1 LDS read : 5 VALU (a 16x16x4 f32 MFMA occupies the
+          // matrix pipe for 32 cycles ~ 8 issue slots)
+          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the spline's own LDS reads first
+#pragma unroll
+          for (int i = 0; i < 2 * PT * KSH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+        } else if (nnext == 1) {
+          final_layer_chunk_n<PT, KSH, 1>(lds, sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst), pl, S, id, h, dnext);
+          spline_chunk(c);
+          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+          for (int i = 0; i < PT * KSH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          }
+        } else {
+          spline_chunk(c);
+        }
+        wave_lds_fence();
+      }
     }
     TSF(20);
     if (!INV && !(pl.ablate & 8)) {

@@ -92,7 +92,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
       s->l_U = l; l += lus * lus;
       s->l_L = l; l += lus * lus; }
     s->l_lub = l; l += D + 1;   // bias, then sum_i log U_ii
-    s->lds_floats = round_up(l + 64, 4);   // slack: tail K-steps of the last rows read past their row
+    s->lds_floats = round_up(l + 8, 4);
     if (s->lds_floats > pl->lds_w_floats) pl->lds_w_floats = s->lds_floats;
   }
   pl->img_floats = pl->lds_w_floats;
@@ -113,31 +113,28 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->CINW = two_odd_at_least(need > need2 ? need : need2);
   // spline-parameter staging: P (made odd) floats per row => conflict-free per-row reads;
   // slot stride == 16 (mod 32) puts the second dim slot of a 32-lane half on the other banks
-  pl->PSW = pl->P | 1;
+  pl->PSW = 16 * pl->PT + 1;   // odd (conflict-free per-row reads) and wide enough for all 16*PT outputs
   pl->DS = 16 * pl->PSW;
   while ((pl->DS & 31) != 16) pl->DS += 1;
+  // scratch = flow state rows, context rows, and TWO spline-parameter buffers (the final-layer GEMM
+  // of chunk c+1 is issued under the spline of chunk c).  The conditioner-input rows alias the
+  // second buffer and the LU temporaries the first: both are dead while those are live.
+  int d_tr_max = pl->shape[0].d_tr;
+  pl->DCH = 2 < d_tr_max ? 2 : d_tr_max;   // a spline task occupies a lane PAIR: 16 rows x 2 dims per pass
+  int pst_sz = pl->DCH * pl->DS;
+  if (pst_sz < 16 * pl->CINW) pst_sz = 16 * pl->CINW;
+  if (pst_sz < 16 * pl->ZW + 16) pst_sz = 16 * pl->ZW + 16;
   int o = 0;
   pl->sc_zs = o; o += 16 * pl->ZW;
-  pl->sc_cs = o; o += 16 * pl->CW;
-  pl->sc_cin = o; o += 16 * pl->CINW;
-  pl->sc_us = pl->sc_cin;   // LU temporaries alias the conditioner-input rows (dead by then)
-  if (pl->ZW > pl->CINW) return SBI_AMD_E_UNSUPPORTED;
-  pl->sc_pst = o;
-  int fixed = o;
-  int d_tr_max = pl->shape[0].d_tr;
-  // a spline task occupies a lane PAIR, so a 64-lane wave evaluates 16 rows x 2 dims per pass
-  int dch = 2 < d_tr_max ? 2 : d_tr_max;
-  for (; dch >= 1; --dch) {
-    int tot = round_up(fixed + dch * pl->DS, 4);
-    if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * tot) <= NSF_LDS_LIMIT_BYTES) {
-      // balance the chunks: e.g. 5 dims with room for 4 -> (3, 2) instead of (4, 1)
-      int nch = (d_tr_max + dch - 1) / dch;
-      pl->DCH = (d_tr_max + nch - 1) / nch;
-      pl->sc_total = tot;
-      return 0;
-    }
-  }
-  return SBI_AMD_E_LDS;
+  pl->sc_cs = o;
+  if (C > 16) o += 16 * pl->CW;   // C <= 16: the standardized context lives in 4 registers per lane
+  pl->sc_pst = o; o += pst_sz;
+  pl->sc_pst2 = o; o += pst_sz;
+  pl->sc_us = pl->sc_pst;
+  pl->sc_cin = pl->sc_pst2;
+  pl->sc_total = round_up(o, 4);
+  if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * pl->sc_total) > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
+  return 0;
 }
 
 int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out) {

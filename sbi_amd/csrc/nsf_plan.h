@@ -53,7 +53,7 @@ struct NsfPlan {
   int lds_w_floats;             // LDS weight image size (max over parities)
   // per-wave scratch (float offsets relative to the wave's scratch base)
   int ZW, CW, CINW, PSW, DS, DCH;
-  int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_total;
+  int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_pst2, sc_total;
   int ablate;                   // debug/timing only (env SBI_AMD_ABLATE): skip phases, results invalid
 };
 

@@ -351,6 +351,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const bool valid = row < n;
       const float wn = valid ? (row_w ? row_w[row] : uni_w) : 0.f;
       const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
+      float cr[4];
       __syncthreads();                             // weights staged / previous tile's shared reads done
       TS(0);
       // ---- P0: load state, context, upstream gradient
@@ -365,6 +366,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           float v = valid ? x[xr * C + c] : 0.f;
           cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cr[u] = (id.g + 4 * u < C && C <= 16) ? cs[id.j * pl.CW + id.g + 4 * u] : 0.f;
       }
       wave_lds_fence();
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
@@ -388,7 +391,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           }
         }
       }
-      build_cin(pl, S, par, id, zs, cs, cin);
+      build_cin(pl, S, par, id, zs, cs, cr, cin);
       const float* cin_row = cin + id.j * pl.CINW + id.g;
       TS(1);
 
