@@ -217,12 +217,32 @@ __device__ __forceinline__ float softplus_bf(float x) {
 
 // ResidualNet hidden stack (nflows nn/nets/resnet.py, configuration flow.py:411-419):
 // h = W0 [z_id; c] + b0;  per block: t = W2 relu(W1 relu(h) + b1) + b2; h += t * sigmoid(Wc c + bc)
+// activation stash (training): one slot = this wave's 16x64 D-fragment array stored in register
+// order [mt*4+r][lane] (256-byte coalesced stores); slots: 0 h_0 | per block b: 1+4b t1 (pre-relu),
+// 2+4b t2, 3+4b sigmoid(gate), 4+4b h_{b+1}.  The backward kernel reloads them instead of
+// recomputing the conditioner (trading ~0.75 GB/step of HBM traffic for 480 MFMAs per 16 rows).
+#define NSF_AST_SLOTS(NB) (1 + 4 * (NB))
+__device__ __forceinline__ void ast_store(float* __restrict__ ast, int slot, const f4 (&v)[NSF_HT]) {
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ast[(slot * 16 + mt * 4 + r) * 64] = v[mt][r];
+}
+__device__ __forceinline__ void ast_load(const float* __restrict__ ast, int slot, f4 (&v)[NSF_HT]) {
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[mt][r] = ast[(slot * 16 + mt * 4 + r) * 64];
+}
+
 template <int KSH>
 __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds, const NsfPlan& pl,
                                                    const ShapeDesc& S, const LaneId& id,
-                                                   const float* __restrict__ cin_row, f4 (&h)[NSF_HT]) {
+                                                   const float* __restrict__ cin_row, f4 (&h)[NSF_HT],
+                                                   float* __restrict__ ast = nullptr) {
   acc_init_bias(lds, S.lin[0], id, h);
   gemm_blds(lds, S.lin[0], id, cin_row, h);
+  if (ast) ast_store(ast, 0, h);
   for (int b = 0; b < pl.NB; ++b) {
     f4 gate[NSF_HT], t[NSF_HT], u[NSF_HT];
     acc_init_bias(lds, S.lin[1 + 3 * b], id, gate);
@@ -230,19 +250,25 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[mt][r] = fmaxf(h[mt][r], 0.f);
+      for (int r = 0; r < 4; ++r) {
+        t[mt][r] = fmaxf(h[mt][r], 0.f);
+        gate[mt][r] = sigmoid_f(gate[mt][r]);
+      }
     acc_init_bias(lds, S.lin[2 + 3 * b], id, u);
     gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, t, u);
+    if (ast) { ast_store(ast, 1 + 4 * b, u); ast_store(ast, 3 + 4 * b, gate); }
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[mt][r] = fmaxf(u[mt][r], 0.f);
     acc_init_bias(lds, S.lin[3 + 3 * b], id, t);
     gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, u, t);
+    if (ast) ast_store(ast, 2 + 4 * b, t);
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[mt][r] += t[mt][r] * sigmoid_f(gate[mt][r]);
+      for (int r = 0; r < 4; ++r) h[mt][r] += t[mt][r] * gate[mt][r];
+    if (ast) ast_store(ast, 4 + 4 * b, h);
   }
 }
 

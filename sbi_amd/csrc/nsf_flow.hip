@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(512)
 nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
-                long long* __restrict__ dbg) {
+                float* __restrict__ astash, long long* __restrict__ dbg) {
 #define TSF(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && li == 1) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
@@ -103,7 +103,13 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     TSF(4);
 
     f4 h[NSF_HT];
-    if (!(pl.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h);
+    float* ast = nullptr;
+    if (!INV && astash) {
+      const long long nt16 = (n + 15) / 16;
+      const long long tile16 = (long long)blockIdx.x * nw + wave;
+      if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * NSF_AST_SLOTS(pl.NB)) * 1024 + id.lane;
+    }
+    if (!(pl.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
     TSF(5);
@@ -209,7 +215,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
 template <int K, int KSH, bool INV>
 static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                        const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                       float* z_stash, hipStream_t stream) {
+                       float* z_stash, float* astash, hipStream_t stream) {
   const int64_t lds_bytes = nsf_lds_bytes(pl, nw);
   auto kern = nsf_flow_kernel<K, KSH, INV>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -217,7 +223,7 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
   const int64_t rows_per_wg = 16 * nw;
   const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, packed, zstats, in,
-                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash,
+                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash, astash,
                      getenv("SBI_AMD_TIMELINE") ? (long long*)out_aux : nullptr);
   return (int)hipGetLastError();
 }
@@ -225,16 +231,16 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
 template <int K, bool INV>
 static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                            const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                           float* z_stash, hipStream_t st) {
+                           float* z_stash, float* astash, hipStream_t st) {
   if (pl.KSH == 13)
-    return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-  return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+  return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
 }
 
 template <bool INV>
 static int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* in,
                          const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                         float* z_stash, void* stream) {
+                         float* z_stash, float* astash, void* stream) {
   if (n == 0) return 0;
   if (!cfg || !packed || !zstats || !in || !x || !out_main || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
   NsfPlan pl;
@@ -243,11 +249,11 @@ static int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, con
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   switch (cfg->K) {
-    case 4: return launch_flow_ksh<4, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 5: return launch_flow_ksh<5, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 8: return launch_flow_ksh<8, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 10: return launch_flow_ksh<10, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-    case 16: return launch_flow_ksh<16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+    case 4: return launch_flow_ksh<4, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    case 5: return launch_flow_ksh<5, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    case 8: return launch_flow_ksh<8, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    case 10: return launch_flow_ksh<10, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    case 16: return launch_flow_ksh<16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
     default: return SBI_AMD_E_UNSUPPORTED;
   }
 }
@@ -255,8 +261,8 @@ static int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, con
 // used by the training path (nsf_train.hip): forward with per-layer state stash
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
-                       float* z_stash, void* stream) {
-  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, stream);
+                       float* z_stash, float* astash, void* stream) {
+  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, astash, stream);
 }
 
 extern "C" int64_t sbi_amd_nsf_packed_floats(const sbi_amd_nsf_config* cfg) {
@@ -278,11 +284,11 @@ extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* para
 extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                     const float* theta, const float* x, int64_t n, int64_t x_rows,
                                     float* logp_out, float* noise_out, void* stream) {
-  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, stream);
+  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, nullptr, stream);
 }
 
 extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                   const float* noise, const float* x, int64_t n, int64_t x_rows,
                                   float* theta_out, float* logabsdet_out, void* stream) {
-  return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, stream);
+  return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, stream);
 }

@@ -268,6 +268,42 @@ __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int pl
   }
 }
 
+// g_h += Wf[rows of the chunk's dims]^T g_p for this wave's 16 rows (B operand = the g_p this wave
+// just wrote into the shared A tile).  Select-free like gemm_T_breg: the padding K slots (p >= P)
+// carry exact-zero g_p, so whatever finite weight they meet is harmless; lanes supplying an A row
+// for an in-feature >= H substitute 0.
+template <int PT>
+__device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const LinDesc& LF, const NsfPlan& pl,
+                                          const ShapeDesc& S, const LaneId& id, const float* __restrict__ Arow,
+                                          int SA, int d0, f4 (&gh)[NSF_HT]) {
+  constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
+  bool ok[NSF_HT];
+  int col[NSF_HT];
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt) {
+    const int f = 16 * mt + id.iperm;
+    ok[mt] = f < LF.in;
+    col[mt] = ok[mt] ? f : 0;
+  }
+#pragma unroll
+  for (int sl = 0; sl < DCHB; ++sl) {
+    const int dd = d0 + sl;
+    if (dd < S.d_tr) {
+      const float* wrow = lds + LF.l_w + (dd * pl.P + id.g) * LF.ldk;
+      const float* brow = Arow + id.j * SA + sl * 16 * PT + id.g;
+#pragma unroll
+      for (int s = 0; s < 4 * PT; ++s) {
+        const float bv = brow[4 * s];
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) {
+          const float a = wrow[4 * s * LF.ldk + col[mt]];
+          gh[mt] = MFMA16(ok[mt] ? a : 0.f, bv, gh[mt]);
+        }
+      }
+    }
+  }
+}
+
 // partial-gradient write-out of one weight tile (lane (g,j), reg r: out = out0+4g+r, in = 16nt+j)
 __device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDesc& L, int out0, int nt,
                                            const LaneId& id, const f4& acc) {
@@ -295,8 +331,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
                      const float* __restrict__ x, const float* __restrict__ gz_up,
                      const float* __restrict__ row_w, const float uni_w, long long n, long long x_rows,
                      float* __restrict__ gz_dn, float* __restrict__ partial, float* __restrict__ grad_theta,
-                     long long* __restrict__ dbg) {
-#define TS(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tile == (int)blockIdx.x) \
+                     const float* __restrict__ astash, long long* __restrict__ dbg) {
+  const int dbg_tile_sel = pl.ablate & 128;   // timeline of the 2nd tile (warm caches) instead of the 1st
+#define TS(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tile == (int)(blockIdx.x + (dbg_tile_sel ? gridDim.x : 0))) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
   constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);   // dim slots per chunk (lane pairs: <= 2)
@@ -354,22 +391,50 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       float cr[4];
       __syncthreads();                             // weights staged / previous tile's shared reads done
       TS(0);
-      // ---- P0: load state, context, upstream gradient
+      // ---- P0: load state, context, upstream gradient.  All loads are issued before the first
+      // use (clamped addresses instead of predicated loads), so one HBM round trip covers them.
       {
         const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
-        for (int d = id.g; d < D; d += 4) {
-          zs[id.j * pl.ZW + d] = valid ? z_in[row * D + d] : 0.f;
-          float gz = valid ? gz_up[row * D + d] : 0.f;
-          gzs[id.j * pl.ZW + d] = is_last ? wn * gz : gz;   // last transform: d/dz_T of w*(0.5|z|^2) = w z
+        const long long rs = valid ? row : 0;
+        float zv[4], gv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = id.g + 4 * u;
+          const int dc = d < D ? d : 0;
+          zv[u] = z_in[rs * D + dc];
+          gv[u] = gz_up[rs * D + dc];
+          const int c = d < C ? d : 0;
+          xv[u] = x[(valid ? xr : 0) * C + c];
         }
-        for (int c = id.g; c < C; c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = id.g + 4 * u;
+          if (d < D) {
+            zs[id.j * pl.ZW + d] = valid ? zv[u] : 0.f;
+            const float gz = valid ? gv[u] : 0.f;
+            gzs[id.j * pl.ZW + d] = is_last ? wn * gz : gz;   // last transform: d/dz_T of w*(0.5|z|^2) = w z
+          }
+          if (d < C) {
+            const float v = ((valid ? xv[u] : 0.f) - x_mean[d]) / x_std[d];
+            cs[id.j * pl.CW + d] = v;
+          }
+          cr[u] = (d < C && C <= 16) ? ((valid ? xv[u] : 0.f) - x_mean[d < C ? d : 0]) / x_std[d < C ? d : 0] : 0.f;
+        }
+        for (int c = id.g + 16; c < C; c += 4) {   // C > 16: remaining context columns
           float v = valid ? x[xr * C + c] : 0.f;
           cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cr[u] = (id.g + 4 * u < C && C <= 16) ? cs[id.j * pl.CW + id.g + 4 * u] : 0.f;
       }
       wave_lds_fence();
+      // ---- P1: reload the block inputs h_0..h_NB the forward pass stashed (register-order slabs,
+      // 256-byte coalesced loads) instead of recomputing the hidden stack; issued right after
+      // P0's own loads (vmcnt retires in order) so the HBM latency hides under the LULinear backward
+      f4 hpre[NB + 1][NSF_HT];
+      const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + wave) *
+                                   NSF_AST_SLOTS(NB)) * 1024 + id.lane;
+      ast_load(ast, 4 * NB, hpre[NB]);
+#pragma unroll
+      for (int b = NB - 1; b >= 0; --b) ast_load(ast, 4 * b, hpre[b]);
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
       if (!(pl.ablate & 64)) {
         float v[16], o[4];
@@ -395,34 +460,6 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const float* cin_row = cin + id.j * pl.CINW + id.g;
       TS(1);
 
-      // ---- P1: recompute the conditioner's hidden stack; keep the block inputs h_0..h_NB
-      // (the per-block temporaries are recomputed again in P3 to stay inside 512 registers)
-      f4 hpre[NB + 1][NSF_HT];
-      acc_init_bias(lds, L0, id, hpre[0]);
-      gemm_blds(lds, L0, id, cin_row, hpre[0]);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        f4 rl[NSF_HT], t1[NSF_HT], sg[NSF_HT];
-        acc_init_bias(lds, S.lin[1 + 3 * b], id, sg);
-        gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, sg);
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(hpre[b][mt][r], 0.f);
-        acc_init_bias(lds, S.lin[2 + 3 * b], id, t1);
-        if (!(pl.ablate & 16)) gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(t1[mt][r], 0.f);
-        acc_init_bias(lds, S.lin[3 + 3 * b], id, t1);
-        if (!(pl.ablate & 16)) gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t1);
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hpre[b + 1][mt][r] = hpre[b][mt][r] + t1[mt][r] * sigmoid_f(sg[mt][r]);
-      }
-
       TS(2);
       // ---- P2: final layer + spline, chunk by chunk; d Wf; g_h = Wf^T g_p
       stage_D(Bst, SA, arow0 + id.j, id, hpre[NB], false);
@@ -430,103 +467,79 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       f4 gh[NSF_HT];
 #pragma unroll
       for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (c < nch) {
-          const int d0 = c * DCHB;
-          TS(3 + 4 * c);
-          if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);
-          wave_lds_fence();
-          TS(4 + 4 * c);
-          {
-            // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id
-            const int slot = id.g & 1, part = id.g >> 1;
-            const int dd = d0 + slot;
-            float* pp = Arow + id.j * SA + slot * tp.PTW;
-            if (slot < DCHB) {
-              if (dd < S.d_tr && !(pl.ablate & 4)) {
-                const int zi = id.j * pl.ZW + 2 * dd + par;
-                float yv, gxv;
-                rq_spline_pair_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);
-                if (part == 0) {
-                  ys[zi] = yv;
-                  gxs[zi] = gxv;
-                }
-              } else if (part == 0) {
-                for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;
-              }
-            }
-          }
-          TS(5 + 4 * c);
-          __syncthreads();
-          TS(6 + 4 * c);
-          // g_h += Wf[chunk rows]^T g_p   (own rows; B operand from the shared A tile)
-          if (!(pl.ablate & 2)) {
-            int co[NSF_HT];
-#pragma unroll
-            for (int mt = 0; mt < NSF_HT; ++mt) {
-              const int f = 16 * mt + id.iperm;
-              co[mt] = f < LF.in ? f : -1;
-            }
-            const int zero_off = LF.l_w + LF.out * LF.ldk;
-#pragma unroll
-            for (int sl = 0; sl < DCHB; ++sl) {
-              const int dd = d0 + sl;
-              if (dd < S.d_tr) {
-#pragma unroll
-                for (int s = 0; s < 4 * PT; ++s) {
-                  const int pq = 4 * s + id.g;
-                  const bool kin = pq < pl.P;
-                  const int ro = LF.l_w + (dd * pl.P + pq) * LF.ldk;
-                  const float bv = Arow[id.j * SA + sl * 16 * PT + pq];
-#pragma unroll
-                  for (int mt = 0; mt < NSF_HT; ++mt) {
-                    const int off = (kin && co[mt] >= 0) ? ro + co[mt] : zero_off;
-                    gh[mt] = MFMA16(lds[off], bv, gh[mt]);
-                  }
-                }
-              }
-            }
-          }
-          __syncthreads();
-        }
+      f4 bt1[NSF_HT], bt2[NSF_HT], bsg[NSF_HT];   // block temporaries, loaded one phase ahead of their use
+      // chunk loop with the LAST iteration peeled (it also starts the prefetch of the last block's
+      // temporaries; peeling keeps those 48 registers dead during the earlier chunks' splines)
+#define CHUNK_BODY(LAST)                                                                                              \
+      {                                                                                                               \
+          const int d0 = c * DCHB;                                                                                    \
+          TS(3 + 4 * c);                                                                                              \
+          if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);                \
+          wave_lds_fence();                                                                                           \
+          TS(4 + 4 * c);                                                                                              \
+          {                                                                                                           \
+            const int slot = id.g & 1, part = id.g >> 1;                                                              \
+            const int dd = d0 + slot;                                                                                 \
+            float* pp = Arow + id.j * SA + slot * tp.PTW;                                                             \
+            if (slot < DCHB) {                                                                                        \
+              if (dd < S.d_tr && !(pl.ablate & 4)) {                                                                  \
+                const int zi = id.j * pl.ZW + 2 * dd + par;                                                           \
+                float yv, gxv;                                                                                        \
+                rq_spline_pair_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);                           \
+                if (part == 0) {                                                                                      \
+                  ys[zi] = yv;                                                                                        \
+                  gxs[zi] = gxv;                                                                                      \
+                }                                                                                                     \
+              } else if (part == 0) {                                                                                 \
+                for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;                                                         \
+              }                                                                                                       \
+            }                                                                                                         \
+          }                                                                                                           \
+          TS(5 + 4 * c);                                                                                              \
+          __syncthreads();                                                                                            \
+          TS(6 + 4 * c);                                                                                              \
+          if (LAST) {                                                                                                 \
+            ast_load(ast, 1 + 4 * (NB - 1), bt1);                                                                     \
+            ast_load(ast, 2 + 4 * (NB - 1), bt2);                                                                     \
+            ast_load(ast, 3 + 4 * (NB - 1), bsg);                                                                     \
+          }                                                                                                           \
+          if (!(pl.ablate & 2)) wft_chunk<PT>(lds, LF, pl, S, id, Arow, SA, d0, gh);                                  \
+          __syncthreads();                                                                                            \
       }
+      for (int c = 0; c < nch - 1; ++c) CHUNK_BODY(false)
+      { const int c = nch - 1; CHUNK_BODY(true) }
+#undef CHUNK_BODY
 
       TS(19);
       // ---- P3: residual blocks, last -> first
 #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
-        f4 ga[NSF_HT], gc[NSF_HT], gb[NSF_HT], t1[NSF_HT];
+        f4 ga[NSF_HT], gb[NSF_HT];
         {
-          // recompute this block's temporaries from h_b: sg = sigmoid(Wc c + bc), t1, t2
-          f4 sg[NSF_HT], t2[NSF_HT], rl[NSF_HT];
-          acc_init_bias(lds, S.lin[1 + 3 * b], id, sg);
-          if (!(pl.ablate & 8)) gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, sg);
-#pragma unroll
-          for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(hpre[b][mt][r], 0.f);
-          acc_init_bias(lds, S.lin[2 + 3 * b], id, t1);
-          if (!(pl.ablate & 8)) gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, rl, t1);
-#pragma unroll
-          for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rl[mt][r] = fmaxf(t1[mt][r], 0.f);
-          acc_init_bias(lds, S.lin[3 + 3 * b], id, t2);
-          if (!(pl.ablate & 8)) gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, rl, t2);
+          f4 gc[NSF_HT];
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float sgm = sigmoid_f(sg[mt][r]);
-              ga[mt][r] = gh[mt][r] * sgm;                                // d t2
-              gc[mt][r] = gh[mt][r] * t2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
+              const float sgm = bsg[mt][r];
+              ga[mt][r] = gh[mt][r] * sgm;                                 // d t2
+              gc[mt][r] = gh[mt][r] * bt2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
             }
+          // d Wc first (A = g_c, B = standardized context): g_c dies right away
+          stage_D(Ast, SA, arow0 + id.j, id, gc, false);
+          for (int k = id.g; k < 16 * ntc; k += 4)
+            Brow[id.j * SA + k] = k < C ? cs[id.j * pl.CW + k] : (k == C ? 1.f : 0.f);
         }
+        if (b > 0) {   // next (earlier) block's t2 / gate: fetch under this block's GEMM phases
+          ast_load(ast, 2 + 4 * (b - 1), bt2);
+          ast_load(ast, 3 + 4 * (b - 1), bsg);
+        }
+        __syncthreads();
+        __syncthreads();
         TS(20 + 8 * b);
         // d W2 : A = g_t2, B = relu(t1)
         stage_D(Ast, SA, arow0 + id.j, id, ga, false);
-        stage_D(Bst, SA, arow0 + id.j, id, t1, true);
+        stage_D(Bst, SA, arow0 + id.j, id, bt1, true);
         if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
         __syncthreads();
 #pragma unroll
@@ -539,7 +552,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ga[mt][r] = t1[mt][r] > 0.f ? gb[mt][r] : 0.f;   // d t1
+          for (int r = 0; r < 4; ++r) ga[mt][r] = bt1[mt][r] > 0.f ? gb[mt][r] : 0.f;   // d t1
+        if (b > 0) ast_load(ast, 1 + 4 * (b - 1), bt1);
         // d W1 : A = g_t1, B = relu(h_b)
         stage_D(Ast, SA, arow0 + id.j, id, ga, false);
         stage_D(Bst, SA, arow0 + id.j, id, hpre[b], true);
@@ -556,12 +570,6 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) gh[mt][r] += hpre[b][mt][r] > 0.f ? gb[mt][r] : 0.f;
-        // d Wc : A = g_c, B = standardized context
-        stage_D(Ast, SA, arow0 + id.j, id, gc, false);
-        for (int k = id.g; k < 16 * ntc; k += 4)
-          Brow[id.j * SA + k] = k < C ? cs[id.j * pl.CW + k] : (k == C ? 1.f : 0.f);
-        __syncthreads();
-        __syncthreads();
       }
 
       TS(40);
@@ -655,6 +663,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
         __syncthreads();
+        dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc, pl.ablate);
+        __syncthreads();
+        __syncthreads();
         TS(21 + 8 * b);
         dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
         TS(22 + 8 * b);
@@ -663,9 +674,6 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         TS(24 + 8 * b);
         dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
         TS(25 + 8 * b);
-        __syncthreads();
-        __syncthreads();
-        dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc, pl.ablate);
         __syncthreads();
       }
       __syncthreads();
@@ -796,10 +804,10 @@ __global__ void neg_copy_kernel(const float* __restrict__ in, float* __restrict_
 // ------------------------------------------------------------------ host side
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
-                       float* z_stash, void* stream);
+                       float* z_stash, float* astash, void* stream);
 
 static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int64_t* o_stash, int64_t* o_noise,
-                         int64_t* o_logp, int64_t* o_gza, int64_t* o_gzb, int64_t* o_part) {
+                         int64_t* o_logp, int64_t* o_gza, int64_t* o_gzb, int64_t* o_part, int64_t* o_ast) {
   int64_t o = 0;
   *o_stash = o; o += (int64_t)pl.T * n * pl.D;
   *o_noise = o; o += n * pl.D;
@@ -809,6 +817,8 @@ static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int6
   o = (o + 3) / 4 * 4;
   *o_part = o; o += (int64_t)pl.T * tp.grid * tp.PLP;
   o = (o + 3) / 4 * 4;
+  *o_ast = o;   // activation stash: T x ceil(n/16) wave-tiles x slots x 1024 floats
+  o += (int64_t)pl.T * ((n + 15) / 16) * NSF_AST_SLOTS(pl.NB) * 1024;
   o += 2048;   // debug timeline (SBI_AMD_TIMELINE): last 1024 int64 of the workspace
   return o;
 }
@@ -820,21 +830,21 @@ extern "C" int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* 
   TrainPlan tp;
   rc = build_train_plan(pl, n > 0 ? n : 1, &tp);
   if (rc) return rc;
-  int64_t a, b, c, d, e, f;
-  return ws_layout(pl, tp, n > 0 ? n : 1, &a, &b, &c, &d, &e, &f);
+  int64_t a, b, c, d, e, f, g;
+  return ws_layout(pl, tp, n > 0 ? n : 1, &a, &b, &c, &d, &e, &f, &g);
 }
 
 template <int K, int KSH, int NB, int NCH>
 static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
                       const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
-                      int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta, long long* dbg,
-                      hipStream_t st) {
+                      int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
+                      const float* astash, long long* dbg, hipStream_t st) {
   auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH>;
   const int lds_bytes = 4 * tp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(tp.grid), dim3(128 * TR_NW), (size_t)lds_bytes, st, pl, tp, t, packed, zstats, z_in, x,
-                     gz_up, row_w, uni_w, (long long)n, (long long)x_rows, gz_dn, partial, grad_theta, dbg);
+                     gz_up, row_w, uni_w, (long long)n, (long long)x_rows, gz_dn, partial, grad_theta, astash, dbg);
   return (int)hipGetLastError();
 }
 
@@ -842,9 +852,9 @@ template <int K>
 static int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
                         const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
                         int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
-                        long long* dbg, hipStream_t st) {
+                        const float* astash, long long* dbg, hipStream_t st) {
 #define BWD_ARGS pl, tp, t, packed, zstats, z_in, x, gz_up, row_w, uni_w, n, x_rows, gz_dn, partial, grad_theta, \
-                 dbg, st
+                 astash, dbg, st
   const int nchmax = tp.nch[0] > tp.nch[1] ? tp.nch[0] : tp.nch[1];
 #define BWD_NCH(KS, NBV) \
   switch (nchmax) { \
@@ -872,16 +882,17 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
   rc = build_train_plan(pl, n, &tp);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part;
-  ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part);
+  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
+  const int64_t ws_total = ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
+  float* astash = workspace + o_ast;
   float* stash = workspace + o_stash;
   float* noise = workspace + o_noise;
   float* logp = workspace + o_logp;
   float* gz[2] = {workspace + o_gza, workspace + o_gzb};
   float* partial = workspace + o_part;
-  long long* dbg = (long long*)(workspace + (o_part + (int64_t)pl.T * tp.grid * tp.PLP + 3) / 4 * 4);
+  long long* dbg = (long long*)(workspace + ws_total - 2048);
 
-  rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, logp, noise, stash, stream);
+  rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, logp, noise, stash, astash, stream);
   if (rc) return rc;
   if (loss_out) {
     hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logp, loss_out,
@@ -894,7 +905,7 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
     switch (cfg->K) {
 #define CASE_K(KK) \
   case KK: rc = launch_bwd_k<KK>(pl, tp, t, packed, zstats, z_in, x, up, row_weight, uniform_weight, n, x_rows, dn, \
-                                 partial, grad_theta_out, (t == 0 && getenv("SBI_AMD_TIMELINE")) ? dbg : nullptr, st); break;
+                                 partial, grad_theta_out, astash, (t == 0 && getenv("SBI_AMD_TIMELINE")) ? dbg : nullptr, st); break;
       CASE_K(10)
 #undef CASE_K
       default: rc = SBI_AMD_E_UNSUPPORTED;
