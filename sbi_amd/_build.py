@@ -13,8 +13,9 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libsbi_amd_nsf.so"
-SOURCES = ["nsf_plan.cpp", "nsf_flow.hip", "nsf_train.hip", "adam.hip"]
-HEADERS = ["nsf_plan.h", "nsf_device.h", "../../include/sbi_amd_nsf.h"]
+SOURCES = ["nsf_plan.cpp", "nsf_flow.hip", "nsf_flow_inv.hip", "nsf_train.hip", "nsf_train_k5.hip", "nsf_train_k8.hip",
+           "adam.hip"]
+HEADERS = ["nsf_plan.h", "nsf_device.h", "nsf_flow_kernel.h", "nsf_train_kernel.h", "../../include/sbi_amd_nsf.h"]
 
 
 def hipcc_path() -> str:
@@ -33,18 +34,35 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every translation unit for gfx950 (in parallel) and link the shared library."""
     if not force and not needs_build():
         return LIB_PATH
-    srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
-    cmd = [
-        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-Wno-unused-result", *srcs, "-o", str(LIB_PATH),
-    ]
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = hipcc_path()
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+    def compile_one(src: str):
+        obj = objdir / (Path(src).stem + ".o")
+        cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{res.stdout}\n{res.stderr}")
+        return str(obj)
+
+    srcs = [s for s in SOURCES if (CSRC / s).exists()]
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
     return LIB_PATH
 
 

@@ -1,0 +1,233 @@
+#pragma once
+// nsf_flow_kernel.h -- whole-flow fused NSF kernel template for gfx950 (MI355X):
+//   nsf_flow_kernel<K, false>: theta, x -> log p(theta|x) [+ noise]   (Flow.log_prob)
+//   nsf_flow_kernel<K, true >: noise, x -> theta [+ logabsdet]        (Flow._sample's inverse)
+// One launch covers z-scoring, all T x (RQ-spline coupling + LULinear) and the
+// base density; per coupling layer a workgroup stages the layer's weights into
+// LDS once and every wave pushes its 16 rows through the conditioner on MFMA.
+// Reference path replaced: nflows_flow.py:77-128 -> nflows Flow/CompositeTransform
+// (SURVEY.md 3.2, Appendix A).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "nsf_device.h"
+
+template <int K, int KSH, bool INV>
+__global__ void __launch_bounds__(512)
+nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
+                const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
+                float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
+                float* __restrict__ astash, long long* __restrict__ dbg) {
+#define TSF(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && li == 1) \
+    dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+  constexpr int PT = (3 * K - 1 + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int wave = tid >> 6;
+  const int nw = nthreads >> 6;
+  const LaneId id = make_lane();
+  float* sc = lds + pl.lds_w_floats + wave * pl.sc_total;
+  float* zs = sc + pl.sc_zs;
+  float* us = sc + pl.sc_us;
+  float* cs = sc + pl.sc_cs;
+  float* cin = sc + pl.sc_cin;
+  float* pst = sc + pl.sc_pst;
+  float* pst2 = sc + pl.sc_pst2;
+
+  const long long row = (long long)blockIdx.x * (16 * nw) + 16 * wave + id.j;
+  const bool valid = row < n;
+  const int D = pl.D, C = pl.C;
+  const float* th_shift = zstats;
+  const float* th_scale = zstats + D;
+  const float* x_mean = zstats + 2 * D;
+  const float* x_std = x_mean + C;
+
+  float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
+  float cr[4] = {0.f, 0.f, 0.f, 0.f};   // standardized context of this lane (C <= 16)
+  for (int i = id.lane; i < pl.sc_total; i += 64) sc[i] = 0.f;   // no uninitialised LDS behind short rows
+  // ---- load + z-score (PointwiseAffineTransform fwd / Standardize) ----
+  {
+    const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
+    for (int d = id.g; d < D; d += 4) {
+      float v = valid ? in[row * D + d] : 0.f;
+      if (!INV) {
+        v = v * th_scale[d] + th_shift[d];
+        ld_acc += logf(fabsf(th_scale[d]));
+      }
+      zs[id.j * pl.ZW + d] = v;
+    }
+    if (C <= 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = id.g + 4 * u;
+        cr[u] = (c < C) ? ((valid ? x[xr * C + c] : 0.f) - x_mean[c]) / x_std[c] : 0.f;
+      }
+    } else {
+      for (int c = id.g; c < C; c += 4) {
+        float v = valid ? x[xr * C + c] : 0.f;
+        cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
+      }
+    }
+  }
+  wave_lds_fence();
+
+  for (int li = 0; li < pl.T; ++li) {
+    const int t = INV ? (pl.T - 1 - li) : li;
+    const int par = t & 1;
+    const ShapeDesc& S = pl.shape[par];
+    TSF(0);
+    __syncthreads();   // every wave is done with the previous layer's weights
+    TSF(1);
+    if (!(pl.ablate & 16) || li == 0)
+      stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
+    TSF(2);
+    __syncthreads();
+    TSF(3);
+
+    if (!INV && z_stash) {
+      for (int d = id.g; d < D; d += 4)
+        if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
+    }
+    if (INV && !(pl.ablate & 8)) {
+      lu_inverse(lds, pl, S, id, zs, us);
+      if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
+    }
+    build_cin(pl, S, par, id, zs, cs, cr, cin);
+    TSF(4);
+
+    f4 h[NSF_HT];
+    float* ast = nullptr;
+    if (!INV && astash) {
+      const long long nt16 = (n + 15) / 16;
+      const long long tile16 = (long long)blockIdx.x * nw + wave;
+      if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * NSF_AST_SLOTS(pl.NB)) * 1024 + id.lane;
+    }
+    if (!(pl.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast);
+    else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
+
+    TSF(5);
+    // ---- final layer + spline, software-pipelined over chunks of DCH dims: the MFMA stream of
+    // chunk c+1 (into the other staging buffer) is issued in the same basic block as the VALU-only
+    // spline of chunk c, so the matrix pipe works under the spline's latency chains.
+    {
+      const int nchunks = (S.d_tr + pl.DCH - 1) / pl.DCH;
+      const int dch_ = pl.DCH, dtr_ = S.d_tr;
+      const bool spl_on = !(pl.ablate & 1);
+      // integer offsets (not a pointer array): keeps the accesses in the LDS address space
+      auto spline_chunk = [&](int c) {
+        // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id.
+        // Executed by every lane (idle slots recompute a valid task and drop the result) to keep
+        // the block branch-free.
+        const int slot = id.g & 1, part = id.g >> 1;
+        const int dd_raw = c * pl.DCH + slot;
+        const bool live = (slot < dch_) & (dd_raw < dtr_) & spl_on;   // bitwise: no short-circuit branches
+        const int sl = live ? slot : 0;
+        const int dd = live ? dd_raw : c * pl.DCH;
+        const int zi = id.j * pl.ZW + 2 * dd + par;
+        float y, ld;
+        rq_spline_pair<K, INV>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part,
+                               y, ld);
+        // every lane stores: partner / idle lanes hold the same y for the same zi (idempotent)
+        zs[zi] = y;
+        ld_acc += (live && part == 0) ? ld : 0.f;
+      };
+      {
+        const int n0 = S.d_tr < pl.DCH ? S.d_tr : pl.DCH;
+        if (n0 == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 0);
+        else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, 0);
+      }
+      wave_lds_fence();
+      for (int c = 0; c < nchunks; ++c) {
+        TSF(6 + 2 * c);
+        const int dnext = (c + 1) * pl.DCH;
+        int nnext = S.d_tr - dnext;
+        nnext = nnext < 0 ? 0 : (nnext < pl.DCH ? nnext : pl.DCH);
+        if (nnext == 2) {
+          final_layer_chunk_n<PT, KSH, 2>(lds, sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst), pl, S, id, h, dnext);
+          spline_chunk(c);
+          // an in-order wave only overlaps its VALU with its own MFMAs if they alternate in program
+          // order: ask the scheduler for 1 MFMA : 1 LDS read : 5 VALU (a 16x16x4 f32 MFMA occupies the
+          // matrix pipe for 32 cycles ~ 8 issue slots)
+          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the spline's own LDS reads first
+#pragma unroll
+          for (int i = 0; i < 2 * PT * KSH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+        } else if (nnext == 1) {
+          final_layer_chunk_n<PT, KSH, 1>(lds, sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst), pl, S, id, h, dnext);
+          spline_chunk(c);
+          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+          for (int i = 0; i < PT * KSH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          }
+        } else {
+          spline_chunk(c);
+        }
+        wave_lds_fence();
+      }
+    }
+    TSF(20);
+    if (!INV && !(pl.ablate & 8)) {
+      lu_forward(lds, pl, S, id, zs, us);
+      if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
+    }
+    TSF(21);
+  }
+
+  // ---- epilogue ----
+  if (!INV) {
+    float part = 0.f;
+    for (int d = id.g; d < D; d += 4) {
+      float z = zs[id.j * pl.ZW + d];
+      part += z * z;
+      if (out_aux && valid && !dbg) out_aux[row * D + d] = z;
+    }
+    float v = -0.5f * part + ld_acc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (id.g == 0 && valid) out_main[row] = v - pl.log_z;
+  } else {
+    for (int d = id.g; d < D; d += 4) {
+      float z = zs[id.j * pl.ZW + d];
+      ld_acc -= logf(fabsf(th_scale[d]));
+      if (valid) out_main[row * D + d] = (z - th_shift[d]) / th_scale[d];
+    }
+    float v = ld_acc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (out_aux && id.g == 0 && valid) out_aux[row] = v;
+  }
+}
+
+
+// ---- launch helpers (shared by the forward and inverse translation units)
+template <int K, int KSH, bool INV>
+static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
+                       const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                       float* z_stash, float* astash, hipStream_t stream) {
+  const int64_t lds_bytes = nsf_lds_bytes(pl, nw);
+  auto kern = nsf_flow_kernel<K, KSH, INV>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  const int64_t rows_per_wg = 16 * nw;
+  const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, packed, zstats, in,
+                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash, astash,
+                     getenv("SBI_AMD_TIMELINE") ? (long long*)out_aux : nullptr);
+  return (int)hipGetLastError();
+}
+
+template <int K, bool INV>
+static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
+                           const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                           float* z_stash, float* astash, hipStream_t st) {
+  if (pl.KSH == 13)
+    return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+  return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+}
+

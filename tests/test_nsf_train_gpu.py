@@ -24,6 +24,8 @@ CONFIGS = [
     dict(D=4, C=7),
     dict(D=3, C=5, hidden_features=32, num_transforms=3, num_blocks=1),
     dict(D=5, C=3, hidden_features=50, num_transforms=2),
+    dict(D=4, C=4, num_bins=8, num_transforms=2),
+    dict(D=6, C=2, num_bins=5, hidden_features=40, num_transforms=3),
 ]
 
 
