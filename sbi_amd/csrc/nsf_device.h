@@ -310,6 +310,67 @@ __device__ __forceinline__ void final_layer_chunk_n(const float* __restrict__ ld
         pst[sl * pl.DS + id.j * pl.PSW + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
 }
 
+// The same final-layer GEMM as a resumable stream: operator() issues ONE MFMA (K-step major, then
+// dim slot, then row tile) and pins it in program order; finish() drains the rest and stores.
+template <int PT, int KSH, int NACT>
+struct FinalLayerStream {
+  f4 acc[NACT][PT];
+  int ro[NACT][PT];
+  const float* lds;
+  const f4* h;
+  float abuf[4];
+  __device__ __forceinline__ void init(const float* __restrict__ lds_, const NsfPlan& pl, const ShapeDesc& S,
+                                       const LaneId& id, const f4 (&h_)[NSF_HT], int d0) {
+    const LinDesc& L = S.lin[1 + 3 * pl.NB];
+    lds = lds_;
+    h = h_;
+#pragma unroll
+    for (int sl = 0; sl < NACT; ++sl) {
+      const int dd = d0 + sl;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = 16 * pt + id.iperm;
+        ro[sl][pt] = L.l_w + ((p < pl.P) ? dd * pl.P + p : L.out) * L.ldk + id.g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[sl][pt][r] = lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g];
+      }
+    }
+    abuf[0] = a_load(0);
+    abuf[1] = a_load(1);
+  }
+  __device__ __forceinline__ float a_load(int n) const {
+    const int s = n / (NACT * PT), rem = n % (NACT * PT);
+    return lds[ro[rem / PT][rem % PT] + 4 * s];
+  }
+  // n is a compile-time constant at every call site.  The A operand of step n was requested two
+  // yield points earlier (the scheduling barriers would otherwise pin each LDS read right in front
+  // of its MFMA and expose the full LDS latency 52 times).
+  __device__ __forceinline__ void step(int n) {
+    const int s = n / (NACT * PT), rem = n % (NACT * PT);
+    const int sl = rem / PT, pt = rem % PT;
+    const float a = abuf[n & 3];
+    if (n + 2 < NACT * PT * KSH) abuf[(n + 2) & 3] = a_load(n + 2);
+    acc[sl][pt] = MFMA16(a, h[s >> 2][s & 3], acc[sl][pt]);
+  }
+  __device__ __forceinline__ void operator()(int n) {
+    if (n < NACT * PT * KSH) step(n);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // nyield = number of yield points the host routine went through (steps 0 .. nyield-1 are done)
+  template <int NYIELD>
+  __device__ __forceinline__ void finish(float* __restrict__ pst, const NsfPlan& pl, const LaneId& id) {
+#pragma unroll
+    for (int n = NYIELD; n < NACT * PT * KSH; ++n) step(n);
+#pragma unroll
+    for (int sl = 0; sl < NACT; ++sl)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pst[sl * pl.DS + id.j * pl.PSW + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+  }
+};
+
 template <int PT, int KSH>
 __device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds, float* __restrict__ pst,
                                                   const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
@@ -347,21 +408,33 @@ struct SplineSide {
   float c[K + 1];   // knots of this side in [-B, B]
 };
 
-template <int K>
+// "Yield points": a VALU-heavy routine calls y() between small groups of instructions; the functor
+// issues one MFMA of an independent matrix stream followed by a scheduling barrier, so an in-order
+// wave alternates matrix and vector instructions in program order (hipcc otherwise emits all MFMAs
+// first and the VALU never overlaps them).  NoYield compiles to nothing.
+// Yield points are numbered 0 .. 5K (compile-time constants after unrolling): the functor maps the
+// number straight to one MFMA of its stream, so every register index stays static.
+struct NoYield {
+  __device__ __forceinline__ void operator()(int) {}
+};
+
+template <int K, class Y = NoYield>
 __device__ __forceinline__ void spline_side(const float* __restrict__ q, const NsfPlan& pl, int part,
-                                            SplineSide<K>& S) {
+                                            SplineSide<K>& S, Y&& y = Y()) {
   const float B = pl.B;
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     S.e[k] = q[k] * pl.inv_sqrt_h;   // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
     m = fmaxf(m, S.e[k]);
+    y(k);
   }
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     S.e[k] = exp_f(S.e[k] - m);
     s += S.e[k];
+    y(K + k);
   }
   S.inv_s = rcp_f(s);
   const float n_ = (part ? pl.one_minus_kh : pl.one_minus_kw) * S.inv_s;
@@ -373,6 +446,7 @@ __device__ __forceinline__ void spline_side(const float* __restrict__ q, const N
   for (int k = 0; k < K; ++k) {
     cum += fmaf(S.e[k], n_, mn);
     S.c[k + 1] = (2.f * B) * cum + (-B);
+    y(2 * K + k);
   }
   S.c[K] = B;
 }
@@ -383,16 +457,19 @@ struct SplineSel {   // per-task scalars both lanes hold after the exchange
   float cw_i, cw_n, ch_i, ch_n, d_i, d_n, ud_mine;
 };
 
-template <int K, bool INV>
+template <int K, bool INV, class Y = NoYield>
 __device__ __forceinline__ void spline_select(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
-                                              const SplineSide<K>& S, SplineSel& o) {
+                                              const SplineSide<K>& S, SplineSel& o, Y&& y = Y()) {
   const float B = pl.B;
   o.inside = (x >= -B) && (x <= B);
   // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6; done by the
   // side that owns the searched knots (widths forward, heights inverse)
   int cnt = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) cnt += (x >= S.c[k]) ? 1 : 0;
+  for (int k = 0; k < K; ++k) {
+    cnt += (x >= S.c[k]) ? 1 : 0;
+    y(3 * K + k);
+  }
   cnt += (x >= (S.c[K] + 1e-6f)) ? 1 : 0;
   int idx = cnt - 1;
   idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
@@ -404,6 +481,7 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
     const bool hit = (idx == k);
     c_i = hit ? S.c[k] : c_i;
     c_n = hit ? S.c[k + 1] : c_n;
+    y(4 * K + k - 1);
   }
   const float o_i = xchg32(c_i), o_n = xchg32(c_n);
   o.idx = idx;
@@ -416,7 +494,9 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
   const int kc = kd - 1 < 0 ? 0 : (kd - 1 > K - 2 ? K - 2 : kd - 1);   // always a valid slot: no branch
   const float ud_ld = p[2 * K + kc];
   o.ud_mine = (kd == 0 || kd == K) ? pl.d_const : ud_ld;
+  y(5 * K - 1);
   const float d_mine = pl.min_d + softplus_bf(o.ud_mine);
+  y(5 * K);
   const float d_oth = xchg32(d_mine);
   o.d_i = part ? d_oth : d_mine;
   o.d_n = part ? d_mine : d_oth;
@@ -424,13 +504,13 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
 
 // forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
 // receive y and ld.
-template <int K, bool INV>
+template <int K, bool INV, class Y = NoYield>
 __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
-                                               float& y, float& ld) {
+                                               float& y, float& ld, Y&& yield = Y()) {
   SplineSide<K> S;
-  spline_side<K>(p + part * K, pl, part, S);
+  spline_side<K>(p + part * K, pl, part, S, yield);
   SplineSel o;
-  spline_select<K, INV>(p, x, pl, part, S, o);
+  spline_select<K, INV>(p, x, pl, part, S, o, yield);
   const float w_i = o.cw_n - o.cw_i;
   const float h_i = o.ch_n - o.ch_i;
   const float rw_i = rcp_f(w_i);

@@ -114,7 +114,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       const int dch_ = pl.DCH, dtr_ = S.d_tr;
       const bool spl_on = !(pl.ablate & 1);
       // integer offsets (not a pointer array): keeps the accesses in the LDS address space
-      auto spline_chunk = [&](int c) {
+      auto spline_chunk = [&](int c, auto&& yield) {
         // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id.
         // Executed by every lane (idle slots recompute a valid task and drop the result) to keep
         // the block branch-free.
@@ -126,7 +126,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
         const int zi = id.j * pl.ZW + 2 * dd + par;
         float y, ld;
         rq_spline_pair<K, INV>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part,
-                               y, ld);
+                               y, ld, yield);
         // every lane stores: partner / idle lanes hold the same y for the same zi (idempotent)
         zs[zi] = y;
         ld_acc += (live && part == 0) ? ld : 0.f;
@@ -142,31 +142,20 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
         const int dnext = (c + 1) * pl.DCH;
         int nnext = S.d_tr - dnext;
         nnext = nnext < 0 ? 0 : (nnext < pl.DCH ? nnext : pl.DCH);
+        float* pnext = sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst);
         if (nnext == 2) {
-          final_layer_chunk_n<PT, KSH, 2>(lds, sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst), pl, S, id, h, dnext);
-          spline_chunk(c);
-          // an in-order wave only overlaps its VALU with its own MFMAs if they alternate in program
-          // order: ask the scheduler for 1 MFMA : 1 LDS read : 5 VALU (a 16x16x4 f32 MFMA occupies the
-          // matrix pipe for 32 cycles ~ 8 issue slots)
-          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the spline's own LDS reads first
-#pragma unroll
-          for (int i = 0; i < 2 * PT * KSH; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-          }
+          // the next chunk's final-layer GEMM advances one MFMA per yield point of this chunk's spline
+          FinalLayerStream<PT, KSH, 2> fs;
+          fs.init(lds, pl, S, id, h, dnext);
+          spline_chunk(c, fs);
+          fs.template finish<5 * K + 1>(pnext, pl, id);
         } else if (nnext == 1) {
-          final_layer_chunk_n<PT, KSH, 1>(lds, sc + (((c + 1) & 1) ? pl.sc_pst2 : pl.sc_pst), pl, S, id, h, dnext);
-          spline_chunk(c);
-          __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-#pragma unroll
-          for (int i = 0; i < PT * KSH; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-          }
+          FinalLayerStream<PT, KSH, 1> fs;
+          fs.init(lds, pl, S, id, h, dnext);
+          spline_chunk(c, fs);
+          fs.template finish<5 * K + 1>(pnext, pl, id);
         } else {
-          spline_chunk(c);
+          spline_chunk(c, NoYield());
         }
         wave_lds_fence();
       }
