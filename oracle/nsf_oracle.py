@@ -224,6 +224,23 @@ class ResidualNet(nn.Module):
         return self.final_layer(temps)
 
 
+class ContextSplineMap(nn.Module):
+    """sbi's conditioner for 1-D theta (flow.py:1419-1478): the spline parameters depend on the context
+    only; `hidden_features` exists so the coupling transform applies its 1/sqrt(H) scaling.  Note the
+    reference builds `[Linear, ReLU] * hidden_layers`, i.e. ONE hidden Linear reused hidden_layers times."""
+
+    def __init__(self, in_features, out_features, hidden_features, context_features, hidden_layers=1):
+        super().__init__()
+        self.hidden_features = hidden_features
+        layer_list = [nn.Linear(context_features, hidden_features), nn.ReLU()]
+        layer_list += [nn.Linear(hidden_features, hidden_features), nn.ReLU()] * hidden_layers
+        layer_list += [nn.Linear(hidden_features, out_features)]
+        self.spline_predictor = nn.Sequential(*layer_list)
+
+    def forward(self, inputs, context=None):
+        return self.spline_predictor(context)
+
+
 # --------------------------------------------------------------- transforms (A.2-A.8)
 class PointwiseAffineTransform(nn.Module):
     def __init__(self, shift, scale):
@@ -246,7 +263,8 @@ class PointwiseAffineTransform(nn.Module):
 
 
 class PiecewiseRationalQuadraticCouplingTransform(nn.Module):
-    def __init__(self, mask, in_context, hidden_features, num_blocks, num_bins=10, tail_bound=3.0):
+    def __init__(self, mask, in_context, hidden_features, num_blocks, num_bins=10, tail_bound=3.0,
+                 context_spline_map=False, hidden_layers_spline_context=1):
         super().__init__()
         mask = torch.as_tensor(mask)
         features_vector = torch.arange(len(mask))
@@ -254,11 +272,16 @@ class PiecewiseRationalQuadraticCouplingTransform(nn.Module):
         self.register_buffer("transform_features", features_vector.masked_select(mask > 0))
         self.num_bins = num_bins
         self.tail_bound = tail_bound
-        self.transform_net = ResidualNet(
-            in_features=len(self.identity_features),
-            out_features=len(self.transform_features) * (3 * num_bins - 1),
-            hidden_features=hidden_features, context_features=in_context, num_blocks=num_blocks,
-        )
+        if context_spline_map:
+            self.transform_net = ContextSplineMap(
+                len(self.identity_features), len(self.transform_features) * (3 * num_bins - 1), hidden_features,
+                in_context, hidden_layers_spline_context)
+        else:
+            self.transform_net = ResidualNet(
+                in_features=len(self.identity_features),
+                out_features=len(self.transform_features) * (3 * num_bins - 1),
+                hidden_features=hidden_features, context_features=in_context, num_blocks=num_blocks,
+            )
 
     def _piecewise_cdf(self, inputs, transform_params, inverse):
         K = self.num_bins
@@ -448,12 +471,16 @@ class NSFOracle(nn.Module):
         super().__init__()
         D = batch_theta[0].numel()
         C = batch_x[0].numel()
-        if D < 2:
-            raise NotImplementedError("oracle covers the ResidualNet-conditioned case D>1")
         self.input_shape = batch_theta[0].shape
         self.condition_shape = batch_x[0].shape
         transforms: List[nn.Module] = []
         for i in range(num_transforms):
+            if D == 1:   # flow.py:401-408, 426, 436: dummy mask [1], context-only conditioner, no LULinear
+                transforms.append(
+                    PiecewiseRationalQuadraticCouplingTransform(
+                        torch.tensor([1], dtype=torch.uint8), C, hidden_features, num_blocks, num_bins=num_bins,
+                        tail_bound=tail_bound, context_spline_map=True))
+                continue
             mask = create_alternating_binary_mask(D, even=(i % 2 == 0))
             transforms.append(
                 PiecewiseRationalQuadraticCouplingTransform(

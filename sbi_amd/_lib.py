@@ -19,7 +19,7 @@ _LIB: Optional[ctypes.CDLL] = None
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
     E_UNSUPPORTED: "configuration not supported by the HIP kernels "
-    "(need 2<=D<=64, H<=64, num_bins in {4,5,8,10,16}, num_transforms<=16, num_blocks<=4)",
+    "(need 1<=D<=64, H<=64, num_bins in {4,5,8,10,16}, num_transforms<=16, num_blocks<=4)",
     E_BADARG: "bad argument",
     E_LDS: "configuration needs more than 160 KiB of LDS per workgroup",
 }

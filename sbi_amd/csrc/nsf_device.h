@@ -105,8 +105,10 @@ __device__ __forceinline__ void pack_layer(float* __restrict__ img, const float*
     pack_linear(img, gl, S.lin[2 + 3 * b], hb, hb, hb, tid, nthreads);
     pack_linear(img, gl, S.lin[3 + 3 * b], hb, hb, hb, tid, nthreads);
   }
-  pack_linear(img, gl, S.lin[1 + 3 * pl.NB], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
-  pack_lu(img, gl, S, pl.D, pl.lu_eps, tid, nthreads);
+  if (pl.ctx_mlp) pack_linear(img, gl, S.lin[1], hb, hb, hb, tid, nthreads);
+  pack_linear(img, gl, S.lin[S.fin], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
+  if (!pl.ctx_mlp) pack_lu(img, gl, S, pl.D, pl.lu_eps, tid, nthreads);
+  else for (int idx = S.l_U + tid; idx < S.l_lub + pl.D + 1; idx += nthreads) img[idx] = 0.f;
   for (int idx = S.l_lub + pl.D + 1 + tid; idx < pl.img_floats; idx += nthreads) img[idx] = 0.f;
 }
 
@@ -221,7 +223,7 @@ __device__ __forceinline__ float softplus_bf(float x) {
 // order [mt*4+r][lane] (256-byte coalesced stores); slots: 0 h_0 | per block b: 1+4b t1 (pre-relu),
 // 2+4b t2, 3+4b sigmoid(gate), 4+4b h_{b+1}.  The backward kernel reloads them instead of
 // recomputing the conditioner (trading ~0.75 GB/step of HBM traffic for 480 MFMAs per 16 rows).
-#define NSF_AST_SLOTS(NB) (1 + 4 * (NB))
+#define NSF_AST_SLOTS(NB) ((NB) > 0 ? 1 + 4 * (NB) : 2)   // ctx_mlp (NB == 0): h1, h2
 __device__ __forceinline__ void ast_store(float* __restrict__ ast, int slot, const f4 (&v)[NSF_HT]) {
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt)
@@ -242,6 +244,23 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
                                                    float* __restrict__ ast = nullptr) {
   acc_init_bias(lds, S.lin[0], id, h);
   gemm_blds(lds, S.lin[0], id, cin_row, h);
+  if (pl.ctx_mlp) {
+    // ContextSplineMap (flow.py:1419-1478): h = relu(W_h relu(W_in c + b_in) + b_h)
+    f4 u[NSF_HT];
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.f);
+    if (ast) ast_store(ast, 0, h);
+    acc_init_bias(lds, S.lin[1], id, u);
+    gemm_breg<KSH>(lds, S.lin[1], id, h, u);
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(u[mt][r], 0.f);
+    if (ast) ast_store(ast, 1, h);
+    return;
+  }
   if (ast) ast_store(ast, 0, h);
   for (int b = 0; b < pl.NB; ++b) {
     f4 gate[NSF_HT], t[NSF_HT], u[NSF_HT];
@@ -279,7 +298,7 @@ template <int PT, int KSH, int NACT>
 __device__ __forceinline__ void final_layer_chunk_n(const float* __restrict__ lds, float* __restrict__ pst,
                                                     const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
                                                     const f4 (&h)[NSF_HT], int d0) {
-  const LinDesc& L = S.lin[1 + 3 * pl.NB];
+  const LinDesc& L = S.lin[S.fin];
   f4 acc[NACT][PT];
   int ro[NACT][PT];
 #pragma unroll
@@ -321,7 +340,7 @@ struct FinalLayerStream {
   float abuf[4];
   __device__ __forceinline__ void init(const float* __restrict__ lds_, const NsfPlan& pl, const ShapeDesc& S,
                                        const LaneId& id, const f4 (&h_)[NSF_HT], int d0) {
-    const LinDesc& L = S.lin[1 + 3 * pl.NB];
+    const LinDesc& L = S.lin[S.fin];
     lds = lds_;
     h = h_;
 #pragma unroll

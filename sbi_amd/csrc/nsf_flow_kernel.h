@@ -73,7 +73,8 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
 
   for (int li = 0; li < pl.T; ++li) {
     const int t = INV ? (pl.T - 1 - li) : li;
-    const int par = t & 1;
+    const int par = pl.ctx_mlp ? 0 : (t & 1);   // D == 1: the same dummy mask [1] in every transform
+    const bool has_lu = !pl.ctx_mlp;
     const ShapeDesc& S = pl.shape[par];
     TSF(0);
     __syncthreads();   // every wave is done with the previous layer's weights
@@ -88,7 +89,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       for (int d = id.g; d < D; d += 4)
         if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
     }
-    if (INV && !(pl.ablate & 8)) {
+    if (INV && has_lu && !(pl.ablate & 8)) {
       lu_inverse(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
@@ -161,7 +162,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       }
     }
     TSF(20);
-    if (!INV && !(pl.ablate & 8)) {
+    if (!INV && has_lu && !(pl.ablate & 8)) {
       lu_forward(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
     }

@@ -16,7 +16,7 @@ static int supported_bins(int K) { return K == 4 || K == 5 || K == 8 || K == 10 
 
 static int check_cfg(const sbi_amd_nsf_config* c) {
   if (!c) return SBI_AMD_E_BADARG;
-  if (c->D < 2 || c->C < 1 || c->H < 1 || c->T < 1 || c->NB < 0) return SBI_AMD_E_BADARG;
+  if (c->D < 1 || c->C < 1 || c->H < 1 || c->T < 1 || c->NB < 0) return SBI_AMD_E_BADARG;
   if (c->H > 16 * NSF_HT || c->T > NSF_MAX_T || c->NB > NSF_MAX_NB || !supported_bins(c->K))
     return SBI_AMD_E_UNSUPPORTED;
   if (c->D > 64 || c->C > 256) return SBI_AMD_E_UNSUPPORTED;
@@ -52,7 +52,10 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   memset(pl, 0, sizeof(*pl));
-  const int D = cfg->D, C = cfg->C, H = cfg->H, K = cfg->K, T = cfg->T, NB = cfg->NB;
+  const int D = cfg->D, C = cfg->C, H = cfg->H, K = cfg->K, T = cfg->T;
+  const int ctx_mlp = (D == 1);
+  const int NB = ctx_mlp ? 0 : cfg->NB;   // the context-only conditioner has no residual blocks
+  pl->ctx_mlp = ctx_mlp;
   pl->D = D; pl->C = C; pl->H = H; pl->K = K; pl->T = T; pl->NB = NB;
   pl->P = 3 * K - 1;
   pl->PT = (pl->P + 15) / 16;
@@ -72,21 +75,27 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     ShapeDesc* s = &pl->shape[par];
     // create_alternating_binary_mask (torchutils.py:396-410): even transforms
     // transform the even feature indices, odd ones the odd indices.
-    s->d_tr = (par == 0) ? (D + 1) / 2 : D / 2;
+    s->d_tr = ctx_mlp ? 1 : ((par == 0) ? (D + 1) / 2 : D / 2);   // D == 1: dummy mask [1] every transform
     s->d_id = D - s->d_tr;
     s->in0 = s->d_id + C;
     int g = 0, l = 0;
     const int hb = 16 * NSF_HT;
     const int tr_rows = 4 * pl->KSH + 1;   // transposed (backward) K loops walk 4*KSH rows
     set_lin(&s->lin[0], &g, &l, H, s->in0, hb, 0, tr_rows);
-    for (int b = 0; b < NB; ++b) {
-      set_lin(&s->lin[1 + 3 * b], &g, &l, H, C, hb, 0);
-      set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb, pl->KSH, tr_rows);
-      set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb, pl->KSH, tr_rows);
+    if (ctx_mlp) {
+      set_lin(&s->lin[1], &g, &l, H, H, hb, pl->KSH, tr_rows);
+      s->fin = 2;
+    } else {
+      for (int b = 0; b < NB; ++b) {
+        set_lin(&s->lin[1 + 3 * b], &g, &l, H, C, hb, 0);
+        set_lin(&s->lin[2 + 3 * b], &g, &l, H, H, hb, pl->KSH, tr_rows);
+        set_lin(&s->lin[3 + 3 * b], &g, &l, H, H, hb, pl->KSH, tr_rows);
+      }
+      s->fin = 1 + 3 * NB;
     }
-    set_lin(&s->lin[1 + 3 * NB], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT, pl->KSH);
+    set_lin(&s->lin[s->fin], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT, pl->KSH);
     s->g_lu = g;
-    g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias
+    if (!ctx_mlp) g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias
     s->n_params = g;
     { const int lus = D <= 16 ? 16 : D;   // dense U, L padded to 16 x 16 for D <= 16
       s->l_U = l; l += lus * lus;

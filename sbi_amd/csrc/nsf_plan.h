@@ -33,6 +33,8 @@ struct LinDesc {
 struct ShapeDesc {   // one per mask parity (even / odd transform index)
   int d_id, d_tr, in0;
   LinDesc lin[NSF_MAX_LIN];   // 0 initial | 1+3b ctx_b | 2+3b lin0_b | 3+3b lin1_b | 1+3NB final
+                              // ctx_mlp (D == 1): 0 input C->H | 1 hidden H->H | 2 final
+  int fin;                    // index of the final layer in lin[]
   int g_lu;                   // LULinear block offset relative to the layer block
   int l_U, l_L, l_lub;        // LDS offsets of expanded U[D][D], L[D][D], bias[D]
   int n_params;               // floats in this layer block
@@ -41,6 +43,8 @@ struct ShapeDesc {   // one per mask parity (even / odd transform index)
 
 struct NsfPlan {
   int D, C, H, K, T, NB, P, PT;   // P = 3K-1, PT = ceil(P/16)
+  int ctx_mlp;                    // D == 1: sbi's ContextSplineMap conditioner (flow.py:1419-1478): params from
+                                  // the context only (C->H relu, H->H relu, H->P), mask [1], no LULinear
   int KSH;                        // hidden-layer K-steps the kernel template is instantiated for (13 or 16)
   float B, min_w, min_h, min_d, lu_eps, sqrt_h, inv_sqrt_h;
   float one_minus_kw, one_minus_kh;   // 1 - min_w*K, 1 - min_h*K

@@ -24,7 +24,7 @@ nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __rest
   const float* base = partial + (long long)t * tp.grid * tp.PLP;
   const int ntri = pl.D * (pl.D - 1) / 2;
   const int d0 = S.g_lu + 2 * ntri;
-  const bool is_diag = live && li >= d0 && li < d0 + pl.D;
+  const bool is_diag = live && !pl.ctx_mlp && li >= d0 && li < d0 + pl.D;
   float a = 0.f, sgl = 0.f;
   if (live) {
     float acc4[4] = {0.f, 0.f, 0.f, 0.f};

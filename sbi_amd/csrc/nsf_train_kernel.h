@@ -35,7 +35,7 @@ struct TrainPlan {
 };
 
 static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
-  if (pl.D > 15 || pl.H > 63 || pl.NB < 1 || pl.NB > 2) return SBI_AMD_E_UNSUPPORTED;
+  if (pl.D > 15 || pl.H > 63 || pl.NB > 2 || (pl.NB < 1 && !pl.ctx_mlp)) return SBI_AMD_E_UNSUPPORTED;
   const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
   if (d_id_max + pl.C + 1 > 32 || pl.C + 1 > 32) return SBI_AMD_E_UNSUPPORTED;
   tp->DCHB = 4 / pl.PT;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
                                                     const NsfPlan& pl, const TrainPlan& tp, const ShapeDesc& S,
                                                     const LaneId& id, const f4 (&h)[NSF_HT], int d0) {
   constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
-  const LinDesc& L = S.lin[1 + 3 * pl.NB];
+  const LinDesc& L = S.lin[S.fin];
   f4 acc[DCHB][PT];
   int ro[DCHB][PT];
 #pragma unroll
@@ -342,7 +342,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const LaneId id = make_lane();
-  const int par = t & 1;
+  const bool cm = pl.ctx_mlp != 0;            // theta-dim 1: context-only MLP conditioner, no LULinear
+  const int par = cm ? 0 : (t & 1);
   const ShapeDesc& S = pl.shape[par];
   const int D = pl.D, C = pl.C, SA = tp.SA;
   const bool is_last = (t == pl.T - 1);
@@ -367,7 +368,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, blockDim.x);
 
   const LinDesc& L0 = S.lin[0];
-  const LinDesc& LF = S.lin[1 + 3 * NB];
+  const LinDesc& LF = S.lin[S.fin];
   const int nch = tp.nch[par];
   const int nt0 = (S.in0 + 1 + 15) / 16;        // n-tiles of d W0 (incl. the bias column)
   const int ntc = (C + 1 + 15) / 16;
@@ -432,12 +433,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       // P0's own loads (vmcnt retires in order) so the HBM latency hides under the LULinear backward
       f4 hpre[NB + 1][NSF_HT];
       const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + wave) *
-                                   NSF_AST_SLOTS(NB)) * 1024 + id.lane;
-      ast_load(ast, 4 * NB, hpre[NB]);
+                                   NSF_AST_SLOTS(cm ? 0 : NB)) * 1024 + id.lane;
+      ast_load(ast, cm ? 1 : 4 * NB, hpre[NB]);   // ctx_mlp: slot 1 = h2, slot 0 = h1 (both post-relu)
 #pragma unroll
-      for (int b = NB - 1; b >= 0; --b) ast_load(ast, 4 * b, hpre[b]);
+      for (int b = NB - 1; b >= 0; --b) ast_load(ast, cm ? 0 : 4 * b, hpre[b]);
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
-      if (!(pl.ablate & 64)) {
+      if (cm) {   // no LULinear for theta-dim 1: the transform output IS the layer output
+        for (int k = id.g; k < D; k += 4) {
+          const float gzv = gzs[id.j * pl.ZW + k];
+          gys[id.j * pl.ZW + k] = gzv;
+          gxs[id.j * pl.ZW + k] = gzv;
+          ys[id.j * pl.ZW + k] = zs[id.j * pl.ZW + k];
+        }
+      } else if (!(pl.ablate & 64)) {
         float v[16], o[4];
         row_to_regs16(gzs + id.j * pl.ZW, D, v);
         dense_mv16<true>(lds + S.l_L, D, v, id.g, o);
@@ -499,7 +507,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           TS(5 + 4 * c);                                                                                              \
           __syncthreads();                                                                                            \
           TS(6 + 4 * c);                                                                                              \
-          if (LAST) {                                                                                                 \
+          if (LAST && !cm) {                                                                                          \
             ast_load(ast, 1 + 4 * (NB - 1), bt1);                                                                     \
             ast_load(ast, 2 + 4 * (NB - 1), bt2);                                                                     \
             ast_load(ast, 3 + 4 * (NB - 1), bsg);                                                                     \
@@ -512,7 +520,28 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #undef CHUNK_BODY
 
       TS(19);
+      // ---- P3 (ctx_mlp): h2 = relu(W_h h1 + b_h): one hidden layer to walk back through
+      if (cm) {
+        f4 ga[NSF_HT], gb[NSF_HT];
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[NB][mt][r] > 0.f ? gh[mt][r] : 0.f;
+        stage_D(Ast, SA, arow0 + id.j, id, ga, false);
+        stage_D(Bst, SA, arow0 + id.j, id, hpre[0], true);
+        if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[1], id, ga, gb, pl.ablate);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gh[mt][r] = hpre[0][mt][r] > 0.f ? gb[mt][r] : 0.f;
+      }
       // ---- P3: residual blocks, last -> first
+      if (!cm)
 #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
         f4 ga[NSF_HT], gb[NSF_HT];
@@ -593,7 +622,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 
       TS(41);
       // ---- P5: LULinear parameter gradients as two more 16x16 tiles
-      if (!(pl.ablate & 64)) {
+      if (!cm && !(pl.ablate & 64)) {
         float v[16], o[4];
         row_to_regs16(ys + id.j * pl.ZW, D, v);
         dense_mv16<false>(lds + S.l_U, D, v, id.g, o);
@@ -661,6 +690,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           __syncthreads();
         }
       }
+      if (cm) {
+        __syncthreads();
+        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[0], 4, pl.ablate);
+        __syncthreads();
+      }
+      if (!cm)
   #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
         __syncthreads();
@@ -681,7 +716,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       __syncthreads();
       __syncthreads();
-      if (gw < 2) dw_gemm<1>(Ast, Bst, SA, 16 * gw, 16 * gw, id, accLU);
+      if (gw < 2 && !cm) dw_gemm<1>(Ast, Bst, SA, 16 * gw, 16 * gw, id, accLU);
     }
 
     // ---- write this workgroup's partial gradients (natural parameter order)
@@ -689,14 +724,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     const int out0 = 16 * gw;
   #pragma unroll
     for (int nt = 0; nt < 2; ++nt) write_tile(part, L0, out0, nt, id, acc0[nt]);
+    if (cm) {
   #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+      for (int nt = 0; nt < 4; ++nt) write_tile(part, S.lin[1], out0, nt, id, acc1[0][nt]);   // hidden H->H layer
+    } else {
   #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) write_tile(part, S.lin[1 + 3 * b], out0, nt, id, accC[b][nt]);
+      for (int b = 0; b < NB; ++b) {
   #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        write_tile(part, S.lin[2 + 3 * b], out0, nt, id, acc1[b][nt]);
-        write_tile(part, S.lin[3 + 3 * b], out0, nt, id, acc2[b][nt]);
+        for (int nt = 0; nt < 2; ++nt) write_tile(part, S.lin[1 + 3 * b], out0, nt, id, accC[b][nt]);
+  #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          write_tile(part, S.lin[2 + 3 * b], out0, nt, id, acc1[b][nt]);
+          write_tile(part, S.lin[3 + 3 * b], out0, nt, id, acc2[b][nt]);
+        }
       }
     }
   #pragma unroll
@@ -720,7 +760,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         }
       }
     }
-    {
+    if (!cm) {
       const int ntri = D * (D - 1) / 2;
       float* plow = part + S.g_lu;
       float* pup = plow + ntri;
@@ -777,8 +817,9 @@ int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* pac
     case 2: case 3: return launch_bwd<K, KS, NBV, 3>(BWD_ARGS); \
     default: return launch_bwd<K, KS, NBV, 4>(BWD_ARGS); \
   }
-  if (pl.KSH == 13) { if (pl.NB == 1) { BWD_NCH(13, 1) } else { BWD_NCH(13, 2) } }
-  if (pl.NB == 1) { BWD_NCH(16, 1) } else { BWD_NCH(16, 2) }
+  // ctx_mlp (NB == 0) runs on the NB = 1 instantiation (one hidden H x H gradient tile set)
+  if (pl.KSH == 13) { if (pl.NB <= 1) { BWD_NCH(13, 1) } else { BWD_NCH(13, 2) } }
+  if (pl.NB <= 1) { BWD_NCH(16, 1) } else { BWD_NCH(16, 2) }
 #undef BWD_NCH
 #undef BWD_ARGS
 }

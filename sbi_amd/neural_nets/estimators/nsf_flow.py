@@ -52,7 +52,15 @@ class NSFHyper:
         )
 
     # -- layout of the flat buffer (must agree with csrc/nsf_plan.cpp) -----------
+    @property
+    def ctx_mlp(self) -> bool:
+        """theta-dim 1: sbi swaps the ResidualNet for ``ContextSplineMap`` (flow.py:401-408), uses the
+        dummy mask [1] in every transform and drops the LULinear layers (flow.py:426, 436)."""
+        return self.D == 1
+
     def d_tr(self, t: int) -> int:
+        if self.ctx_mlp:
+            return 1
         return (self.D + 1) // 2 if t % 2 == 0 else self.D // 2
 
     def d_id(self, t: int) -> int:
@@ -61,6 +69,10 @@ class NSFHyper:
     def layer_entries(self, t: int) -> List[Tuple[str, Tuple[int, ...]]]:
         """(nflows sub-key, shape) in flat order for transform t."""
         H, C, P = self.hidden_features, self.C, 3 * self.num_bins - 1
+        if self.ctx_mlp:   # nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) -> indices 0, 2, 4
+            pre = "transform_net.spline_predictor."
+            return [(pre + "0.weight", (H, C)), (pre + "0.bias", (H,)), (pre + "2.weight", (H, H)),
+                    (pre + "2.bias", (H,)), (pre + "4.weight", (P, H)), (pre + "4.bias", (P,))]
         out = [("transform_net.initial_layer.weight", (H, self.d_id(t) + C)),
                ("transform_net.initial_layer.bias", (H,))]
         for b in range(self.num_blocks):
@@ -73,6 +85,8 @@ class NSFHyper:
         return out
 
     def lu_entries(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        if self.ctx_mlp:
+            return []
         n_tri = self.D * (self.D - 1) // 2
         return [("lower_entries", (n_tri,)), ("upper_entries", (n_tri,)),
                 ("unconstrained_upper_diag", (self.D,)), ("bias", (self.D,))]
@@ -115,6 +129,15 @@ class NSFNet(nn.Module):
         chunks: List[Tensor] = []
         for t in range(h.num_transforms):
             mods: Dict[str, nn.Linear] = {}
+            if h.ctx_mlp:
+                pre = "transform_net.spline_predictor."
+                mods[pre + "0"] = nn.Linear(h.C, h.hidden_features)
+                mods[pre + "2"] = nn.Linear(h.hidden_features, h.hidden_features)
+                mods[pre + "4"] = nn.Linear(h.hidden_features, 3 * h.num_bins - 1)
+                for key, _shape in h.layer_entries(t):
+                    mod, attr = key.rsplit(".", 1)
+                    chunks.append(getattr(mods[mod], attr).detach().reshape(-1))
+                continue
             mods["transform_net.initial_layer"] = nn.Linear(h.d_id(t) + h.C, h.hidden_features)
             for b in range(h.num_blocks):
                 pre = f"transform_net.blocks.{b}."
@@ -141,13 +164,14 @@ class NSFNet(nn.Module):
         h = self.hyper
         first = 1 if self.z_score_theta else 0
         off = 0
+        stride = 1 if h.ctx_mlp else 2   # no LULinear between couplings for theta-dim 1
         for t in range(h.num_transforms):
-            pre = f"_transform._transforms.{first + 2 * t}."
+            pre = f"_transform._transforms.{first + stride * t}."
             for key, shape in h.layer_entries(t):
                 n = int(np.prod(shape))
                 yield pre + key, off, n, shape
                 off += n
-            pre = f"_transform._transforms.{first + 2 * t + 1}."
+            pre = f"_transform._transforms.{first + stride * t + 1}."
             for key, shape in h.lu_entries():
                 n = int(np.prod(shape))
                 yield pre + key, off, n, shape

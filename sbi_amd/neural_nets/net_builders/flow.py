@@ -63,10 +63,10 @@ def build_nsf(
         raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
     x_numel = batch_x[0].numel()
     y_numel = batch_y[0].numel()
-    if x_numel == 1:
+    if x_numel == 1 and hidden_layers_spline_context != 1:
         raise NotImplementedError(
-            "sbi_amd.build_nsf: 1-D theta uses sbi's ContextSplineMap conditioner (flow.py:1419-1478), "
-            "which the HIP path does not implement yet."
+            "sbi_amd.build_nsf: the 1-D theta conditioner (ContextSplineMap, flow.py:1419-1478) is implemented "
+            "for hidden_layers_spline_context=1 (the reference default)."
         )
     if batch_x[0].dim() != 1 or batch_y[0].dim() != 1:
         raise NotImplementedError("sbi_amd.build_nsf: theta and x events must be 1-D")

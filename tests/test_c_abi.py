@@ -52,7 +52,8 @@ def test_unsupported_configs_are_refused_not_degraded():
     lib = _lib.load()
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, hidden_features=128).c_config()) == _lib.E_UNSUPPORTED
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, num_bins=7).c_config()) == _lib.E_UNSUPPORTED
-    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=1, C=10).c_config()) == _lib.E_BADARG
+    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=0, C=10).c_config()) == _lib.E_BADARG
+    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=1, C=3).c_config()) == NSFHyper(D=1, C=3).param_count() == 21145
     # null pointers never reach a launch
     cfg = NSFHyper(D=10, C=10).c_config()
     assert lib.sbi_amd_nsf_log_prob(cfg, None, None, None, None, 4, 4, None, None, None) == _lib.E_BADARG

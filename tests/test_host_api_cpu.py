@@ -56,7 +56,8 @@ def test_builder_rejects_what_the_hip_path_does_not_implement():
     with pytest.raises(ValueError, match="transform_to_unconstrained"):
         build_nsf(theta, x, z_score_x="transform_to_unconstrained")
     with pytest.raises(NotImplementedError):
-        build_nsf(theta[:, :1], x)
+        build_nsf(theta[:, :1], x, hidden_layers_spline_context=2)
+    assert build_nsf(theta[:, :1], x).net.hyper.ctx_mlp
     with pytest.raises(NotImplementedError):
         build_nsf(theta, x, embedding_net=torch.nn.Linear(7, 3))
     with pytest.raises(ValueError, match="Invalid z-scoring"):

@@ -25,6 +25,8 @@ CONFIGS = [
     dict(D=10, C=10, z_score_theta="none", z_score_x="none"),
     dict(D=6, C=12, num_bins=16, num_transforms=2),
     dict(D=7, C=4, num_bins=4, hidden_features=20, tail_bound=5.0),
+    dict(D=1, C=3),                                     # ContextSplineMap conditioner (flow.py:401-408)
+    dict(D=1, C=7, hidden_features=32, num_transforms=3),
 ]
 
 
@@ -72,7 +74,7 @@ def test_log_prob_matches_oracle(cfg):
     _assert_as_accurate_as_fp32_reference(got, ref, ref64, "stress log_prob")
 
 
-@pytest.mark.parametrize("cfg", CONFIGS[:5], ids=_ids)
+@pytest.mark.parametrize("cfg", CONFIGS[:5] + CONFIGS[-2:], ids=_ids)
 def test_sample_matches_oracle(cfg):
     """`sample` parity = parity of transform^-1(noise | x) for GIVEN noise (DESIGN.md RNG)."""
     oracle, est, _, x_d = matched_pair(**cfg)
