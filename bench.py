@@ -62,6 +62,18 @@ def cpu_baseline(mode, budget_s=12.0):
     oracle = NSFOracle(theta, x)
     n = 16384
     th, xx = theta[:n], x[:n]
+    if mode == "sample":
+        x_o = x[:1]
+        with torch.no_grad():
+            oracle.sample((n,), x_o)
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s or reps < 2:
+                oracle.sample((n,), x_o)
+                reps += 1
+            dt = time.perf_counter() - t0
+        return {"value": n * reps / dt, "unit": "draws/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x {n}-draw oracle sample calls, no support check ({dt:.1f} s), "
+                          f"torch {torch.__version__} CPU fp32"}
     if mode == "log_prob":
         with torch.no_grad():
             oracle.log_prob(th, xx)
@@ -124,9 +136,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["both", "train", "log_prob"],
+    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--draws", type=int, default=1_000_000, help="posterior draws per step in the sample leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -160,6 +173,24 @@ def main():
         results["log_prob"] = {"value": B * world * args.steps / wall, "unit": "evals/s",
                                "ms_per_step": wall / args.steps * 1e3,
                                "roofline": roofline(F_EVAL, B, args.steps, dev_ms)}
+    if args.mode in ("both", "sample"):
+        # BASELINE configs[3] (M3): DirectPosterior.sample of 10^6 draws for one x_o, prior support check included
+        from torch.distributions import Independent, Normal
+
+        from sbi_amd.inference.posteriors.direct_posterior import DirectPosterior
+
+        prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
+        posterior = DirectPosterior(est, prior, device=device)
+        x_o = x[:1].clone()
+        nd = args.draws
+
+        def sample_step():
+            posterior.sample((nd,), x=x_o, max_sampling_batch_size=nd, show_progress_bars=False)
+
+        ssteps = max(1, min(args.steps, 10))
+        wall, dev_ms = timed(sample_step, ssteps, min(args.warmup, 2), device, dist)
+        results["sample"] = {"value": nd * world * ssteps / wall, "unit": "draws/s", "steps": ssteps,
+                             "ms_per_step": wall / ssteps * 1e3, "roofline": roofline(F_EVAL, nd, ssteps, dev_ms)}
     if args.mode in ("both", "train"):
         from sbi_amd.inference.trainers.fused import FusedTrainStep
 
@@ -170,10 +201,11 @@ def main():
                             "roofline": roofline(F_TRAIN, B, args.steps, dev_ms)}
 
     if rank == 0:
-        head = "train" if "train" in results else "log_prob"
+        head = "train" if "train" in results else ("log_prob" if "log_prob" in results else "sample")
         r = results[head]
         out = {
-            "metric": "NPE train (theta,x)-pairs/sec" if head == "train" else "NSF log_prob evals/sec",
+            "metric": {"train": "NPE train (theta,x)-pairs/sec", "log_prob": "NSF log_prob evals/sec",
+                       "sample": "DirectPosterior.sample draws/sec"}[head],
             "value": r["value"], "unit": r["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -190,8 +222,15 @@ def main():
             lp = results["log_prob"]
             out["log_prob"] = {"metric": "NSF log_prob evals/sec", "value": lp["value"], "unit": lp["unit"],
                                "ms_per_step": lp["ms_per_step"], "roofline": lp["roofline"]}
+        if "sample" in results and head != "sample":
+            sp = results["sample"]
+            out["posterior_sample"] = {"metric": "DirectPosterior.sample draws/sec", "value": sp["value"],
+                                       "unit": sp["unit"], "draws_per_step": args.draws, "steps": sp["steps"],
+                                       "ms_per_step": sp["ms_per_step"], "roofline": sp["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(head)
+            if "posterior_sample" in out:
+                out["posterior_sample"]["cpu_baseline"] = cpu_baseline("sample", budget_s=6.0)
             if "log_prob" in results and head == "train":
                 out["log_prob"]["cpu_baseline"] = cpu_baseline("log_prob", budget_s=8.0)
         print(json.dumps(out))
