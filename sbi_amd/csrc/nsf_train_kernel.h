@@ -325,7 +325,9 @@ __device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDe
 // (m-tile = wave-4 of every linear layer) and consume the (gradient, activation) tiles
 // the row waves publish in LDS.  One wave of each kind shares a SIMD, so a row wave's
 // transposed GEMM overlaps its partner's weight-gradient GEMM; both stay under 256 VGPRs.
-template <int K, int KSH, int NB, int NCH>
+// NBT = residual blocks; NBT == 0 selects the theta-dim-1 ContextSplineMap conditioner (compile time, so the
+// residual-net instantiations carry none of its code or registers).
+template <int K, int KSH, int NBT, int NCH>
 __global__ void __launch_bounds__(128 * TR_NW, 2)
 nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const float* __restrict__ packed,
                      const float* __restrict__ zstats, const float* __restrict__ z_in,
@@ -342,7 +344,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const LaneId id = make_lane();
-  const bool cm = pl.ctx_mlp != 0;            // theta-dim 1: context-only MLP conditioner, no LULinear
+  constexpr bool cm = (NBT == 0);             // theta-dim 1: context-only MLP conditioner, no LULinear
+  constexpr int NB = cm ? 1 : NBT;            // ctx_mlp: one hidden H x H gradient tile set
   const int par = cm ? 0 : (t & 1);
   const ShapeDesc& S = pl.shape[par];
   const int D = pl.D, C = pl.C, SA = tp.SA;
@@ -817,7 +820,10 @@ int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* pac
     case 2: case 3: return launch_bwd<K, KS, NBV, 3>(BWD_ARGS); \
     default: return launch_bwd<K, KS, NBV, 4>(BWD_ARGS); \
   }
-  // ctx_mlp (NB == 0) runs on the NB = 1 instantiation (one hidden H x H gradient tile set)
+  if (pl.ctx_mlp) {   // theta-dim 1: one transformed dim => one chunk
+    if (pl.KSH == 13) return launch_bwd<K, 13, 0, 1>(BWD_ARGS);
+    return launch_bwd<K, 16, 0, 1>(BWD_ARGS);
+  }
   if (pl.KSH == 13) { if (pl.NB <= 1) { BWD_NCH(13, 1) } else { BWD_NCH(13, 2) } }
   if (pl.NB <= 1) { BWD_NCH(16, 1) } else { BWD_NCH(16, 2) }
 #undef BWD_NCH
