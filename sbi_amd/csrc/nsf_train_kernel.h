@@ -5,13 +5,12 @@
 //                                                         trainers/base.py:1178-1181)
 // Structure (DESIGN.md "training pass"):
 //   1. forward flow kernel with the per-transform input state stashed (T*N*D floats);
-//   2. one backward launch per transform, last -> first.  Persistent workgroups of 4
-//      waves walk 64-row tiles: each wave recomputes its 16 rows' conditioner
-//      activations on MFMA (registers), back-propagates spline -> conditioner -> input
-//      on MFMA with the transposed weight image, and the four waves share their
-//      (activation, gradient) tiles through LDS so that every wave accumulates a fixed
-//      quarter of the layer's weight-gradient tiles in registers across all of the
-//      workgroup's rows;
+//   2. one backward launch per transform, last -> first.  Persistent workgroups walk
+//      64-row tiles with 4 "row" waves (spline forward + reverse mode on the VALU, the
+//      row-wise backward through the residual blocks on MFMA with the transposed weight
+//      image) and 4 "grad" waves (final-layer recompute, Wf^T g, and a fixed quarter of
+//      every weight-gradient tile, all on MFMA); the two kinds share a SIMD pairwise and
+//      exchange (activation, gradient) tiles through LDS, one barrier per phase;
 //   3. a deterministic reduction of the per-workgroup partial gradients (no atomics).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -23,10 +22,10 @@
 #define TR_GRID_MAX 256    // persistent workgroups (one per CU)
 
 struct TrainPlan {
-  int SA;                  // row stride of the shared staging tiles
-  int o_Ast, o_Bst;        // LDS float offsets of the staging tiles [64][SA]
-  int o_wave, w_total;     // per-wave scratch base / size
-  int w_zs, w_ys, w_gys, w_gxs, w_gzs, w_cs, w_cin, w_us, w_gus;
+  int SA, SB, SS;          // row strides: gradient tiles A0/A1, activation tile B, static input tile Bs
+  int o_A0, o_A1, o_B, o_Bs, o_cnt;   // LDS float offsets ([64][stride] tiles; grad-wave sync counter)
+  int o_wave, w_total;     // per-row-wave scratch base / size
+  int w_zs, w_gys, w_gzs;  // 16 x ZW each: state (z -> y in place), gradient (g_y -> g_x in place), upstream g_z
   int DCHB, PTW;           // spline dims per chunk, floats per dim slot (16*PT)
   int nch[2];              // chunks per mask parity
   int PLP;                 // floats per (workgroup, transform) partial-gradient slab
@@ -34,6 +33,11 @@ struct TrainPlan {
   int lds_floats;
 };
 
+// Tile strides: the grad waves read K = row down a tile (row = 4s + g, column = c0 + j), so a stride
+// = 16 (mod 64) puts the four g groups in disjoint bank quadrants (conflict free); the row waves
+// write/read D fragments (row = j, column = 4r + g), for which stride 68 is the conflict-free one.
+// The activation tile B is read 4x as often as it is written => 80; the gradient tiles keep 68
+// (they double as the spline's parameter rows, read and written by the row waves).
 static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   if (pl.D > 15 || pl.H > 63 || pl.NB > 2 || (pl.NB < 1 && !pl.ctx_mlp)) return SBI_AMD_E_UNSUPPORTED;
   const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
@@ -47,22 +51,24 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
     if (tp->nch[par] > TR_MAXCH) return SBI_AMD_E_UNSUPPORTED;
   }
   tp->SA = 68;
-  int o = pl.lds_w_floats;
-  tp->o_Ast = o; o += TR_ROWS * tp->SA;
-  tp->o_Bst = o; o += TR_ROWS * tp->SA;
-  tp->o_wave = o;
+  tp->SS = 48;   // [z_id ; context ; 1 ; 0...]: d W0 reads columns [0, 32), d Wc columns [d_id, d_id + 32)
   int w = 0;
   tp->w_zs = w; w += 16 * pl.ZW;
-  tp->w_ys = w; w += 16 * pl.ZW;
   tp->w_gys = w; w += 16 * pl.ZW;
-  tp->w_gxs = w; w += 16 * pl.ZW;
   tp->w_gzs = w; w += 16 * pl.ZW;
-  tp->w_us = w; w += 16 * pl.ZW;
-  tp->w_gus = w; w += 16 * pl.ZW;
-  tp->w_cs = w; w += 16 * pl.CW;
-  tp->w_cin = w; w += 16 * pl.CINW;
-  tp->w_total = (w + 3) / 4 * 4;
-  tp->lds_floats = tp->o_wave + TR_NW * tp->w_total;
+  tp->w_total = (w + 8 + 3) / 4 * 4;   // + slack: the 16-wide row reads run past a ZW-float row
+  for (int sb = 80; sb >= 68; sb -= 12) {
+    tp->SB = sb;
+    int o = pl.lds_w_floats;
+    tp->o_A0 = o; o += TR_ROWS * tp->SA;
+    tp->o_A1 = o; o += TR_ROWS * tp->SA;
+    tp->o_B = o; o += TR_ROWS * tp->SB;
+    tp->o_Bs = o; o += TR_ROWS * tp->SS;
+    tp->o_cnt = o; o += 4;
+    tp->o_wave = o;
+    tp->lds_floats = tp->o_wave + TR_NW * tp->w_total;
+    if (4ll * tp->lds_floats <= NSF_LDS_LIMIT_BYTES) break;
+  }
   if (4ll * tp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
   int pmax = pl.shape[0].n_params > pl.shape[1].n_params ? pl.shape[0].n_params : pl.shape[1].n_params;
   tp->PLP = (pmax + 1 + 3) / 4 * 4;
@@ -86,7 +92,7 @@ __device__ __forceinline__ void stage_D(float* __restrict__ st, int SA, int row,
 
 // weight-gradient tile(s): acc[nt] += sum_{rows of the 64-row tile} A[row][acol0+i] * B[row][bcol0+16nt+j]
 template <int NT>
-__device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst, int SA,
+__device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst, int SA, int SB,
                                         int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT,
                                         int abl = 0) {
   if (abl & 1) return;
@@ -96,8 +102,27 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
     const float a = Ast[row * SA + acol0 + id.j];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      if (nt < nt_on) acc[nt] = MFMA16(a, Bst[row * SA + bcol0 + 16 * nt + id.j], acc[nt]);
+      if (nt < nt_on) acc[nt] = MFMA16(a, Bst[row * SB + bcol0 + 16 * nt + id.j], acc[nt]);
   }
+}
+
+// row-major tile -> D fragments (inverse of stage_D)
+__device__ __forceinline__ void load_D(const float* __restrict__ st, int SA, int row, const LaneId& id,
+                                       f4 (&v)[NSF_HT]) {
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[mt][r] = st[row * SA + 16 * mt + 4 * r + id.g];
+}
+
+// Rendezvous of the four grad waves only (the row waves are busy in their own phase): LDS counter,
+// monotonically increasing; `target` = 4 x (number of rendezvous so far).  DS ops of a wave execute
+// in order, so the tile reads issued before the increment have completed when it lands.
+__device__ __forceinline__ void grad_wave_sync(int* cnt, int target, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // row-wise backward through a linear layer: acc[mt] += sum_k W[k][feat(mt)] * g[k], g = D fragments.
@@ -320,11 +345,18 @@ __device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDe
 }
 
 // ------------------------------------------------------------------ backward kernel
-// Wave specialisation: waves 0-3 ("row" waves) own 16 rows each and run recompute +
-// row-wise backward; waves 4-7 ("grad" waves) own the weight-gradient accumulators
-// (m-tile = wave-4 of every linear layer) and consume the (gradient, activation) tiles
-// the row waves publish in LDS.  One wave of each kind shares a SIMD, so a row wave's
-// transposed GEMM overlaps its partner's weight-gradient GEMM; both stay under 256 VGPRs.
+// Wave specialisation, one workgroup = 64-row tile:
+//   waves 0-3 ("row" waves): 16 rows each.  Loads, LULinear backward, the spline forward + reverse
+//     mode (VALU), the row-wise backward through the residual blocks (transposed-weight MFMA GEMMs);
+//   waves 4-7 ("grad" waves): wave 4+w recomputes the final layer for row wave w's rows, multiplies the
+//     spline-parameter gradients back through Wf (both MFMA, B operand = stashed h in registers), and
+//     owns m-tile w of every weight-gradient for the whole launch (accumulators in registers).
+// Wave w and wave 4+w share a SIMD, so the spline's VALU work runs under its partner's MFMAs.
+// Tiles in LDS: A0/A1 (gradient side, double buffered: spline parameters of chunk k+1 are produced
+// while chunk k is in the spline and chunk k-1 is being consumed), B (activation side), Bs (conditioner
+// input [z_id ; context ; 1], static per tile: B operand of d W0 and d Wc).  One workgroup barrier per
+// phase; both wave kinds execute the same barrier sequence:
+//   S0 | prologue | K0 | chunk steps 0..nch (K1..K_nch) | H | per block: X1 X2 X3 (X4) | Y1 | Y2
 // NBT = residual blocks; NBT == 0 selects the theta-dim-1 ContextSplineMap conditioner (compile time, so the
 // residual-net instantiations carry none of its code or registers).
 template <int K, int KSH, int NBT, int NCH>
@@ -346,29 +378,18 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   const LaneId id = make_lane();
   constexpr bool cm = (NBT == 0);             // theta-dim 1: context-only MLP conditioner, no LULinear
   constexpr int NB = cm ? 1 : NBT;            // ctx_mlp: one hidden H x H gradient tile set
+  constexpr int SLOTS = NSF_AST_SLOTS(NBT);
   const int par = cm ? 0 : (t & 1);
   const ShapeDesc& S = pl.shape[par];
-  const int D = pl.D, C = pl.C, SA = tp.SA;
+  const int D = pl.D, C = pl.C, SA = tp.SA, SB = tp.SB, SS = tp.SS;
   const bool is_last = (t == pl.T - 1);
-  float* Ast = lds + tp.o_Ast;
-  float* Bst = lds + tp.o_Bst;
-  float* sc = lds + tp.o_wave + wave * tp.w_total;
-  float* zs = sc + tp.w_zs;
-  float* ys = sc + tp.w_ys;
-  float* gys = sc + tp.w_gys;
-  float* gxs = sc + tp.w_gxs;
-  float* gzs = sc + tp.w_gzs;
-  float* us = sc + tp.w_us;
-  float* gus = sc + tp.w_gus;
-  float* cs = sc + tp.w_cs;
-  float* cin = sc + tp.w_cin;
-  const int arow0 = 16 * wave;                 // this wave's rows inside the shared tiles
-  float* Arow = Ast + arow0 * SA;
-  float* Brow = Bst + arow0 * SA;
+  float* Bt = lds + tp.o_B;
+  float* Bs = lds + tp.o_Bs;
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
   stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, blockDim.x);
+  if (tid == 0) *(int*)(lds + tp.o_cnt) = 0;
 
   const LinDesc& L0 = S.lin[0];
   const LinDesc& LF = S.lin[S.fin];
@@ -376,11 +397,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   const int nt0 = (S.in0 + 1 + 15) / 16;        // n-tiles of d W0 (incl. the bias column)
   const int ntc = (C + 1 + 15) / 16;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // after the chunk steps: AX receives g_h from the grad waves, AY is the other gradient tile
+  const int o_AX = (nch & 1) ? tp.o_A1 : tp.o_A0;
+  const int o_AY = (nch & 1) ? tp.o_A0 : tp.o_A1;
 
   if (wave < TR_NW) {
     // =========================== row waves ===========================
-    // the guard-free mat-vec helpers read up to 6 floats past a 10-float row: make sure that
-    // never is uninitialised LDS (NaN x 0 = NaN)
+    float* sc = lds + tp.o_wave + wave * tp.w_total;
+    float* zs = sc + tp.w_zs;      // z; transformed dims become the spline output y in place
+    float* gys = sc + tp.w_gys;    // g_y; becomes g_x (gradient wrt this transform's input) in place
+    float* gzs = sc + tp.w_gzs;    // upstream gradient wrt the LULinear output
+    const int arow0 = 16 * wave;   // this wave's rows inside the shared tiles
+    // the guard-free mat-vec helpers read 16 floats from a ZW-float row: make sure that never is
+    // uninitialised LDS (NaN x 0 = NaN)
     for (int i = id.lane; i < tp.w_total; i += 64) sc[i] = 0.f;
     const LaneId id0 = id;
     for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
@@ -393,23 +422,26 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const bool valid = row < n;
       const float wn = valid ? (row_w ? row_w[row] : uni_w) : 0.f;
       const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
-      float cr[4];
-      __syncthreads();                             // weights staged / previous tile's shared reads done
+      const int trow = arow0 + id.j;
+      __syncthreads();                             // S0: weights staged / previous tile fully consumed
       TS(0);
       // ---- P0: load state, context, upstream gradient.  All loads are issued before the first
       // use (clamped addresses instead of predicated loads), so one HBM round trip covers them.
       {
         const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
         const long long rs = valid ? row : 0;
-        float zv[4], gv[4], xv[4];
+        float zv[4], gv[4], xv[8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int d = id.g + 4 * u;
           const int dc = d < D ? d : 0;
           zv[u] = z_in[rs * D + dc];
           gv[u] = gz_up[rs * D + dc];
-          const int c = d < C ? d : 0;
-          xv[u] = x[(valid ? xr : 0) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = id.g + 4 * u - S.d_id;
+          xv[u] = x[(valid ? xr : 0) * C + ((c >= 0 && c < C) ? c : 0)];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -419,198 +451,174 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
             const float gz = valid ? gv[u] : 0.f;
             gzs[id.j * pl.ZW + d] = is_last ? wn * gz : gz;   // last transform: d/dz_T of w*(0.5|z|^2) = w z
           }
-          if (d < C) {
-            const float v = ((valid ? xv[u] : 0.f) - x_mean[d]) / x_std[d];
-            cs[id.j * pl.CW + d] = v;
-          }
-          cr[u] = (d < C && C <= 16) ? ((valid ? xv[u] : 0.f) - x_mean[d < C ? d : 0]) / x_std[d < C ? d : 0] : 0.f;
         }
-        for (int c = id.g + 16; c < C; c += 4) {   // C > 16: remaining context columns
-          float v = valid ? x[xr * C + c] : 0.f;
-          cs[id.j * pl.CW + c] = (v - x_mean[c]) / x_std[c];
+        wave_lds_fence();
+        // conditioner-input row [z_id ; standardized context ; 1 ; 0 ...] -> static tile Bs
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+          const int k = id.g + 4 * u;
+          float v = 0.f;
+          if (u < 8) {
+            const int c = k - S.d_id;
+            if (k < S.d_id) v = zs[id.j * pl.ZW + 2 * k + (1 - par)];
+            else if (c < C) v = ((valid ? xv[u] : 0.f) - x_mean[c]) / x_std[c];
+            else if (k == S.in0) v = 1.f;
+          }
+          Bs[trow * SS + k] = v;
         }
       }
-      wave_lds_fence();
-      // ---- P1: reload the block inputs h_0..h_NB the forward pass stashed (register-order slabs,
-      // 256-byte coalesced loads) instead of recomputing the hidden stack; issued right after
-      // P0's own loads (vmcnt retires in order) so the HBM latency hides under the LULinear backward
-      f4 hpre[NB + 1][NSF_HT];
-      const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + wave) *
-                                   NSF_AST_SLOTS(cm ? 0 : NB)) * 1024 + id.lane;
-      ast_load(ast, cm ? 1 : 4 * NB, hpre[NB]);   // ctx_mlp: slot 1 = h2, slot 0 = h1 (both post-relu)
-#pragma unroll
-      for (int b = NB - 1; b >= 0; --b) ast_load(ast, cm ? 0 : 4 * b, hpre[b]);
-      // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T gz, g_y = U^T g_u
+      // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T g_z, g_y = U^T g_u
+      float gus_r[4] = {0.f, 0.f, 0.f, 0.f};     // g_u of dims g + 4 ii, kept for the LU parameter gradients
       if (cm) {   // no LULinear for theta-dim 1: the transform output IS the layer output
-        for (int k = id.g; k < D; k += 4) {
-          const float gzv = gzs[id.j * pl.ZW + k];
-          gys[id.j * pl.ZW + k] = gzv;
-          gxs[id.j * pl.ZW + k] = gzv;
-          ys[id.j * pl.ZW + k] = zs[id.j * pl.ZW + k];
-        }
+        for (int k = id.g; k < D; k += 4) gys[id.j * pl.ZW + k] = gzs[id.j * pl.ZW + k];
       } else if (!(pl.ablate & 64)) {
         float v[16], o[4];
         row_to_regs16(gzs + id.j * pl.ZW, D, v);
-        dense_mv16<true>(lds + S.l_L, D, v, id.g, o);
+        dense_mv16<true>(lds + S.l_L, D, v, id.g, gus_r);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
-          if (id.g + 4 * ii < D) gus[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+          if (id.g + 4 * ii < D) gys[id.j * pl.ZW + id.g + 4 * ii] = gus_r[ii];
         wave_lds_fence();
-        row_to_regs16(gus + id.j * pl.ZW, D, v);
+        row_to_regs16(gys + id.j * pl.ZW, D, v);
         dense_mv16<true>(lds + S.l_U, D, v, id.g, o);
+        wave_lds_fence();
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int k = id.g + 4 * ii;
-          if (k < D) {
-            gys[id.j * pl.ZW + k] = o[ii];
-            gxs[id.j * pl.ZW + k] = o[ii];             // identity dims pass through (transformed dims overwritten)
-            ys[id.j * pl.ZW + k] = zs[id.j * pl.ZW + k];
+        for (int ii = 0; ii < 4; ++ii)
+          if (id.g + 4 * ii < D) gys[id.j * pl.ZW + id.g + 4 * ii] = o[ii];   // identity dims pass through
+      }
+      wave_lds_fence();
+      const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + wave) * SLOTS) * 1024 +
+                         id.lane;
+      TS(1);
+      __syncthreads();                             // K0: spline parameters of chunk 0 are in A0
+      TS(2);
+
+      // ---- chunk steps: spline forward + reverse mode in place on the grad waves' parameter rows
+      f4 bt1[NSF_HT], bt2[NSF_HT], bsg[NSF_HT];   // block temporaries, loaded one phase ahead of their use
+      f4 hpre[cm ? 2 : 1][NSF_HT];                // block input h_b (ctx_mlp: h1, h2)
+      for (int c = 0; c < nch; ++c) {
+        const int d0 = c * DCHB;
+        const int slot = id.g & 1, part = id.g >> 1;
+        const int dd = d0 + slot;
+        float* pp = lds + ((c & 1) ? tp.o_A1 : tp.o_A0) + trow * SA + slot * tp.PTW;
+        if (slot < DCHB) {
+          if (dd < S.d_tr && !(pl.ablate & 4)) {
+            const int zi = id.j * pl.ZW + 2 * dd + par;
+            float yv, gxv;
+            rq_spline_pair_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);
+            if (part == 0) {
+              zs[zi] = yv;
+              gys[zi] = gxv;
+            }
+          } else if (part == 0) {
+            for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;
           }
         }
+        TS(3 + c);
+        __syncthreads();                           // K_{c+1}
       }
-      build_cin(pl, S, par, id, zs, cs, cr, cin);
-      const float* cin_row = cin + id.j * pl.CINW + id.g;
-      TS(1);
-
-      TS(2);
-      // ---- P2: final layer + spline, chunk by chunk; d Wf; g_h = Wf^T g_p
-      stage_D(Bst, SA, arow0 + id.j, id, hpre[NB], false);
-      if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;      // bias column
-      f4 gh[NSF_HT];
-#pragma unroll
-      for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
-      f4 bt1[NSF_HT], bt2[NSF_HT], bsg[NSF_HT];   // block temporaries, loaded one phase ahead of their use
-      // chunk loop with the LAST iteration peeled (it also starts the prefetch of the last block's
-      // temporaries; peeling keeps those 48 registers dead during the earlier chunks' splines)
-#define CHUNK_BODY(LAST)                                                                                              \
-      {                                                                                                               \
-          const int d0 = c * DCHB;                                                                                    \
-          TS(3 + 4 * c);                                                                                              \
-          if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, Arow, pl, tp, S, id, hpre[NB], d0);                \
-          wave_lds_fence();                                                                                           \
-          TS(4 + 4 * c);                                                                                              \
-          {                                                                                                           \
-            const int slot = id.g & 1, part = id.g >> 1;                                                              \
-            const int dd = d0 + slot;                                                                                 \
-            float* pp = Arow + id.j * SA + slot * tp.PTW;                                                             \
-            if (slot < DCHB) {                                                                                        \
-              if (dd < S.d_tr && !(pl.ablate & 4)) {                                                                  \
-                const int zi = id.j * pl.ZW + 2 * dd + par;                                                           \
-                float yv, gxv;                                                                                        \
-                rq_spline_pair_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);                           \
-                if (part == 0) {                                                                                      \
-                  ys[zi] = yv;                                                                                        \
-                  gxs[zi] = gxv;                                                                                      \
-                }                                                                                                     \
-              } else if (part == 0) {                                                                                 \
-                for (int k = 0; k < tp.PTW; ++k) pp[k] = 0.f;                                                         \
-              }                                                                                                       \
-            }                                                                                                         \
-          }                                                                                                           \
-          TS(5 + 4 * c);                                                                                              \
-          __syncthreads();                                                                                            \
-          TS(6 + 4 * c);                                                                                              \
-          if (LAST && !cm) {                                                                                          \
-            ast_load(ast, 1 + 4 * (NB - 1), bt1);                                                                     \
-            ast_load(ast, 2 + 4 * (NB - 1), bt2);                                                                     \
-            ast_load(ast, 3 + 4 * (NB - 1), bsg);                                                                     \
-          }                                                                                                           \
-          if (!(pl.ablate & 2)) wft_chunk<PT>(lds, LF, pl, S, id, Arow, SA, d0, gh);                                  \
-          __syncthreads();                                                                                            \
-      }
-      for (int c = 0; c < nch - 1; ++c) CHUNK_BODY(false)
-      { const int c = nch - 1; CHUNK_BODY(true) }
-#undef CHUNK_BODY
-
-      TS(19);
-      // ---- P3 (ctx_mlp): h2 = relu(W_h h1 + b_h): one hidden layer to walk back through
+      // ---- step nch (the grad waves finish d Wf / Wf^T g of the last chunk): fetch the last block's
+      // temporaries and do the LULinear forward piece its parameter gradients need, u = U y
       if (cm) {
+        ast_load(ast, 0, hpre[0]);
+        ast_load(ast, 1, hpre[1]);
+      } else {
+        ast_load(ast, 2 + 4 * (NB - 1), bt2);
+        ast_load(ast, 3 + 4 * (NB - 1), bsg);
+        ast_load(ast, 1 + 4 * (NB - 1), bt1);
+      }
+      float us_r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!cm && !(pl.ablate & 64)) {
+        float v[16];
+        row_to_regs16(zs + id.j * pl.ZW, D, v);
+        dense_mv16<false>(lds + S.l_U, D, v, id.g, us_r);
+      }
+      TS(8);
+      __syncthreads();                             // H: g_h = Wf^T g_p of this wave's rows is in AX
+      TS(9);
+      f4 gh[NSF_HT];
+      load_D(lds + o_AX, SA, trow, id, gh);
+      wave_lds_fence();
+
+      if (cm) {
+        // ---- ctx_mlp: h2 = relu(W_h h1 + b_h): one hidden layer to walk back through
         f4 ga[NSF_HT], gb[NSF_HT];
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[NB][mt][r] > 0.f ? gh[mt][r] : 0.f;
-        stage_D(Ast, SA, arow0 + id.j, id, ga, false);
-        stage_D(Bst, SA, arow0 + id.j, id, hpre[0], true);
-        if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
-        __syncthreads();
+          for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[1][mt][r] > 0.f ? gh[mt][r] : 0.f;
+        stage_D(lds + o_AY, SA, trow, id, ga, false);
+        stage_D(Bt, SB, trow, id, hpre[0], true);
+        if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;
+        __syncthreads();                           // X1
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
         gemm_T_breg<KSH, NSF_HT>(lds, S.lin[1], id, ga, gb, pl.ablate);
-        __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) gh[mt][r] = hpre[0][mt][r] > 0.f ? gb[mt][r] : 0.f;
-      }
-      // ---- P3: residual blocks, last -> first
-      if (!cm)
+      } else {
+        // ---- residual blocks, last -> first
 #pragma unroll
-      for (int b = NB - 1; b >= 0; --b) {
-        f4 ga[NSF_HT], gb[NSF_HT];
-        {
-          f4 gc[NSF_HT];
+        for (int b = NB - 1; b >= 0; --b) {
+          f4 ga[NSF_HT], gb[NSF_HT];
+          {
+            f4 gc[NSF_HT];
+#pragma unroll
+            for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float sgm = bsg[mt][r];
+                ga[mt][r] = gh[mt][r] * sgm;                                 // d t2
+                gc[mt][r] = gh[mt][r] * bt2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
+              }
+            stage_D(lds + o_AY, SA, trow, id, ga, false);
+            stage_D(lds + o_AX, SA, trow, id, gc, false);
+          }
+          stage_D(Bt, SB, trow, id, bt1, true);
+          if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;      // bias column
+          ast_load(ast, 4 * b, hpre[0]);                  // h_b: needed two phases from now
+          if (b > 0) {   // next (earlier) block's t2 / gate: fetch under this block's GEMM phases
+            ast_load(ast, 2 + 4 * (b - 1), bt2);
+            ast_load(ast, 3 + 4 * (b - 1), bsg);
+          }
+          TS(20 + 8 * b);
+          __syncthreads();                         // X1: (g_t2, relu t1) and (g_c, Bs) published
+          TS(21 + 8 * b);
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb, pl.ablate);       // d relu(t1)
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float sgm = bsg[mt][r];
-              ga[mt][r] = gh[mt][r] * sgm;                                 // d t2
-              gc[mt][r] = gh[mt][r] * bt2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
-            }
-          // d Wc first (A = g_c, B = standardized context): g_c dies right away
-          stage_D(Ast, SA, arow0 + id.j, id, gc, false);
-          for (int k = id.g; k < 16 * ntc; k += 4)
-            Brow[id.j * SA + k] = k < C ? cs[id.j * pl.CW + k] : (k == C ? 1.f : 0.f);
+            for (int r = 0; r < 4; ++r) ga[mt][r] = bt1[mt][r] > 0.f ? gb[mt][r] : 0.f;   // d t1
+          if (b > 0) ast_load(ast, 1 + 4 * (b - 1), bt1);
+          TS(22 + 8 * b);
+          __syncthreads();                         // X2: d W2 / d Wc done, tiles free
+          TS(23 + 8 * b);
+          stage_D(lds + o_AY, SA, trow, id, ga, false);
+          stage_D(Bt, SB, trow, id, hpre[0], true);
+          if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;
+          __syncthreads();                         // X3: (g_t1, relu h_b) published
+          TS(24 + 8 * b);
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb, pl.ablate);       // d relu(h_b)
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gh[mt][r] += hpre[0][mt][r] > 0.f ? gb[mt][r] : 0.f;
+          TS(25 + 8 * b);
+          if (b > 0) __syncthreads();              // X4: d W1 done, tiles free for the next block
         }
-        if (b > 0) {   // next (earlier) block's t2 / gate: fetch under this block's GEMM phases
-          ast_load(ast, 2 + 4 * (b - 1), bt2);
-          ast_load(ast, 3 + 4 * (b - 1), bsg);
-        }
-        __syncthreads();
-        __syncthreads();
-        TS(20 + 8 * b);
-        // d W2 : A = g_t2, B = relu(t1)
-        stage_D(Ast, SA, arow0 + id.j, id, ga, false);
-        stage_D(Bst, SA, arow0 + id.j, id, bt1, true);
-        if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-        TS(21 + 8 * b);
-        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb, pl.ablate);       // d relu(t1)
-        TS(22 + 8 * b);
-        __syncthreads();
-        TS(23 + 8 * b);
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ga[mt][r] = bt1[mt][r] > 0.f ? gb[mt][r] : 0.f;   // d t1
-        if (b > 0) ast_load(ast, 1 + 4 * (b - 1), bt1);
-        // d W1 : A = g_t1, B = relu(h_b)
-        stage_D(Ast, SA, arow0 + id.j, id, ga, false);
-        stage_D(Bst, SA, arow0 + id.j, id, hpre[b], true);
-        if (id.g == 0) Bst[(arow0 + id.j) * SA + pl.H] = 1.f;
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-        TS(24 + 8 * b);
-        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb, pl.ablate);       // d relu(h_b)
-        TS(25 + 8 * b);
-        __syncthreads();
-        TS(26 + 8 * b);
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gh[mt][r] += hpre[b][mt][r] > 0.f ? gb[mt][r] : 0.f;
       }
 
+      // ---- initial layer: publish g_h0 (AX is free: d Wc finished before X2)
+      stage_D(lds + o_AX, SA, trow, id, gh, false);
       TS(40);
-      // ---- P4: initial layer
-      stage_D(Ast, SA, arow0 + id.j, id, gh, false);
-      for (int k = id.g; k < 16 * nt0; k += 4)
-        Brow[id.j * SA + k] = k < S.in0 ? cin[id.j * pl.CINW + k] : (k == S.in0 ? 1.f : 0.f);
-      __syncthreads();
+      __syncthreads();                             // Y1
+      TS(41);
       {
         f4 gin[1];
         gin[0] = zero4;
@@ -618,36 +626,29 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 4 * r + id.g;     // identity feature slot
-          if (k < S.d_id) gxs[id.j * pl.ZW + 2 * k + (1 - par)] += gin[0][r];
+          if (k < S.d_id) gys[id.j * pl.ZW + 2 * k + (1 - par)] += gin[0][r];
         }
       }
-      __syncthreads();
-
-      TS(41);
-      // ---- P5: LULinear parameter gradients as two more 16x16 tiles
-      if (!cm && !(pl.ablate & 64)) {
-        float v[16], o[4];
-        row_to_regs16(ys + id.j * pl.ZW, D, v);
-        dense_mv16<false>(lds + S.l_U, D, v, id.g, o);
+      // ---- LULinear parameter gradients as two more 16x16 tiles (AY / B are free after Y1):
+      //   d U = g_u (x) y (+ the logabsdet row),  d L = g_z (x) u,  d bias = sum g_z
+      if (!cm) {
+        float* Ay = lds + o_AY + trow * SA;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-          if (id.g + 4 * ii < D) us[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+        for (int ii = 0; ii < 4; ++ii) {
+          const int k = id.g + 4 * ii;
+          const int o = id.j * pl.ZW + k;
+          Ay[k] = k < D ? gus_r[ii] : (k == D ? gld : 0.f);
+          Ay[16 + k] = k < D ? gzs[o] : 0.f;
+          Bt[trow * SB + k] = k < D ? zs[o] : (k == D ? 1.f : 0.f);
+          Bt[trow * SB + 16 + k] = k < D ? us_r[ii] : (k == D ? 1.f : 0.f);
+        }
       }
-      wave_lds_fence();
-      for (int k = id.g; k < 16; k += 4) {
-        const int o = id.j * pl.ZW + k;
-        Arow[id.j * SA + k] = k < D ? gus[o] : (k == D ? gld : 0.f);
-        Arow[id.j * SA + 16 + k] = k < D ? gzs[o] : 0.f;
-        Brow[id.j * SA + k] = k < D ? ys[o] : (k == D ? 1.f : 0.f);
-        Brow[id.j * SA + 16 + k] = k < D ? us[o] : (k == D ? 1.f : 0.f);
-      }
-      __syncthreads();
-
       TS(42);
-      // ---- P6: gradient wrt this transform's input
+      __syncthreads();                             // Y2
+      // ---- gradient wrt this transform's input
       for (int d = id.g; d < D; d += 4) {
         if (valid) {
-          const float g = gxs[id.j * pl.ZW + d];
+          const float g = gys[id.j * pl.ZW + d];
           if (t > 0) gz_dn[row * D + d] = g;
           else if (grad_theta) grad_theta[row * D + d] = g * zstats[D + d];
         }
@@ -658,6 +659,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   } else {
     // =========================== grad waves ==========================
     const int gw = wave - TR_NW;
+    int* cnt = (int*)(lds + tp.o_cnt);
+    int sync_target = 0;
     // weight-gradient accumulators owned by this wave (m-tile = wave) for the whole launch
     f4 acc0[2], accC[NB][2], acc1[NB][4], acc2[NB][4], accF[NCH][4], accLU[1];
   #pragma unroll
@@ -675,51 +678,77 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       for (int i = 0; i < 4; ++i) accF[c][i] = zero4;
     accLU[0] = zero4;
 
-
     const LaneId id0 = id;
     for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
       LaneId id = id0;
-      asm volatile("" : "+v"(id.j), "+v"(id.g));
-      // mirrors the row waves' barrier sequence exactly
-      __syncthreads();
+      asm volatile("" : "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
+      const int trow = 16 * gw + id.j;             // rows of the partner row wave
+      __syncthreads();                             // S0
       TS(0);
+      // ---- prologue: h_last of the partner's rows (stash, D-fragment order = MFMA B operand), its
+      // activation-tile rows, and the spline parameters of chunk 0
+      f4 hl[NSF_HT];
+      {
+        const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + gw) * SLOTS) * 1024 +
+                           id.lane;
+        ast_load(ast, cm ? 1 : 4 * NB, hl);
+      }
+      stage_D(Bt, SB, trow, id, hl, false);
+      if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;   // bias column
+      if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
+      f4 gh[NSF_HT];
   #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (c < nch) {
-          __syncthreads();
-          TS(6 + 4 * c);
-          dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, accF[c], 4, pl.ablate);
-          TS(7 + 4 * c);
-          __syncthreads();
+      for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
+      TS(1);
+      __syncthreads();                             // K0
+      TS(2);
+      // ---- chunk steps: d Wf and Wf^T g of chunk k-1, spline parameters of chunk k+1
+  #pragma unroll
+      for (int k = 0; k <= NCH; ++k) {
+        if (k <= nch) {
+          if (k >= 1) {
+            const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
+            dw_gemm<4>(lds + oa, Bt, SA, SB, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate);
+            if (!(pl.ablate & 2)) wft_chunk<PT>(lds, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
+          }
+          TS(3 + 2 * k);
+          if (k + 1 < nch) {
+            if (k >= 1) { sync_target += 4; grad_wave_sync(cnt, sync_target, id.lane); }   // all d Wf reads of that tile done
+            if (!(pl.ablate & 32))
+              final_layer_chunk_T<PT, KSH>(lds, lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, pl, tp, S, id,
+                                           hl, (k + 1) * DCHB);
+          }
+          if (k == nch) stage_D(lds + o_AX, SA, trow, id, gh, false);   // hand g_h to the partner row wave
+          TS(4 + 2 * k);
+          __syncthreads();                         // K_{k+1} / H
         }
       }
       if (cm) {
-        __syncthreads();
-        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[0], 4, pl.ablate);
-        __syncthreads();
-      }
-      if (!cm)
+        __syncthreads();                           // X1
+        dw_gemm<4>(lds + o_AY, Bt, SA, SB, 16 * gw, 0, id, acc1[0], 4, pl.ablate);
+      } else {
   #pragma unroll
-      for (int b = NB - 1; b >= 0; --b) {
-        __syncthreads();
-        dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, accC[b], ntc, pl.ablate);
-        __syncthreads();
-        __syncthreads();
-        TS(21 + 8 * b);
-        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
-        TS(22 + 8 * b);
-        __syncthreads();
-        __syncthreads();
-        TS(24 + 8 * b);
-        dw_gemm<4>(Ast, Bst, SA, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
-        TS(25 + 8 * b);
-        __syncthreads();
+        for (int b = NB - 1; b >= 0; --b) {
+          __syncthreads();                         // X1
+          TS(21 + 8 * b);
+          dw_gemm<4>(lds + o_AY, Bt, SA, SB, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
+          dw_gemm<2>(lds + o_AX, Bs, SA, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
+          TS(22 + 8 * b);
+          __syncthreads();                         // X2
+          __syncthreads();                         // X3
+          TS(24 + 8 * b);
+          dw_gemm<4>(lds + o_AY, Bt, SA, SB, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
+          TS(25 + 8 * b);
+          if (b > 0) __syncthreads();              // X4
+        }
       }
-      __syncthreads();
-      dw_gemm<2>(Ast, Bst, SA, 16 * gw, 0, id, acc0, nt0, pl.ablate);
-      __syncthreads();
-      __syncthreads();
-      if (gw < 2 && !cm) dw_gemm<1>(Ast, Bst, SA, 16 * gw, 16 * gw, id, accLU);
+      __syncthreads();                             // Y1
+      TS(41);
+      dw_gemm<2>(lds + o_AX, Bs, SA, SS, 16 * gw, 0, id, acc0, nt0, pl.ablate);
+      TS(42);
+      __syncthreads();                             // Y2
+      if (gw < 2 && !cm) dw_gemm<1>(lds + o_AY, Bt, SA, SB, 16 * gw, 16 * gw, id, accLU);
+      TS(43);
     }
 
     // ---- write this workgroup's partial gradients (natural parameter order)
