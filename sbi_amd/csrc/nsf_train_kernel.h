@@ -20,6 +20,12 @@
 #define TR_ROWS 64         // rows per tile
 #define TR_MAXCH 4         // spline chunks per transform the accumulators are sized for
 #define TR_GRID_MAX 256    // persistent workgroups (one per CU)
+#define TR_SA 68           // row stride of the gradient tiles A0/A1
+#define TR_SB 68           // row stride of the activation tile B (column-interleaved, see stage_DB)
+#define TR_SS 48           // row stride of the static conditioner-input tile Bs
+#ifndef TR_LA
+#define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
+#endif
 
 struct TrainPlan {
   int SA, SB, SS;          // row strides: gradient tiles A0/A1, activation tile B, static input tile Bs
@@ -33,11 +39,14 @@ struct TrainPlan {
   int lds_floats;
 };
 
-// Tile strides: the grad waves read K = row down a tile (row = 4s + g, column = c0 + j), so a stride
-// = 16 (mod 64) puts the four g groups in disjoint bank quadrants (conflict free); the row waves
-// write/read D fragments (row = j, column = 4r + g), for which stride 68 is the conflict-free one.
-// The activation tile B is read 4x as often as it is written => 80; the gradient tiles keep 68
-// (they double as the spline's parameter rows, read and written by the row waves).
+// Tile layouts.  The grad waves read K = row down a tile (row = 4s + g, column = c0 + j); the row
+// waves write/read D fragments (row = j, column = 16mt + 4r + g).
+//   A0/A1 (gradient side): row major, stride 68: conflict-free for the row waves (they also run the
+//     spline on these rows); the grad waves' one A read per K-step takes the 4-way conflict.
+//   B (activation side): column-interleaved, physical column = 4*(c & 15) + (c >> 4), stride 68: the four
+//     n-tiles' operands of a lane are adjacent => ONE ds_read_b128 per K-step (and one ds_write_b128 per
+//     register row when staging); LDS-fed MFMA loops are limited by the number of LDS instructions.
+//   Bs (static conditioner input): row major, stride 48 (= 48 mod 64: the g groups hit disjoint banks).
 static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   if (pl.D > 15 || pl.H > 63 || pl.NB > 2 || (pl.NB < 1 && !pl.ctx_mlp)) return SBI_AMD_E_UNSUPPORTED;
   const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
@@ -50,15 +59,15 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
     tp->nch[par] = (pl.shape[par].d_tr + tp->DCHB - 1) / tp->DCHB;
     if (tp->nch[par] > TR_MAXCH) return SBI_AMD_E_UNSUPPORTED;
   }
-  tp->SA = 68;
-  tp->SS = 48;   // [z_id ; context ; 1 ; 0...]: d W0 reads columns [0, 32), d Wc columns [d_id, d_id + 32)
+  tp->SA = TR_SA;
+  tp->SB = TR_SB;
+  tp->SS = TR_SS;   // [z_id ; context ; 1 ; 0...]: d W0 reads columns [0, 32), d Wc columns [d_id, d_id + 32)
   int w = 0;
   tp->w_zs = w; w += 16 * pl.ZW;
   tp->w_gys = w; w += 16 * pl.ZW;
   tp->w_gzs = w; w += 16 * pl.ZW;
   tp->w_total = (w + 8 + 3) / 4 * 4;   // + slack: the 16-wide row reads run past a ZW-float row
-  for (int sb = 80; sb >= 68; sb -= 12) {
-    tp->SB = sb;
+  {
     int o = pl.lds_w_floats;
     tp->o_A0 = o; o += TR_ROWS * tp->SA;
     tp->o_A1 = o; o += TR_ROWS * tp->SA;
@@ -67,7 +76,6 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
     tp->o_cnt = o; o += 4;
     tp->o_wave = o;
     tp->lds_floats = tp->o_wave + TR_NW * tp->w_total;
-    if (4ll * tp->lds_floats <= NSF_LDS_LIMIT_BYTES) break;
   }
   if (4ll * tp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
   int pmax = pl.shape[0].n_params > pl.shape[1].n_params ? pl.shape[0].n_params : pl.shape[1].n_params;
@@ -90,19 +98,59 @@ __device__ __forceinline__ void stage_D(float* __restrict__ st, int SA, int row,
     }
 }
 
+// column-interleaved activation tile: logical column c lives at 4*(c & 15) + (c >> 4)
+__device__ __forceinline__ int il_col(int c) { return 4 * (c & 15) + (c >> 4); }
+__device__ __forceinline__ void stage_DB(float* __restrict__ st, int SB, int row, const LaneId& id,
+                                         const f4 (&v)[NSF_HT], bool relu) {
+  static_assert(NSF_HT == 4, "one float4 per register row");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f4 w = {v[0][r], v[1][r], v[2][r], v[3][r]};
+    if (relu) w = {fmaxf(w[0], 0.f), fmaxf(w[1], 0.f), fmaxf(w[2], 0.f), fmaxf(w[3], 0.f)};
+    *(f4*)(st + row * SB + 4 * (4 * r + id.g)) = w;
+  }
+}
+
 // weight-gradient tile(s): acc[nt] += sum_{rows of the 64-row tile} A[row][acol0+i] * B[row][bcol0+16nt+j]
-template <int NT>
-__device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst, int SA, int SB,
+// Strides are compile time (every LDS read is base + immediate) and the operands of K-step s+2 are
+// requested before the MFMAs of step s issue, so the LDS latency hides under the matrix pipe.
+template <int NT, int SA, int SB, bool IL = false>
+__device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst,
                                         int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT,
                                         int abl = 0) {
   if (abl & 1) return;
-#pragma unroll 4
-  for (int s = 0; s < TR_ROWS / 4; ++s) {
-    const int row = 4 * s + id.g;
-    const float a = Ast[row * SA + acol0 + id.j];
+  constexpr int KS = TR_ROWS / 4, LA = TR_LA;
+  const float* ap = Ast + id.g * SA + acol0 + id.j;
+  // interleaved B (bcol0 a multiple of 16): the NT operands of this lane are adjacent floats
+  const float* bp = IL ? Bst + id.g * SB + 4 * id.j + (bcol0 >> 4) : Bst + id.g * SB + bcol0 + id.j;
+  float a[LA + 1], b[LA + 1][NT];
+  auto load_b = [&](int u, int s) {
+    if (IL && NT == 4) {
+      const f4 w = *(const f4*)(bp + 4 * s * SB);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[u][nt] = w[nt];
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[u][nt] = bp[4 * s * SB + (IL ? nt : 16 * nt)];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < LA; ++u) {
+    a[u] = ap[4 * u * SA];
+    load_b(u, u);
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + LA < KS) {
+      a[(s + LA) % (LA + 1)] = ap[4 * (s + LA) * SA];
+      load_b((s + LA) % (LA + 1), s + LA);
+    }
+    // pin the order: hipcc otherwise sinks every load next to its MFMA (load, wait, 2 MFMAs, load, ...)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      if (nt < nt_on) acc[nt] = MFMA16(a, Bst[row * SB + bcol0 + 16 * nt + id.j], acc[nt]);
+      if (nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -142,20 +190,23 @@ __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const
     base[mt] = lds + L.l_w + id.g * L.ldk + (ok[mt] ? f : 0);
   }
   const int kstride = 4 * L.ldk;
-  float a_cur[MT], a_nxt[MT];
+  constexpr int LA = TR_LA;
+  float a[LA + 1][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) a_cur[mt] = ok[mt] ? base[mt][0] : 0.f;
+  for (int u = 0; u < LA; ++u)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[u][mt] = u < KS ? base[mt][u * kstride] : 0.f;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    if (s + 1 < KS) {
+    if (s + LA < KS) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = ok[mt] ? base[mt][(s + 1) * kstride] : 0.f;
+      for (int mt = 0; mt < MT; ++mt) a[(s + LA) % (LA + 1)][mt] = base[mt][(s + LA) * kstride];
     }
     const float bv = gb[s >> 2][s & 3];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(a_cur[mt], bv, acc[mt]);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(ok[mt] ? a[s % (LA + 1)][mt] : 0.f, bv, acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -181,13 +232,29 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
         acc[sl][pt][r] = on ? lds[L.l_b + dd * 16 * PT + 16 * pt + 4 * r + id.g] : 0.f;
     }
   }
+  constexpr int LA = TR_LA;
+  float a[LA + 1][DCHB][PT];
 #pragma unroll
-  for (int s = 0; s < KSH; ++s) {
-    const float bv = h[s >> 2][s & 3];
+  for (int u = 0; u < LA; ++u)
 #pragma unroll
     for (int sl = 0; sl < DCHB; ++sl)
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(lds[ro[sl][pt] + 4 * s], bv, acc[sl][pt]);
+      for (int pt = 0; pt < PT; ++pt) a[u][sl][pt] = lds[ro[sl][pt] + 4 * u];
+#pragma unroll
+  for (int s = 0; s < KSH; ++s) {
+    if (s + LA < KSH) {
+#pragma unroll
+      for (int sl = 0; sl < DCHB; ++sl)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) a[(s + LA) % (LA + 1)][sl][pt] = lds[ro[sl][pt] + 4 * (s + LA)];
+    }
+    const float bv = h[s >> 2][s & 3];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < DCHB; ++sl)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(a[s % (LA + 1)][sl][pt], bv, acc[sl][pt]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int sl = 0; sl < DCHB; ++sl)
@@ -303,6 +370,7 @@ __device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const L
                                           const ShapeDesc& S, const LaneId& id, const float* __restrict__ Arow,
                                           int SA, int d0, f4 (&gh)[NSF_HT]) {
   constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
+  constexpr int KS = 4 * PT;
   bool ok[NSF_HT];
   int col[NSF_HT];
 #pragma unroll
@@ -311,20 +379,33 @@ __device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const L
     ok[mt] = f < LF.in;
     col[mt] = ok[mt] ? f : 0;
   }
+  const int kstride = 4 * LF.ldk;
 #pragma unroll
   for (int sl = 0; sl < DCHB; ++sl) {
     const int dd = d0 + sl;
     if (dd < S.d_tr) {
       const float* wrow = lds + LF.l_w + (dd * pl.P + id.g) * LF.ldk;
       const float* brow = Arow + id.j * SA + sl * 16 * PT + id.g;
+      constexpr int LA = TR_LA;
+      float a[LA + 1][NSF_HT], bb[LA + 1];
 #pragma unroll
-      for (int s = 0; s < 4 * PT; ++s) {
-        const float bv = brow[4 * s];
+      for (int u = 0; u < LA; ++u) {
+        bb[u] = brow[4 * u];
 #pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) {
-          const float a = wrow[4 * s * LF.ldk + col[mt]];
-          gh[mt] = MFMA16(ok[mt] ? a : 0.f, bv, gh[mt]);
+        for (int mt = 0; mt < NSF_HT; ++mt) a[u][mt] = wrow[u * kstride + col[mt]];
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + LA < KS) {
+          bb[(s + LA) % (LA + 1)] = brow[4 * (s + LA)];
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt) a[(s + LA) % (LA + 1)][mt] = wrow[(s + LA) * kstride + col[mt]];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt)
+          gh[mt] = MFMA16(ok[mt] ? a[s % (LA + 1)][mt] : 0.f, bb[s % (LA + 1)], gh[mt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -381,7 +462,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   constexpr int SLOTS = NSF_AST_SLOTS(NBT);
   const int par = cm ? 0 : (t & 1);
   const ShapeDesc& S = pl.shape[par];
-  const int D = pl.D, C = pl.C, SA = tp.SA, SB = tp.SB, SS = tp.SS;
+  const int D = pl.D, C = pl.C;
+  constexpr int SA = TR_SA, SB = TR_SB, SS = TR_SS;
   const bool is_last = (t == pl.T - 1);
   float* Bt = lds + tp.o_B;
   float* Bs = lds + tp.o_Bs;
@@ -548,8 +630,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #pragma unroll
           for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[1][mt][r] > 0.f ? gh[mt][r] : 0.f;
         stage_D(lds + o_AY, SA, trow, id, ga, false);
-        stage_D(Bt, SB, trow, id, hpre[0], true);
-        if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;
+        stage_DB(Bt, SB, trow, id, hpre[0], true);
+        if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
         __syncthreads();                           // X1
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
@@ -576,8 +658,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
             stage_D(lds + o_AY, SA, trow, id, ga, false);
             stage_D(lds + o_AX, SA, trow, id, gc, false);
           }
-          stage_D(Bt, SB, trow, id, bt1, true);
-          if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;      // bias column
+          stage_DB(Bt, SB, trow, id, bt1, true);
+          if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;      // bias column
           ast_load(ast, 4 * b, hpre[0]);                  // h_b: needed two phases from now
           if (b > 0) {   // next (earlier) block's t2 / gate: fetch under this block's GEMM phases
             ast_load(ast, 2 + 4 * (b - 1), bt2);
@@ -598,8 +680,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           __syncthreads();                         // X2: d W2 / d Wc done, tiles free
           TS(23 + 8 * b);
           stage_D(lds + o_AY, SA, trow, id, ga, false);
-          stage_D(Bt, SB, trow, id, hpre[0], true);
-          if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;
+          stage_DB(Bt, SB, trow, id, hpre[0], true);
+          if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
           __syncthreads();                         // X3: (g_t1, relu h_b) published
           TS(24 + 8 * b);
 #pragma unroll
@@ -639,8 +721,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           const int o = id.j * pl.ZW + k;
           Ay[k] = k < D ? gus_r[ii] : (k == D ? gld : 0.f);
           Ay[16 + k] = k < D ? gzs[o] : 0.f;
-          Bt[trow * SB + k] = k < D ? zs[o] : (k == D ? 1.f : 0.f);
-          Bt[trow * SB + 16 + k] = k < D ? us_r[ii] : (k == D ? 1.f : 0.f);
+          Bt[trow * SB + il_col(k)] = k < D ? zs[o] : (k == D ? 1.f : 0.f);
+          Bt[trow * SB + il_col(16 + k)] = k < D ? us_r[ii] : (k == D ? 1.f : 0.f);
         }
       }
       TS(42);
@@ -693,8 +775,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
                            id.lane;
         ast_load(ast, cm ? 1 : 4 * NB, hl);
       }
-      stage_D(Bt, SB, trow, id, hl, false);
-      if (id.g == 0) Bt[trow * SB + pl.H] = 1.f;   // bias column
+      stage_DB(Bt, SB, trow, id, hl, false);
+      if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
       if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
       f4 gh[NSF_HT];
   #pragma unroll
@@ -708,12 +790,14 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         if (k <= nch) {
           if (k >= 1) {
             const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
-            dw_gemm<4>(lds + oa, Bt, SA, SB, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate);
+            dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate);
+            TS(13 + k);
             if (!(pl.ablate & 2)) wft_chunk<PT>(lds, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
           }
           TS(3 + 2 * k);
           if (k + 1 < nch) {
             if (k >= 1) { sync_target += 4; grad_wave_sync(cnt, sync_target, id.lane); }   // all d Wf reads of that tile done
+            TS(17 + k);
             if (!(pl.ablate & 32))
               final_layer_chunk_T<PT, KSH>(lds, lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, pl, tp, S, id,
                                            hl, (k + 1) * DCHB);
@@ -725,29 +809,29 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       if (cm) {
         __syncthreads();                           // X1
-        dw_gemm<4>(lds + o_AY, Bt, SA, SB, 16 * gw, 0, id, acc1[0], 4, pl.ablate);
+        dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, pl.ablate);
       } else {
   #pragma unroll
         for (int b = NB - 1; b >= 0; --b) {
           __syncthreads();                         // X1
           TS(21 + 8 * b);
-          dw_gemm<4>(lds + o_AY, Bt, SA, SB, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
-          dw_gemm<2>(lds + o_AX, Bs, SA, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
+          dw_gemm<2, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
           TS(22 + 8 * b);
           __syncthreads();                         // X2
           __syncthreads();                         // X3
           TS(24 + 8 * b);
-          dw_gemm<4>(lds + o_AY, Bt, SA, SB, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
           TS(25 + 8 * b);
           if (b > 0) __syncthreads();              // X4
         }
       }
       __syncthreads();                             // Y1
       TS(41);
-      dw_gemm<2>(lds + o_AX, Bs, SA, SS, 16 * gw, 0, id, acc0, nt0, pl.ablate);
+      dw_gemm<2, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       TS(42);
       __syncthreads();                             // Y2
-      if (gw < 2 && !cm) dw_gemm<1>(lds + o_AY, Bt, SA, SB, 16 * gw, 16 * gw, id, accLU);
+      if (gw < 2 && !cm) dw_gemm<1, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 16 * gw, id, accLU);
       TS(43);
     }
 
