@@ -23,6 +23,9 @@
 #define TR_SA 68           // row stride of the gradient tiles A0/A1
 #define TR_SB 68           // row stride of the activation tile B (column-interleaved, see stage_DB)
 #define TR_SS 48           // row stride of the static conditioner-input tile Bs
+#ifndef TR_PF_HL
+#define TR_PF_HL 1          // request the next tile's h_last during this tile's last two phases
+#endif
 #ifndef TR_LA
 #define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
 #endif
@@ -175,8 +178,8 @@ __device__ __forceinline__ void grad_wave_sync(int* cnt, int target, int lane) {
 
 // row-wise backward through a linear layer: acc[mt] += sum_k W[k][feat(mt)] * g[k], g = D fragments.
 // The image keeps rows [out, 4*KS) zero (nsf_plan.cpp: rows_alloc), so K-steps past `out` need no
-// predicate; lanes that supply an A row for an in-feature slot >= in load a neighbouring (finite)
-// weight and replace it by zero with one v_cndmask.
+// predicate; lanes that supply an A row for an in-feature slot >= in load column 0 instead (finite) and
+// the corresponding output slots are cleared after the loop.
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
                                             const f4 (&gb)[NSF_HT], f4 (&acc)[MT], int abl = 0) {
@@ -205,9 +208,15 @@ __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const
     const float bv = gb[s >> 2][s & 3];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(ok[mt] ? a[s % (LA + 1)][mt] : 0.f, bv, acc[mt]);
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(a[s % (LA + 1)][mt], bv, acc[mt]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // in-feature slots >= in accumulated a (finite) neighbouring weight column: clear them on the way out
+  // (16 selects per call instead of one select + hazard nop in front of every MFMA)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[mt][r] = (16 * mt + 4 * r + id.g < L.in) ? acc[mt][r] : 0.f;
 }
 
 // final_layer output for the backward chunk -> this wave's rows of the shared A tile
@@ -363,8 +372,8 @@ __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int pl
 
 // g_h += Wf[rows of the chunk's dims]^T g_p for this wave's 16 rows (B operand = the g_p this wave
 // just wrote into the shared A tile).  Select-free like gemm_T_breg: the padding K slots (p >= P)
-// carry exact-zero g_p, so whatever finite weight they meet is harmless; lanes supplying an A row
-// for an in-feature >= H substitute 0.
+// carry exact-zero g_p, so whatever finite weight they meet is harmless; output slots of in-features
+// >= H are cleared after the loop.
 template <int PT>
 __device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const LinDesc& LF, const NsfPlan& pl,
                                           const ShapeDesc& S, const LaneId& id, const float* __restrict__ Arow,
@@ -403,12 +412,15 @@ __device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const L
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-          gh[mt] = MFMA16(ok[mt] ? a[s % (LA + 1)][mt] : 0.f, bb[s % (LA + 1)], gh[mt]);
+        for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = MFMA16(a[s % (LA + 1)][mt], bb[s % (LA + 1)], gh[mt]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gh[mt][r] = (16 * mt + 4 * r + id.g < LF.in) ? gh[mt][r] : 0.f;
 }
 
 // partial-gradient write-out of one weight tile (lane (g,j), reg r: out = out0+4g+r, in = 16nt+j)
@@ -494,6 +506,28 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     // uninitialised LDS (NaN x 0 = NaN)
     for (int i = id.lane; i < tp.w_total; i += 64) sc[i] = 0.f;
     const LaneId id0 = id;
+    // state, context, upstream gradient and row weight of the NEXT tile are requested a whole block phase
+    // ahead (clamped addresses instead of predicated loads), so the tile prologue never waits on HBM
+    float zv[4], gv[4], xv[8], wv;
+    auto fetch_inputs = [&](int tile_, const LaneId& id) {
+      const long long row_ = (long long)tile_ * TR_ROWS + arow0 + id.j;
+      const long long rs = row_ < n ? row_ : 0;
+      const long long xr = (x_rows == n) ? rs : (x_rows == 1 ? 0 : rs % x_rows);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d = id.g + 4 * u;
+        const int dc = d < D ? d : 0;
+        zv[u] = z_in[rs * D + dc];
+        gv[u] = gz_up[rs * D + dc];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = id.g + 4 * u - S.d_id;
+        xv[u] = x[xr * C + ((c >= 0 && c < C) ? c : 0)];
+      }
+      wv = row_w ? row_w[rs] : uni_w;
+    };
+    fetch_inputs(blockIdx.x, id0);
     for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
       // Re-materialise the lane coordinates per tile: otherwise LICM hoists every
       // lane-dependent LDS address of the body out of the persistent loop and the
@@ -502,29 +536,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       asm volatile("" : "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
       const long long row = (long long)tile * TR_ROWS + arow0 + id.j;
       const bool valid = row < n;
-      const float wn = valid ? (row_w ? row_w[row] : uni_w) : 0.f;
+      const float wn = valid ? wv : 0.f;
       const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
       const int trow = arow0 + id.j;
       __syncthreads();                             // S0: weights staged / previous tile fully consumed
       TS(0);
-      // ---- P0: load state, context, upstream gradient.  All loads are issued before the first
-      // use (clamped addresses instead of predicated loads), so one HBM round trip covers them.
+      // ---- P0: state, context, upstream gradient (prefetched) -> LDS
       {
-        const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
-        const long long rs = valid ? row : 0;
-        float zv[4], gv[4], xv[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int d = id.g + 4 * u;
-          const int dc = d < D ? d : 0;
-          zv[u] = z_in[rs * D + dc];
-          gv[u] = gz_up[rs * D + dc];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int c = id.g + 4 * u - S.d_id;
-          xv[u] = x[(valid ? xr : 0) * C + ((c >= 0 && c < C) ? c : 0)];
-        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int d = id.g + 4 * u;
@@ -621,6 +639,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       f4 gh[NSF_HT];
       load_D(lds + o_AX, SA, trow, id, gh);
       wave_lds_fence();
+      {   // next tile's inputs (the last tile re-reads itself: harmless)
+        const int nxt = tile + (int)gridDim.x;
+        fetch_inputs(nxt < tp.ntiles ? nxt : tile, id);
+      }
 
       if (cm) {
         // ---- ctx_mlp: h2 = relu(W_h h1 + b_h): one hidden layer to walk back through
@@ -761,20 +783,27 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     accLU[0] = zero4;
 
     const LaneId id0 = id;
+    f4 hl[NSF_HT];
+    auto fetch_hl = [&](int tile_) {
+      const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile_ * TR_NW + gw) * SLOTS) * 1024 +
+                         id0.lane;
+      ast_load(ast, cm ? 1 : 4 * NB, hl);
+    };
+#if TR_PF_HL
+    fetch_hl(blockIdx.x);
+#endif
     for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
       LaneId id = id0;
       asm volatile("" : "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
       const int trow = 16 * gw + id.j;             // rows of the partner row wave
+      const int tile_nxt = tile + (int)gridDim.x < tp.ntiles ? tile + (int)gridDim.x : tile;
       __syncthreads();                             // S0
       TS(0);
-      // ---- prologue: h_last of the partner's rows (stash, D-fragment order = MFMA B operand), its
-      // activation-tile rows, and the spline parameters of chunk 0
-      f4 hl[NSF_HT];
-      {
-        const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + gw) * SLOTS) * 1024 +
-                           id.lane;
-        ast_load(ast, cm ? 1 : 4 * NB, hl);
-      }
+      // ---- prologue: h_last of the partner's rows (stash, D-fragment order = MFMA B operand; requested
+      // during the previous tile), its activation-tile rows, and the spline parameters of chunk 0
+#if !TR_PF_HL
+      fetch_hl(tile);
+#endif
       stage_DB(Bt, SB, trow, id, hl, false);
       if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
       if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
@@ -828,6 +857,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       __syncthreads();                             // Y1
       TS(41);
+#if TR_PF_HL
+      fetch_hl(tile_nxt);   // next tile's h_last: lands under this tile's last two phases
+#endif
       dw_gemm<2, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       TS(42);
       __syncthreads();                             // Y2
