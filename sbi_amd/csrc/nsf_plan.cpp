@@ -98,6 +98,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     if (!ctx_mlp) g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias
     s->n_params = g;
     { const int lus = D <= 16 ? 16 : D;   // dense U, L padded to 16 x 16 for D <= 16
+      l = round_up(l, 4);   // 16-byte aligned: the backward kernel reads matrix rows as float4
       s->l_U = l; l += lus * lus;
       s->l_L = l; l += lus * lus; }
     s->l_lub = l; l += D + 1;   // bias, then sum_i log U_ii

@@ -33,6 +33,7 @@
 struct TrainPlan {
   int SA, SB, SS;          // row strides: gradient tiles A0/A1, activation tile B, static input tile Bs
   int o_A0, o_A1, o_B, o_Bs, o_cnt;   // LDS float offsets ([64][stride] tiles; grad-wave sync counter)
+  int o_xs;                // [32] x mean, [32] 1 / x std (context z-scoring constants)
   int o_wave, w_total;     // per-row-wave scratch base / size
   int w_zs, w_gys, w_gzs;  // 16 x ZW each: state (z -> y in place), gradient (g_y -> g_x in place), upstream g_z
   int DCHB, PTW;           // spline dims per chunk, floats per dim slot (16*PT)
@@ -77,6 +78,7 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
     tp->o_B = o; o += TR_ROWS * tp->SB;
     tp->o_Bs = o; o += TR_ROWS * tp->SS;
     tp->o_cnt = o; o += 4;
+    tp->o_xs = o; o += 64;
     tp->o_wave = o;
     tp->lds_floats = tp->o_wave + TR_NW * tp->w_total;
   }
@@ -164,6 +166,32 @@ __device__ __forceinline__ void load_D(const float* __restrict__ st, int SA, int
   for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[mt][r] = st[row * SA + 16 * mt + 4 * r + id.g];
+}
+
+// 16 x 16 mat-vec with CONTIGUOUS outputs per lane group: out[ii] = sum_k M(4g + ii, k) v[k]
+// (TRANSPOSED: M(i,k) = m[k][i], a float4 per k; else M(i,k) = m[i][k], four float4 per output).
+// m is zero padded to 16 x 16 and 16-byte aligned (nsf_plan.cpp).
+template <bool TRANSPOSED>
+__device__ __forceinline__ void dense_mv16c(const float* __restrict__ m, const float (&v)[16], int g, float (&out)[4]) {
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) out[ii] = 0.f;
+  if (TRANSPOSED) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const f4 w = *(const f4*)(m + k * 16 + 4 * g);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) out[ii] = fmaf(w[ii], v[k], out[ii]);
+    }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const f4 w = *(const f4*)(m + (4 * g + ii) * 16 + 4 * k4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[ii] = fmaf(w[u], v[4 * k4 + u], out[ii]);
+      }
+  }
 }
 
 // Rendezvous of the four grad waves only (the row waves are busy in their own phase): LDS counter,
@@ -484,6 +512,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 
   stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, blockDim.x);
   if (tid == 0) *(int*)(lds + tp.o_cnt) = 0;
+  if (tid < 32) {
+    lds[tp.o_xs + tid] = tid < C ? x_mean[tid] : 0.f;
+    lds[tp.o_xs + 32 + tid] = tid < C ? 1.f / x_std[tid] : 1.f;
+  }
+  const float* xs = lds + tp.o_xs;
 
   const LinDesc& L0 = S.lin[0];
   const LinDesc& LF = S.lin[S.fin];
@@ -553,38 +586,45 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           }
         }
         wave_lds_fence();
-        // conditioner-input row [z_id ; standardized context ; 1 ; 0 ...] -> static tile Bs
+        TS(50);
+        // conditioner-input row [z_id ; standardized context ; 1 ; 0 ...] -> static tile Bs (branch-free:
+        // clamped reads + selects).  The context is x * (1/std): within 1 ulp of the forward kernel's
+        // (x - mean) / std; it only feeds the B operand of d W0 / d Wc.
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const int k = id.g + 4 * u;
-          float v = 0.f;
-          if (u < 8) {
-            const int c = k - S.d_id;
-            if (k < S.d_id) v = zs[id.j * pl.ZW + 2 * k + (1 - par)];
-            else if (c < C) v = ((valid ? xv[u] : 0.f) - x_mean[c]) / x_std[c];
-            else if (k == S.in0) v = 1.f;
-          }
+          const int c = k - S.d_id;
+          const int cc = (c >= 0 && c < C) ? c : 0;
+          const int zd = 2 * k + (1 - par);
+          const float zid = zs[id.j * pl.ZW + (zd < D ? zd : 0)];
+          const float ctx = ((valid ? xv[u] : 0.f) - xs[cc]) * xs[32 + cc];
+          float v = (k == S.in0) ? 1.f : 0.f;
+          v = (c >= 0 && c < C) ? ctx : v;
+          v = (k < S.d_id) ? zid : v;
           Bs[trow * SS + k] = v;
         }
+#pragma unroll
+        for (int u = 8; u < 12; ++u) Bs[trow * SS + id.g + 4 * u] = 0.f;
       }
+      TS(51);
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T g_z, g_y = U^T g_u
-      float gus_r[4] = {0.f, 0.f, 0.f, 0.f};     // g_u of dims g + 4 ii, kept for the LU parameter gradients
+      float gus_r[4] = {0.f, 0.f, 0.f, 0.f};     // g_u of dims 4 g + ii, kept for the LU parameter gradients
       if (cm) {   // no LULinear for theta-dim 1: the transform output IS the layer output
         for (int k = id.g; k < D; k += 4) gys[id.j * pl.ZW + k] = gzs[id.j * pl.ZW + k];
       } else if (!(pl.ablate & 64)) {
         float v[16], o[4];
         row_to_regs16(gzs + id.j * pl.ZW, D, v);
-        dense_mv16<true>(lds + S.l_L, D, v, id.g, gus_r);
+        dense_mv16c<true>(lds + S.l_L, v, id.g, gus_r);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
-          if (id.g + 4 * ii < D) gys[id.j * pl.ZW + id.g + 4 * ii] = gus_r[ii];
+          if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = gus_r[ii];
         wave_lds_fence();
         row_to_regs16(gys + id.j * pl.ZW, D, v);
-        dense_mv16<true>(lds + S.l_U, D, v, id.g, o);
+        dense_mv16c<true>(lds + S.l_U, v, id.g, o);
         wave_lds_fence();
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
-          if (id.g + 4 * ii < D) gys[id.j * pl.ZW + id.g + 4 * ii] = o[ii];   // identity dims pass through
+          if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = o[ii];   // identity dims pass through
       }
       wave_lds_fence();
       const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + wave) * SLOTS) * 1024 +
@@ -631,7 +671,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       if (!cm && !(pl.ablate & 64)) {
         float v[16];
         row_to_regs16(zs + id.j * pl.ZW, D, v);
-        dense_mv16<false>(lds + S.l_U, D, v, id.g, us_r);
+        dense_mv16c<false>(lds + S.l_U, v, id.g, us_r);
       }
       TS(8);
       __syncthreads();                             // H: g_h = Wf^T g_p of this wave's rows is in AX
@@ -739,7 +779,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         float* Ay = lds + o_AY + trow * SA;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
-          const int k = id.g + 4 * ii;
+          const int k = 4 * id.g + ii;
           const int o = id.j * pl.ZW + k;
           Ay[k] = k < D ? gus_r[ii] : (k == D ? gld : 0.f);
           Ay[16 + k] = k < D ? gzs[o] : 0.f;
