@@ -87,6 +87,35 @@ __device__ __forceinline__ void pack_lu(float* __restrict__ img, const float* __
     img[S.l_U + idx] = u;
     img[S.l_L + idx] = l;
   }
+  // explicit inverses for the sampling direction (D <= 16): one thread per column, substitution in
+  // double, so the inverse pass is two dense mat-vecs instead of a serial per-row triangular solve
+  if (S.l_Ui >= 0 && tid < 16) {
+    const int c = tid;
+    auto Lm = [&](int i, int k) -> double { return (double)lower[i * (i - 1) / 2 + k]; };                 // k < i
+    auto Um = [&](int i, int k) -> double {                                                                 // k >= i
+      return k == i ? (double)(softplus_f(udiag[i]) + eps) : (double)upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
+    };
+    double xl[16], xu[16];
+    for (int i = 0; i < 16; ++i) { xl[i] = 0.0; xu[i] = 0.0; }
+    if (c < D) {
+      xl[c] = 1.0;
+      for (int i = c + 1; i < D; ++i) {
+        double a = 0.0;
+        for (int k = c; k < i; ++k) a -= Lm(i, k) * xl[k];
+        xl[i] = a;
+      }
+      xu[c] = 1.0 / Um(c, c);
+      for (int i = c - 1; i >= 0; --i) {
+        double a = 0.0;
+        for (int k = i + 1; k <= c; ++k) a -= Um(i, k) * xu[k];
+        xu[i] = a / Um(i, i);
+      }
+    }
+    for (int i = 0; i < 16; ++i) {
+      img[S.l_Li + i * 16 + c] = (float)xl[i];
+      img[S.l_Ui + i * 16 + c] = (float)xu[i];
+    }
+  }
   for (int idx = tid; idx < D; idx += nthreads) img[S.l_lub + idx] = bias[idx];
   if (tid == 0) {   // logabsdet of the LULinear = sum_i log(softplus(u_i) + eps)
     float a = 0.f;
@@ -625,6 +654,23 @@ __device__ __forceinline__ void lu_inverse(const float* __restrict__ lds, const 
                                            const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
   const int D = pl.D;
   const int LUS = D <= 16 ? 16 : D;
+  if (S.l_Ui >= 0) {   // D <= 16: z = U^-1 (L^-1 (y - b)) with the inverses the pack kernel prepared
+    float v[16], o[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = zs[id.j * pl.ZW + k] - (k < D ? lds[S.l_lub + k] : 0.f);
+    dense_mv16<false>(lds + S.l_Li, D, v, id.g, o);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+      if (id.g + 4 * ii < D) us[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+    wave_lds_fence();
+    row_to_regs16(us + id.j * pl.ZW, D, v);
+    dense_mv16<false>(lds + S.l_Ui, D, v, id.g, o);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+      if (id.g + 4 * ii < D) zs[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+    wave_lds_fence();
+    return;
+  }
   if (id.g == 0) {
     float* z = zs + id.j * pl.ZW;
     float* u = us + id.j * pl.ZW;

@@ -37,6 +37,7 @@ struct ShapeDesc {   // one per mask parity (even / odd transform index)
   int fin;                    // index of the final layer in lin[]
   int g_lu;                   // LULinear block offset relative to the layer block
   int l_U, l_L, l_lub;        // LDS offsets of expanded U[D][D], L[D][D], bias[D]
+  int l_Ui, l_Li;             // explicit inverses U^-1, L^-1 (16 x 16, D <= 16 only; else -1)
   int n_params;               // floats in this layer block
   int lds_floats;             // size of the LDS image
 };
