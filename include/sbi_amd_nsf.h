@@ -109,6 +109,19 @@ int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params,
                              const float* row_weight, float uniform_weight, float* loss_out,
                              float* grad_out, float* grad_theta_out, float* workspace, void* stream);
 
+/* The same pass in two calls, for losses whose row weights depend on the log-probabilities themselves
+ * (the atomic proposal-posterior loss of multi-round NPE-C, npe_c.py:356-440: w = d loss / d log p needs the
+ * softmax over each row's atoms).  `train_forward` writes log p (n) and leaves the state / activation stash
+ * in `workspace`; `train_backward` consumes that stash: same cfg, x, n, x_rows, packed image, stream order.
+ * grad_out (P, OVERWRITTEN) = d( sum_n w_n * (-log p_n) ) / d params. */
+int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
+                              const float* theta, const float* x, int64_t n, int64_t x_rows,
+                              float* logp_out, float* workspace, void* stream);
+int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
+                               const float* zstats, const float* x, int64_t n, int64_t x_rows,
+                               const float* row_weight, float uniform_weight, float* grad_out,
+                               float* grad_theta_out, float* workspace, void* stream);
+
 /* Fused global-norm clip + Adam on the flat buffer: replaces
  * clip_grad_norm_(max_norm) + torch.optim.Adam.step (trainers/base.py:1181-1187,
  * :1097).  `step` is the 1-based step count; max_norm <= 0 disables clipping.

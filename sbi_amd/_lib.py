@@ -57,6 +57,16 @@ _SIGNATURES = {
         [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "sbi_amd_nsf_train_forward": (
+        c_int,
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "sbi_amd_nsf_train_backward": (
+        c_int,
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
+         c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "sbi_amd_adam_clip_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,

@@ -102,12 +102,37 @@ extern template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, int, const
                               const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
                               long long*, hipStream_t);
 
-extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
-                                        const float* zstats, const float* theta, const float* x, int64_t n,
-                                        int64_t x_rows, const float* row_weight, float uniform_weight,
-                                        float* loss_out, float* grad_out, float* grad_theta_out, float* workspace,
-                                        void* stream) {
-  if (!cfg || !params || !packed || !zstats || !theta || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
+// forward half of the training pass: log p of every row + the per-transform state / activation stash
+extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
+                                         const float* theta, const float* x, int64_t n, int64_t x_rows,
+                                         float* logp_out, float* workspace, void* stream) {
+  if (!cfg || !packed || !zstats || !theta || !x || !workspace || n < 1 || x_rows < 1) return SBI_AMD_E_BADARG;
+  NsfPlan pl;
+  int rc = nsf_build_plan(cfg, TR_NW, &pl);
+  if (rc) return rc;
+  TrainPlan tp;
+  rc = build_train_plan(pl, n, &tp);
+  if (rc) return rc;
+  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
+  ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
+  rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, workspace + o_logp, workspace + o_noise,
+                          workspace + o_stash, workspace + o_ast, stream);
+  if (rc) return rc;
+  if (logp_out) {
+    hipError_t e = hipMemcpyAsync(logp_out, workspace + o_logp, sizeof(float) * n, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// backward half: consumes the stash the preceding sbi_amd_nsf_train_forward left in `workspace`
+// (same cfg, n, x, x_rows, packed image and stream order); grad_out = d( sum_n w_n * (-log p_n) ) / d params
+extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
+                                          const float* zstats, const float* x, int64_t n, int64_t x_rows,
+                                          const float* row_weight, float uniform_weight, float* grad_out,
+                                          float* grad_theta_out, float* workspace, void* stream) {
+  if (!cfg || !params || !packed || !zstats || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
     return SBI_AMD_E_BADARG;
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, TR_NW, &pl);
@@ -121,17 +146,9 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
   float* astash = workspace + o_ast;
   float* stash = workspace + o_stash;
   float* noise = workspace + o_noise;
-  float* logp = workspace + o_logp;
   float* gz[2] = {workspace + o_gza, workspace + o_gzb};
   float* partial = workspace + o_part;
   long long* dbg = (long long*)(workspace + ws_total - 2048);
-
-  rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, logp, noise, stash, astash, stream);
-  if (rc) return rc;
-  if (loss_out) {
-    hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logp, loss_out,
-                       (long long)n);
-  }
   for (int t = pl.T - 1; t >= 0; --t) {
     const float* up = (t == pl.T - 1) ? noise : gz[(t + 1) & 1];
     float* dn = gz[t & 1];
@@ -149,4 +166,27 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
   hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64 * RED_GROUPS), 0, st, pl, tp, params,
                      partial, grad_out);
   return (int)hipGetLastError();
+}
+
+// one-call form: forward + backward with weights known up front (plain NPE loss)
+extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
+                                        const float* zstats, const float* theta, const float* x, int64_t n,
+                                        int64_t x_rows, const float* row_weight, float uniform_weight,
+                                        float* loss_out, float* grad_out, float* grad_theta_out, float* workspace,
+                                        void* stream) {
+  if (!cfg || !params || !packed || !zstats || !theta || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
+    return SBI_AMD_E_BADARG;
+  int rc = sbi_amd_nsf_train_forward(cfg, packed, zstats, theta, x, n, x_rows, nullptr, workspace, stream);
+  if (rc) return rc;
+  if (loss_out) {
+    NsfPlan pl;
+    TrainPlan tp;
+    if ((rc = nsf_build_plan(cfg, TR_NW, &pl)) || (rc = build_train_plan(pl, n, &tp))) return rc;
+    int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
+    ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
+    hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       workspace + o_logp, loss_out, (long long)n);
+  }
+  return sbi_amd_nsf_train_backward(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
+                                    grad_theta_out, workspace, stream);
 }

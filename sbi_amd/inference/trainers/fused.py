@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 from sbi_amd import _lib
-from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, loss_fwd_bwd
+from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, loss_fwd_bwd, train_backward, train_forward
 
 
 class FusedTrainStep:
@@ -76,6 +76,45 @@ class FusedTrainStep:
         losses, _ = loss_fwd_bwd(self.net, theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
         if self.distributed:
             self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        return losses
+
+    @torch.no_grad()
+    def atomic_loss_and_grad(self, theta: Tensor, x: Tensor, masks: Tensor, prior, num_atoms: int,
+                             use_combined_loss: bool = False, global_batch: Optional[int] = None,
+                             choices: Optional[Tensor] = None) -> Tensor:
+        """Multi-round NPE-C: per-row atomic proposal-posterior loss (npe_c.py:356-440); leaves
+        d(sum loss / global_batch)/d(params) in ``self.grad``.  One forward pass over the A*B (theta, x)
+        pairs (atoms-major: row r is conditioned on x[r % B], the context is never repeated), the softmax
+        weights d loss / d log q on the device, one backward pass on the stash of that forward."""
+        from sbi_amd.inference.trainers.npe.atomic import build_atoms, clamp_num_atoms, sample_contrasting_indices
+
+        B = theta.shape[0]
+        A = clamp_num_atoms(num_atoms, B)
+        gb = global_batch if global_batch is not None else B * self.world
+        if choices is None:
+            choices = sample_contrasting_indices(B, A, theta.device)
+        flat = build_atoms(theta, choices).reshape(A * B, -1).contiguous()
+        ws = self._workspace(A * B)
+        lp = train_forward(self.net, flat, x, ws).reshape(A, B)
+        lprior = prior.log_prob(flat).reshape(A, B)
+        un = lp - lprior
+        lse = torch.logsumexp(un, dim=0)
+        lpp = un[0] - lse
+        w = -torch.exp(un - lse)          # d lpp_b / d log q[a, b] = delta_{a0} - softmax_a
+        w[0] += 1.0
+        if use_combined_loss:             # + masks * log q(theta_b | x_b): the same values as atom 0
+            m = masks.reshape(-1).to(lp.dtype)
+            lpp = m * lp[0] + lpp
+            w[0] += m
+        train_backward(self.net, x, A * B, (w / gb).reshape(-1).contiguous(), self.grad, ws)
+        if self.distributed:
+            self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        return -lpp
+
+    def atomic_step(self, theta: Tensor, x: Tensor, masks: Tensor, prior, num_atoms: int,
+                    use_combined_loss: bool = False, global_batch: Optional[int] = None) -> Tensor:
+        losses = self.atomic_loss_and_grad(theta, x, masks, prior, num_atoms, use_combined_loss, global_batch)
+        self.apply()
         return losses
 
     @torch.no_grad()

@@ -155,27 +155,78 @@ class PosteriorEstimatorTrainer:
     # ------------------------------------------------------------------ data
     def append_simulations(self, theta: Tensor, x: Tensor, proposal=None, exclude_invalid_x: Optional[bool] = None,
                            data_device: Optional[str] = None) -> "PosteriorEstimatorTrainer":
-        if proposal is not None and proposal is not self._prior:
-            raise NotImplementedError(
-                "Multi-round NPE (proposal-corrected atomic loss, npe_c.py:356-440) is a 'next' row of the "
-                "accelerated path; pass proposal=None for single-round NPE."
-            )
+        # round bookkeeping (npe_base.py:222-240): data sampled from the prior is round 0 (MLE loss); any
+        # other proposal opens a new round trained with the proposal-corrected atomic loss
+        if proposal is None or proposal is self._prior:
+            current_round = 0
+        elif not self._data_round_index:
+            current_round = 1
+        else:
+            current_round = max(self._data_round_index) + 1
         if exclude_invalid_x is None:
-            exclude_invalid_x = True
+            exclude_invalid_x = current_round == 0
         if data_device is None:
             data_device = self._device
         theta, x = validate_theta_and_x(theta, x, data_device=data_device, training_device=self._device)
         is_valid_x, num_nans, num_infs = handle_invalid_x(x, exclude_invalid_x=exclude_invalid_x)
-        warn_on_invalid_x(num_nans, num_infs, exclude_invalid_x)
+        if current_round > 0 and (num_nans + num_infs) > 0:
+            # the atomic loss normalises across the batch (sbiutils.py:553-578): invalid rows can neither stay
+            # nor be dropped silently
+            algorithm = f"Multiround {type(self).__name__}"
+            if not exclude_invalid_x:
+                raise ValueError(
+                    f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. {algorithm} does not allow "
+                    "invalid simulations. Replace the invalid values with an unreasonably low or high value."
+                )
+            logging.warning(
+                f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. These will be discarded from "
+                f"training due to `exclude_invalid_x=True`. Please be aware that this gives systematically wrong "
+                f"results for {algorithm} and is only recommended for expert users."
+            )
+        else:
+            warn_on_invalid_x(num_nans, num_infs, exclude_invalid_x)
         x, theta = x[is_valid_x], theta[is_valid_x]
-        self._data_round_index.append(0)
+        self._check_proposal(proposal)
+        self._data_round_index.append(current_round)
         self._theta_roundwise.append(theta)
         self._x_roundwise.append(x)
-        self._prior_masks.append(torch.zeros(theta.shape[0], 1, dtype=torch.bool))
+        # True where theta came from the prior (sbiutils.py:602-613)
+        self._prior_masks.append(torch.full((theta.shape[0], 1), current_round == 0, dtype=torch.bool))
         self._proposal_roundwise.append(proposal)
         if self._prior is None or isinstance(self._prior, ImproperEmpirical):
+            if proposal is not None:
+                raise ValueError(
+                    "You did not pass a prior at initialization, but now you passed a proposal. If you want to run "
+                    "multi-round NPE, you have to specify a prior (set the `.prior` argument or re-initialize the "
+                    "object with a prior distribution). If the samples you passed to `append_simulations()` were "
+                    "sampled from the prior, you can run single-round inference with "
+                    "`append_simulations(..., proposal=None)`."
+                )
             self._prior = ImproperEmpirical(self.get_simulations()[0].to(self._device))
         return self
+
+    def _check_proposal(self, proposal) -> None:
+        """npe_base.py:577-610."""
+        if proposal is None:
+            return
+        if hasattr(proposal, "default_x") and proposal.default_x is None:
+            raise ValueError(
+                "`proposal.default_x` is None, i.e. there is no x_o for training. Set it with "
+                "`posterior.set_default_x(x_o)`."
+            )
+        if (hasattr(proposal, "posterior_estimator") and self._neural_net is not None
+                and proposal.posterior_estimator is self._neural_net):
+            raise ValueError(
+                "The proposal's posterior_estimator is the same object as the trainer's neural network. This will "
+                "cause incorrect training because the proposal's weights will change during optimization. Use "
+                "`deepcopy(estimator)` when creating the proposal, or use `trainer.build_posterior()` which "
+                "handles this automatically."
+            )
+        if not hasattr(proposal, "posterior_estimator"):
+            warnings.warn(
+                "The proposal you passed is neither the prior nor a neural posterior: the atomic multi-round loss "
+                "will be used. If the parameters were sampled from the prior, pass proposal=None.", stacklevel=3,
+            )
 
     def get_simulations(self, starting_round: int = 0):
         th = torch.cat([t for t, r in zip(self._theta_roundwise, self._data_round_index) if r >= starting_round])
@@ -204,22 +255,39 @@ class PosteriorEstimatorTrainer:
         return t
 
     # ------------------------------------------------------------------ training
-    def train(self, training_batch_size: int = 200, learning_rate: float = 5e-4, validation_fraction: float = 0.1,
-              stop_after_epochs: int = 20, max_num_epochs: int = 2**31 - 1, clip_max_norm: Optional[float] = 5.0,
-              calibration_kernel: Optional[Callable] = None, resume_training: bool = False,
-              force_first_round_loss: bool = False, discard_prior_samples: bool = False,
+    def train(self, num_atoms: int = 10, training_batch_size: int = 200, learning_rate: float = 5e-4,
+              validation_fraction: float = 0.1, stop_after_epochs: int = 20, max_num_epochs: int = 2**31 - 1,
+              clip_max_norm: Optional[float] = 5.0, calibration_kernel: Optional[Callable] = None,
+              resume_training: bool = False, force_first_round_loss: bool = False,
+              discard_prior_samples: bool = False, use_combined_loss: bool = False,
               retrain_from_scratch: bool = False, show_train_summary: bool = False,
               dataloader_kwargs: Optional[dict] = None) -> ConditionalDensityEstimator:
         if len(self._data_round_index) == 0:
             raise RuntimeError("No simulations found. You must call .append_simulations() before calling .train().")
         if dataloader_kwargs:
             raise NotImplementedError("The device-resident loop has no DataLoader; dataloader_kwargs is unsupported.")
+        # npe_c.py:194-223 / npe_base.py:629-662
+        self._num_atoms = num_atoms
+        self._use_combined_loss = use_combined_loss
+        self._round = max(self._data_round_index)
+        if self._round == 0 and self._neural_net is not None and not (force_first_round_loss or resume_training):
+            raise ValueError(
+                "This neural network has already been trained. If you want to continue training without adding new "
+                "simulations, set resume_training=True. If you appended new simulations, you must either provide a "
+                "proposal in append_simulations(), or set force_first_round_loss=True for simulations drawn from "
+                "the prior. Warning: Setting force_first_round_loss=True with simulations not drawn from the prior "
+                "will produce the proposal posterior instead of the true posterior, which is typically more narrow."
+            )
+        atomic = self._round > 0 and not force_first_round_loss
+        if atomic:
+            print(f"Using {type(self).__name__} with atomic loss")
+        start_idx = int(discard_prior_samples and self._round > 0)
         cfg = TrainConfig(training_batch_size=training_batch_size, learning_rate=learning_rate,
                           validation_fraction=validation_fraction, stop_after_epochs=stop_after_epochs,
                           max_num_epochs=max_num_epochs, clip_max_norm=clip_max_norm,
                           resume_training=resume_training, retrain_from_scratch=retrain_from_scratch,
                           show_train_summary=show_train_summary)
-        theta, x, _ = self.get_simulations(0)
+        theta, x, prior_masks = self.get_simulations(start_idx)
         n = theta.shape[0]
         n_train = int((1 - cfg.validation_fraction) * n)
         n_val = n - n_train
@@ -246,6 +314,8 @@ class PosteriorEstimatorTrainer:
 
         theta_d = theta.to(self._device)
         x_d = x.to(self._device)
+        masks_d = prior_masks.to(self._device)
+        prior = self._prior
         train_idx = self.train_indices.to(self._device)
         val_idx = self.val_indices.to(self._device)
         rank, world = self._rank_world()
@@ -274,16 +344,29 @@ class PosteriorEstimatorTrainer:
             per = (idx.numel() + world - 1) // world
             return idx[rank * per : min((rank + 1) * per, idx.numel())]
 
+        from sbi_amd.inference.trainers.npe.atomic import log_prob_proposal_posterior_atomic
+
+        def net_losses(th: Tensor, xx: Tensor, mk: Tensor) -> Tensor:
+            """npe_base.py:542-575: MLE in the first round, proposal-corrected atomic loss afterwards."""
+            if not atomic:
+                return net.loss(th, xx)
+            return -log_prob_proposal_posterior_atomic(net, prior, th, xx, mk, self._num_atoms,
+                                                       self._use_combined_loss)
+
         def batch_losses(idx: Tensor, train: bool, global_batch: int) -> Tensor:
             th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)
+            mk = masks_d.index_select(0, idx)
             if fused:
                 if train:
+                    if atomic:
+                        return self._stepper.atomic_step(th, xx, mk, prior, self._num_atoms, self._use_combined_loss,
+                                                         global_batch=global_batch)
                     return self._stepper.step(th, xx, global_batch=global_batch)
                 with torch.no_grad():
-                    return net.loss(th, xx)
+                    return net_losses(th, xx, mk)
             if train:
                 self.optimizer.zero_grad()
-                losses = net.loss(th, xx)
+                losses = net_losses(th, xx, mk)
                 if not torch.isfinite(losses).all():
                     raise AssertionError("NaN/Inf present in NPE loss.")
                 if calibration_kernel is not None:
@@ -297,7 +380,7 @@ class PosteriorEstimatorTrainer:
                 self.optimizer.step()
                 return losses.detach()
             with torch.no_grad():
-                losses = net.loss(th, xx)
+                losses = net_losses(th, xx, mk)
                 return losses * calibration_kernel(xx) if calibration_kernel is not None else losses
 
         while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
@@ -411,7 +494,10 @@ class PosteriorEstimatorTrainer:
 
 
 class NPE_C(PosteriorEstimatorTrainer):
-    """Single-round NPE-C == maximum-likelihood NPE (npe_c.py:91-223 without the multi-round losses)."""
+    """NPE-C / APT (npe_c.py:91-440): maximum likelihood in the first round, the atomic proposal-posterior loss
+    in later rounds (``append_simulations(theta, x, proposal=posterior)``).  The closed-form MoG correction
+    (`_log_prob_proposal_posterior_mog`) applies to mixture-density estimators only and is not part of the
+    NSF path."""
 
 
 NPE = NPE_C   # sbi/inference/__init__.py:22

@@ -297,6 +297,51 @@ def loss_fwd_bwd(net: NSFNet, theta: Tensor, x: Tensor, row_weight: Optional[Ten
     return loss, gtheta
 
 
+def train_workspace(net: NSFNet, n: int, device, workspace: Optional[Tensor] = None) -> Tensor:
+    """A workspace tensor large enough for an n-row training pass (reuses `workspace` when it is)."""
+    lib = _lib.load()
+    need = lib.sbi_amd_nsf_train_workspace_floats(net.hyper.c_config(), n)
+    if need < 0:
+        _lib.check(int(need), "nsf_train_workspace_floats")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(int(need), 1), dtype=torch.float32, device=device)
+    return workspace
+
+
+def train_forward(net: NSFNet, theta: Tensor, x: Tensor, workspace: Tensor) -> Tensor:
+    """First half of the training pass: log p (n,) with the state / activation stash left in `workspace`.
+    `x` may have fewer rows than theta: row r is conditioned on x[r % x.shape[0]]."""
+    dev = _lib.require_device(theta, x, net.flat_params, net.zstats, workspace)
+    lib = _lib.load()
+    n = theta.shape[0]
+    logp = torch.empty(n, dtype=torch.float32, device=dev)
+    packed = packed_weights(net)
+    with torch.cuda.device(dev):
+        rc = lib.sbi_amd_nsf_train_forward(
+            net.hyper.c_config(), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
+            _lib.ptr(logp), _lib.ptr(workspace), _lib.current_stream(dev),
+        )
+    _lib.check(rc, "nsf_train_forward")
+    return logp
+
+
+def train_backward(net: NSFNet, x: Tensor, n: int, row_weight: Tensor, grad_out: Tensor, workspace: Tensor,
+                   want_grad_theta: bool = False) -> Optional[Tensor]:
+    """Second half: grad_out (P,) = d( sum_n w_n * (-log p_n) ) / d params from the stash `train_forward` left."""
+    dev = _lib.require_device(x, net.flat_params, net.zstats, grad_out, row_weight, workspace)
+    lib = _lib.load()
+    gtheta = torch.empty(n, net.hyper.D, dtype=torch.float32, device=dev) if want_grad_theta else None
+    packed = packed_weights(net)
+    with torch.cuda.device(dev):
+        rc = lib.sbi_amd_nsf_train_backward(
+            net.hyper.c_config(), _lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(x), n,
+            x.shape[0], _lib.ptr(row_weight), 0.0, _lib.ptr(grad_out), _lib.ptr(gtheta), _lib.ptr(workspace),
+            _lib.current_stream(dev),
+        )
+    _lib.check(rc, "nsf_train_backward")
+    return gtheta
+
+
 class _NSFLogProbFn(torch.autograd.Function):
     """Autograd bridge: forward = fused log_prob kernel; backward = fused
     recompute+backward kernel with row weights -dL/dlogp."""

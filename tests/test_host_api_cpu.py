@@ -147,8 +147,10 @@ def test_append_simulations_validation_and_invalid_rows():
     x[10, 1] = float("inf")
     inf.append_simulations(theta, x)
     assert inf.get_simulations()[0].shape[0] == 98
-    with pytest.raises(NotImplementedError):
-        inf.append_simulations(theta, x, proposal=object())
+    # a proposal without a prior at initialization (npe_base.py:283-294)
+    theta2, x2 = linear_gaussian_data(100, 2, 2)
+    with pytest.raises(ValueError, match="did not pass a prior"):
+        inf.append_simulations(theta2, x2, proposal=object())
 
 
 def test_training_loop_split_sizes_and_early_stopping():

@@ -1,0 +1,135 @@
+"""Multi-round NPE-C (atomic proposal-posterior loss) host logic on the CPU, with the oracle as estimator.
+Reference behaviour: sbi/inference/trainers/npe/npe_c.py:356-440, npe_base.py:188-299, :542-575, :629-662."""
+
+import warnings
+
+import pytest
+import torch
+
+from sbi_amd.inference import NPE
+from sbi_amd.inference.trainers.npe import atomic
+from tests.helpers import linear_gaussian_data
+from tests.oracle_adapter import OracleEstimator, oracle_build_fn
+
+
+@pytest.mark.parametrize("B,A", [(7, 2), (64, 10), (64, 64), (5000, 10), (3000, 33)])
+def test_contrasting_indices_distinct_and_exclude_own_row(B, A):
+    torch.manual_seed(0)
+    ch = atomic.sample_contrasting_indices(B, A, "cpu")
+    assert ch.shape == (B, A - 1) and ch.dtype == torch.int64
+    assert ch.min() >= 0 and ch.max() <= B - 1
+    assert not (ch == torch.arange(B)[:, None]).any()                    # never the row's own theta
+    assert all(len(set(r.tolist())) == A - 1 for r in ch[:: max(1, B // 50)])   # without replacement
+
+
+def test_contrasting_indices_large_batch_sampler_is_uniform():
+    """The O(B*A^2) sampler that replaces the (B, B) multinomial matrix beyond 2048 rows: every other row is
+    equally likely at every position (chi-square style bound on 16 coarse buckets)."""
+    torch.manual_seed(1)
+    B, A = 4096, 9
+    ch = atomic.sample_contrasting_indices(B, A, "cpu")
+    rel = (ch - torch.arange(B)[:, None]) % B                            # offset to the own row: uniform on 1..B-1
+    assert rel.min() >= 1
+    for pos in range(A - 1):
+        hist = torch.bincount(rel[:, pos] * 16 // B, minlength=16).float()
+        assert (hist - B / 16).abs().max() < 5 * (B / 16) ** 0.5
+
+
+def _reference_atomic(est, prior, theta, x, masks, num_atoms, choices, combined):
+    """npe_c.py:374-436 restated literally (row-major atoms, repeat_rows on x)."""
+    B = theta.shape[0]
+    repeated_x = x.repeat_interleave(num_atoms, dim=0)
+    contrasting = theta[choices]
+    atomic_theta = torch.cat((theta[:, None, :], contrasting), dim=1).reshape(B * num_atoms, -1)
+    lp_prior = prior.log_prob(atomic_theta).reshape(B, num_atoms)
+    lp_post = est.log_prob(atomic_theta.unsqueeze(0), repeated_x).reshape(B, num_atoms)
+    un = lp_post - lp_prior
+    out = un[:, 0] - torch.logsumexp(un, dim=-1)
+    if combined:
+        out = masks.reshape(-1) * est.log_prob(theta.unsqueeze(0), x).squeeze(0) + out
+    return out
+
+
+@pytest.mark.parametrize("combined", [False, True])
+def test_atomic_loss_matches_reference_formula(combined):
+    theta, x = linear_gaussian_data(40, 3, 3)
+    torch.manual_seed(3)
+    est = OracleEstimator(theta, x, hidden_features=16, num_transforms=2, num_bins=4)
+    prior = torch.distributions.MultivariateNormal(torch.zeros(3), 0.1 * torch.eye(3))
+    masks = (torch.arange(40) % 3 == 0)[:, None]
+    choices = atomic.sample_contrasting_indices(40, 6, "cpu")
+    got = atomic.log_prob_proposal_posterior_atomic(est, prior, theta, x, masks, 6, combined, choices=choices)
+    ref = _reference_atomic(est, prior, theta, x, masks, 6, choices, combined)
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+    # gradients too (what the training loop back-propagates)
+    g1 = torch.autograd.grad(-got.sum(), list(est.parameters()), retain_graph=True)
+    g2 = torch.autograd.grad(-ref.sum(), list(est.parameters()))
+    assert all(torch.allclose(a, b, atol=1e-5, rtol=1e-4) for a, b in zip(g1, g2))
+
+
+def test_num_atoms_is_clamped_to_batch():
+    with pytest.warns(UserWarning, match="clamped"):
+        assert atomic.clamp_num_atoms(10, 4) == 4
+    with pytest.warns(UserWarning, match="clamped"):
+        assert atomic.clamp_num_atoms(1, 8) == 2
+    assert atomic.clamp_num_atoms(10, 200) == 10
+
+
+def _two_round_setup(n=300, D=2):
+    theta, x = linear_gaussian_data(n, D, D)
+    prior = torch.distributions.MultivariateNormal(torch.zeros(D), 0.1 * torch.eye(D))
+    torch.manual_seed(4)
+    inf = NPE(prior=prior, density_estimator=oracle_build_fn(hidden_features=16, num_transforms=2, num_bins=4),
+              show_progress_bars=False)
+    return inf, prior, theta, x
+
+
+def test_round_bookkeeping_and_masks():
+    inf, prior, theta, x = _two_round_setup()
+    inf.append_simulations(theta, x)                           # from the prior: round 0, masks True
+    inf.append_simulations(theta, x, proposal=prior)           # passing the prior object itself stays round 0
+    assert inf._data_round_index == [0, 0]
+    assert inf.get_simulations()[2].all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inf.train(training_batch_size=100, max_num_epochs=1)
+    with pytest.raises(ValueError, match="already been trained"):
+        inf.train(training_batch_size=100, max_num_epochs=1)    # npe_base.py:644-659
+    posterior = inf.build_posterior()
+    with pytest.raises(ValueError, match="default_x"):
+        inf.append_simulations(theta, x, proposal=posterior)    # proposal needs an x_o
+    posterior.set_default_x(x[:1])
+    inf.append_simulations(theta[:100], x[:100], proposal=posterior)
+    assert inf._data_round_index == [0, 0, 1]
+    th, xx, mk = inf.get_simulations()
+    assert th.shape[0] == 700 and mk[:600].all() and not mk[600:].any()
+    assert inf.get_simulations(1)[0].shape[0] == 100            # discard_prior_samples view
+    bad = x[:100].clone()
+    bad[0, 0] = float("nan")
+    with pytest.raises(ValueError, match="does not allow invalid simulations"):
+        inf.append_simulations(theta[:100], bad, proposal=posterior)
+
+
+def test_two_round_training_uses_atomic_loss(capsys):
+    inf, prior, theta, x = _two_round_setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inf.append_simulations(theta, x).train(training_batch_size=100, max_num_epochs=2)
+        x_o = torch.zeros(1, 2)
+        posterior = inf.build_posterior().set_default_x(x_o)
+        theta2 = posterior.sample((200,), show_progress_bars=False)
+        x2 = theta2 + 0.1**0.5 * torch.randn_like(theta2)
+        before = [p.detach().clone() for p in inf._neural_net.parameters()]
+        est = inf.append_simulations(theta2, x2, proposal=posterior).train(
+            num_atoms=5, training_batch_size=50, max_num_epochs=2, use_combined_loss=True)
+    assert "atomic loss" in capsys.readouterr().out
+    assert inf._round == 1 and inf.train_indices.numel() == int(0.9 * 500)
+    s = inf.summary
+    assert len(s["epochs_trained"]) == 2 and all(map(lambda v: v == v and abs(v) < 1e6, s["training_loss"]))
+    assert any((a != b.detach()).any() for a, b in zip(before, est.parameters()))      # the net kept training
+    # discard_prior_samples: only the 200 proposal simulations are used
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inf.train(num_atoms=5, training_batch_size=50, max_num_epochs=1, discard_prior_samples=True,
+                  resume_training=False)
+    assert inf.train_indices.numel() == int(0.9 * 200)
