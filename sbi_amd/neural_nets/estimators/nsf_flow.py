@@ -343,24 +343,42 @@ def train_backward(net: NSFNet, x: Tensor, n: int, row_weight: Tensor, grad_out:
 
 
 class _NSFLogProbFn(torch.autograd.Function):
-    """Autograd bridge: forward = fused log_prob kernel; backward = fused
-    recompute+backward kernel with row weights -dL/dlogp."""
+    """Autograd bridge: forward = the training pass's forward half (log p + state / activation stash kept in a
+    workspace tensor on the graph), backward = the backward half with row weights -dL/dlogp on that stash --
+    so `loss.backward()` in sbi's own loop costs one forward and one backward, not two forwards."""
 
     @staticmethod
     def forward(ctx, theta: Tensor, x: Tensor, flat_params: Tensor, net: NSFNet):
-        logp, _ = _log_prob_call(net, theta, x, want_noise=False)
         ctx.net = net
-        ctx.save_for_backward(theta, x)
+        ctx.n = theta.shape[0]
+        ctx.packed_version = net.flat_params._version
+        lib = _lib.load()
+        if ctx.n == 0 or lib.sbi_amd_nsf_train_workspace_floats(net.hyper.c_config(), max(ctx.n, 1)) < 0:
+            # configurations the training kernels do not cover (e.g. hidden_features = 64) still evaluate;
+            # only an actual backward() through them reports the restriction
+            logp, _ = _log_prob_call(net, theta, x, want_noise=False)
+            ctx.stashed = False
+            ctx.save_for_backward(x, theta)
+            return logp
+        ws = train_workspace(net, ctx.n, theta.device)
+        logp = train_forward(net, theta, x, ws)
+        ctx.stashed = True
+        ctx.save_for_backward(x, ws)
         return logp
 
     @staticmethod
     def backward(ctx, grad_logp: Tensor):
-        theta, x = ctx.saved_tensors
+        x, ws = ctx.saved_tensors
         net: NSFNet = ctx.net
+        if net.flat_params._version != ctx.packed_version:
+            raise RuntimeError("NSF parameters were modified in place between log_prob() and backward().")
         gparams = torch.empty_like(net.flat_params)
         w = (-grad_logp).contiguous().to(torch.float32)
-        _, gtheta = loss_fwd_bwd(net, theta, x, w, 0.0, gparams, want_grad_theta=ctx.needs_input_grad[0])
+        if not ctx.stashed:   # ws holds theta here: the one-call form raises the configuration error
+            _, gtheta = loss_fwd_bwd(net, ws, x, w, 0.0, gparams, want_grad_theta=ctx.needs_input_grad[0])
+            return gtheta, None, (gparams if ctx.needs_input_grad[2] else None), None
         # kernel gradients are already weighted by w_n = -dL/dlogp_n
+        gtheta = train_backward(net, x, ctx.n, w, gparams, ws, want_grad_theta=ctx.needs_input_grad[0])
         return gtheta, None, (gparams if ctx.needs_input_grad[2] else None), None
 
 
