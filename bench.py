@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample"],
+    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample", "atomic"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--draws", type=int, default=1_000_000, help="posterior draws per step in the sample leg")
@@ -191,6 +191,30 @@ def main():
         wall, dev_ms = timed(sample_step, ssteps, min(args.warmup, 2), device, dist)
         results["sample"] = {"value": nd * world * ssteps / wall, "unit": "draws/s", "steps": ssteps,
                              "ms_per_step": wall / ssteps * 1e3, "roofline": roofline(F_EVAL, nd, ssteps, dev_ms)}
+    if args.mode == "atomic":
+        # one multi-round NPE-C step (atomic proposal-posterior loss, 10 atoms) on `--batch` pairs
+        from torch.distributions import Independent, Normal
+
+        from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+        prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
+        masks = torch.zeros(B, 1, dtype=torch.bool, device=device)
+        stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+        A = 10
+        wall, dev_ms = timed(lambda: stepper.atomic_step(theta, x, masks, prior, A), args.steps, args.warmup, device,
+                             dist)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "NPE-C atomic-loss train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
+                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"multi-round NPE-C step, {A} atoms, batch {B} per GPU = {A * B} log_prob "
+                                       f"rows forward + backward, theta-dim {D}", "parallelism": f"dp{world}"},
+                "roofline": roofline(F_TRAIN, A * B, args.steps, dev_ms)}))
+        if distributed:
+            dist.destroy_process_group()
+        return
     if args.mode in ("both", "train"):
         from sbi_amd.inference.trainers.fused import FusedTrainStep
 
