@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample", "atomic"],
+    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample", "atomic", "mcmc"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--draws", type=int, default=1_000_000, help="posterior draws per step in the sample leg")
@@ -191,6 +191,36 @@ def main():
         wall, dev_ms = timed(sample_step, ssteps, min(args.warmup, 2), device, dist)
         results["sample"] = {"value": nd * world * ssteps / wall, "unit": "draws/s", "steps": ssteps,
                              "ms_per_step": wall / ssteps * 1e3, "roofline": roofline(F_EVAL, nd, ssteps, dev_ms)}
+    if args.mode == "mcmc":
+        # MCMCPosterior (slice_np_vectorized on the device) over the NSF potential, one x_o
+        from torch.distributions import Independent, Normal
+
+        from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+        from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+        from sbi_amd.utils.sbiutils import mcmc_transform
+
+        prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
+        potential_fn, _ = posterior_estimator_based_potential(est, prior, x_o=None)
+        chains = int(os.environ.get("SBI_AMD_MCMC_CHAINS", "4096"))
+        post = MCMCPosterior(potential_fn, prior, mcmc_transform(prior, device=device), num_chains=chains, thin=1,
+                             warmup_steps=10, init_strategy="resample",
+                             init_strategy_parameters=dict(num_candidate_samples=64), device=str(device))
+        post.set_default_x(x[:1].clone())
+        nd = chains * 10
+        post.sample((nd,), show_progress_bars=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        post.sample((nd,), show_progress_bars=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ticks = post.posterior_sampler.num_ticks
+        if rank == 0:
+            print(json.dumps({"metric": "MCMCPosterior slice_np_vectorized samples/sec", "value": nd / dt,
+                              "unit": "samples/s", "n_gpus": 1, "chains": chains, "ticks": ticks,
+                              "us_per_tick": dt / ticks * 1e6, "log_prob_evals_per_s": ticks * chains / dt,
+                              "config": {"workload": f"{chains} chains x {nd // chains} kept sweeps (+10 warm-up, "
+                                                     f"+50 width-tuning sweeps), theta-dim {D}, one x_o"}}))
+        return
     if args.mode == "atomic":
         # one multi-round NPE-C step (atomic proposal-posterior loss, 10 atoms) on `--batch` pairs
         from torch.distributions import Independent, Normal

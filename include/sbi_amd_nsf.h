@@ -130,6 +130,18 @@ int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, flo
                            int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
                            float max_norm, float* scratch, void* stream);
 
+/* One tick of the vectorised slice sampler for all chains (the loop body of SliceSamplerVectorized.run,
+ * sbi/samplers/mcmc/slice_numpy.py:353-587): consumes the log-probabilities of `next_param` (what the batched
+ * log_prob kernel just produced), advances every chain's BEGIN/LOWER/UPPER/SAMPLE_SLICE state, writes the next
+ * evaluation points back into `next_param`, stores accepted sweeps into `samples`
+ * (num_chains, num_samples, dim) after `tuning` width-tuning sweeps and counts finished chains in *done_count.
+ * uniforms: (num_chains, 4 + dim) U[0,1) draws per tick from the caller's generator.
+ * istate: (num_chains, 4) int32 {state, dim index, sweep, -}; fstate: (num_chains, 8) {cxi, wi, lx, ux, xi, logu}. */
+int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples, int32_t tuning, float max_width,
+                            const float* logp, const float* uniforms, float* x, float* next_param, float* width,
+                            int32_t* order, int32_t* istate, float* fstate, float* samples, int32_t* done_count,
+                            void* stream);
+
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);

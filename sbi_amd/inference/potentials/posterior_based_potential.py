@@ -34,7 +34,7 @@ class PosteriorBasedPotential:
 
     # -- x_o handling -------------------------------------------------------------------
     def set_x(self, x_o: Optional[Tensor], x_is_iid: Optional[bool] = False) -> None:
-        if x_is_iid:
+        if x_is_iid and x_o is not None and x_o.dim() > 1 and x_o.shape[0] > 1:
             raise NotImplementedError(
                 "For NPE, iid observations need a permutation-invariant embedding net, which is outside "
                 "this path (posterior_based_potential.py:74-83)."

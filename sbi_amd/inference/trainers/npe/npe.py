@@ -468,10 +468,10 @@ class PosteriorEstimatorTrainer:
                         direct_sampling_parameters: Optional[Dict[str, Any]] = None, **kwargs):
         from sbi_amd.inference.posteriors.direct_posterior import DirectPosterior
 
-        if sample_with != "direct":
+        if sample_with not in ("direct", "mcmc"):
             raise NotImplementedError(
-                f"sample_with={sample_with!r}: MCMC / VI / importance posteriors are callers of the batched "
-                "log_prob kernel outside this round's scope (SURVEY.md section 8f-3); use 'direct'."
+                f"sample_with={sample_with!r}: VI / importance / rejection posteriors are outside this round's "
+                "scope (SURVEY.md section 8f-3); use 'direct' or 'mcmc'."
             )
         if prior is None:
             if self._prior is None:
@@ -488,6 +488,21 @@ class PosteriorEstimatorTrainer:
         else:
             estimator = density_estimator
             device = str(next(density_estimator.parameters()).device)
+        if sample_with == "mcmc":
+            # npe_base.py:420-512 + posteriors/posterior_parameters.py: potential = estimator log-prob inside the
+            # prior support, proposal = prior, sampling in the unconstrained space of mcmc_transform(prior)
+            from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+            from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+            from sbi_amd.utils.sbiutils import mcmc_transform
+
+            potential_fn, _ = posterior_estimator_based_potential(estimator, prior, x_o=None)
+            mcmc_parameters = dict(kwargs.get("mcmc_parameters") or {})
+            enable_transform = mcmc_parameters.pop("enable_transform", True)
+            theta_transform = mcmc_transform(prior, device=device, enable_transform=enable_transform)
+            self._posterior = MCMCPosterior(potential_fn=potential_fn, proposal=prior, theta_transform=theta_transform,
+                                            method=kwargs.get("mcmc_method", "slice_np_vectorized"), device=device,
+                                            **mcmc_parameters)
+            return deepcopy(self._posterior)
         self._posterior = DirectPosterior(posterior_estimator=estimator, prior=prior, device=device,
                                           **(direct_sampling_parameters or {}))
         return deepcopy(self._posterior)

@@ -126,3 +126,60 @@ def warn_if_outside_prior_support(prior, samples: Tensor) -> None:
             f"{frac:.1%} of the samples drawn without rejection lie outside the prior support.",
             stacklevel=2,
         )
+
+
+def mcmc_transform(prior, num_prior_samples_for_zscoring: int = 1000, enable_transform: bool = True,
+                   device="cpu", **kwargs):
+    """Transform applied to parameters during MCMC (sbiutils.py:867-980): bounded supports are mapped to
+    unbounded space with `biject_to`, unbounded ones are z-scored with the prior's mean / std.  The returned
+    transform's forward maps constrained -> unconstrained."""
+    import torch.distributions.transforms as torch_tf
+    from torch.distributions import biject_to, constraints
+
+    if enable_transform:
+        def prior_mean_std_transform():
+            try:
+                prior_mean, prior_std = prior.mean.to(device), prior.stddev.to(device)
+            except (NotImplementedError, AttributeError):
+                warnings.warn("The passed prior has no mean or stddev attribute, estimating them from samples to "
+                              "build affine standardizing transform.", stacklevel=2)
+                th = prior.sample(torch.Size((num_prior_samples_for_zscoring,)))
+                prior_mean, prior_std = th.mean(dim=0).to(device), th.std(dim=0).to(device)
+            return torch_tf.AffineTransform(loc=prior_mean, scale=prior_std)
+
+        try:
+            _ = prior.support
+            has_support = True
+        except (NotImplementedError, AttributeError):
+            warnings.warn("The passed prior has no support property, transform will be constructed from mean and "
+                          "std. If the passed prior is supposed to be bounded consider implementing the "
+                          "prior.support property.", stacklevel=2)
+            has_support = False
+        if has_support:
+            constraint = prior.support.base_constraint if hasattr(prior.support, "base_constraint") else prior.support
+            if getattr(prior.support, "is_discrete", False) or isinstance(constraint, constraints._Real):
+                transform = prior_mean_std_transform()
+            else:
+                transform = biject_to(prior.support)
+        else:
+            transform = prior_mean_std_transform()
+    else:
+        transform = torch_tf.identity_transform
+    if not isinstance(transform, torch_tf.IndependentTransform):
+        transform = torch_tf.IndependentTransform(transform, reinterpreted_batch_ndims=1)
+    check_transform(prior, transform)
+    return transform.inv
+
+
+def check_transform(prior, transform, atol: float = 1e-3) -> None:
+    """sbiutils.py:983-1003."""
+    try:
+        theta = prior.sample(torch.Size((2,)))
+    except NotImplementedError:
+        theta = prior.mean.repeat(2, *[1] * prior.mean.dim())
+    theta_unconstrained = transform.inv(theta)
+    assert theta_unconstrained.shape == theta.shape, (
+        "Mismatch between transformed and untransformed space. Note that you cannot use a transforms when using a "
+        "MultipleIndependent prior with a Dirichlet prior.")
+    assert torch.allclose(theta, transform(theta_unconstrained), atol=atol), \
+        "Original and re-transformed parameters must be close to each other."

@@ -1,0 +1,73 @@
+"""CPU-side pieces of the MCMC path: parameter transforms, chain initialisation, posterior plumbing
+(sbi/utils/sbiutils.py:867-1003, sbi/samplers/mcmc/init_strategy.py, sbi/utils/potentialutils.py)."""
+
+import pytest
+import torch
+from torch.distributions import MultivariateNormal
+
+from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+from sbi_amd.samplers.mcmc import SliceSamplerVectorized, proposal_init, resample_given_potential_fn, sir_init
+from sbi_amd.utils.potentialutils import transformed_potential
+from sbi_amd.utils.sbiutils import mcmc_transform
+from sbi_amd.utils.torchutils import BoxUniform
+
+
+def test_mcmc_transform_bounded_and_unbounded():
+    box = BoxUniform(-2.0 * torch.ones(3), 3.0 * torch.ones(3))
+    tf = mcmc_transform(box)
+    th = box.sample((50,))
+    u = tf(th)                                                   # constrained -> unconstrained (logit)
+    assert torch.isfinite(u).all() and torch.allclose(tf.inv(u), th, atol=1e-5)
+    assert tf.inv(torch.full((1, 3), 50.0)).max() <= 3.0 and tf.inv(torch.full((1, 3), -50.0)).min() >= -2.0
+    assert tf.log_abs_det_jacobian(th, u).shape == (50,)        # summed over the parameter dimension
+    mvn = MultivariateNormal(torch.tensor([1.0, -1.0]), torch.diag(torch.tensor([4.0, 0.25])))
+    tz = mcmc_transform(mvn)
+    th = mvn.sample((2000,))
+    z = tz(th)                                                   # z-scoring with the prior's mean / std
+    assert torch.allclose(z.mean(0), torch.zeros(2), atol=0.1) and torch.allclose(z.std(0), torch.ones(2), atol=0.1)
+    ident = mcmc_transform(mvn, enable_transform=False)
+    assert torch.equal(ident(th), th)
+
+
+def test_transformed_potential_subtracts_log_abs_det():
+    box = BoxUniform(torch.zeros(2), torch.ones(2))
+    tf = mcmc_transform(box)
+
+    def potential(theta, track_gradients=False):
+        return -((theta - 0.5) ** 2).sum(1)
+
+    th = box.sample((20,))
+    u = tf(th)
+    got = transformed_potential(u, potential, tf, "cpu")
+    want = potential(th) - tf.log_abs_det_jacobian(th, u)
+    assert torch.allclose(got, want, atol=1e-6)
+
+
+def test_init_strategies_return_one_row_per_chain_in_transformed_space():
+    torch.manual_seed(0)
+    prior = MultivariateNormal(torch.zeros(2), torch.eye(2))
+    tf = mcmc_transform(prior)
+    target = MultivariateNormal(torch.tensor([1.5, -1.0]), 0.05 * torch.eye(2))
+    pot = lambda th, track_gradients=False: target.log_prob(th)
+    a = proposal_init(prior, tf, num_chains=7)
+    b = sir_init(prior, pot, tf, num_chains=7, num_candidate_samples=2000)
+    c = resample_given_potential_fn(prior, pot, tf, num_chains=7, num_candidate_samples=2000)
+    assert a.shape == b.shape == c.shape == (7, 2)
+    # the potential-weighted inits concentrate at the target mode, the proposal init does not
+    assert (tf.inv(c) - target.mean).norm(dim=1).mean() < 0.5
+    assert (tf.inv(b) - target.mean).norm(dim=1).mean() < 0.5
+    # candidates all outside the support -> still returns finite rows
+    dead = lambda th, track_gradients=False: torch.full((th.shape[0],), float("-inf"))
+    assert torch.isfinite(resample_given_potential_fn(prior, dead, tf, num_chains=3, num_candidate_samples=10)).all()
+
+
+def test_sampler_and_posterior_fail_loudly_without_a_gpu():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SliceSamplerVectorized(lambda th: -th.pow(2).sum(1), torch.zeros(4, 2), num_chains=4)
+    with pytest.raises(NameError):
+        MCMCPosterior(potential_fn=lambda th: th, proposal=None, method="metropolis")
+    post = MCMCPosterior(potential_fn=lambda th: th, proposal=None, device="cpu")
+    with pytest.raises(ValueError, match="default"):
+        post.sample((3,))
+    assert post.thin == 1 and post.mcmc_method == "slice_np_vectorized"
+    assert post.set_mcmc_method("slice_np").mcmc_method == "slice_np"
