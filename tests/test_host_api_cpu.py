@@ -235,7 +235,12 @@ def test_build_posterior_requires_direct_and_trained_net():
         inf.build_posterior()
     inf.train(training_batch_size=100, max_num_epochs=1)
     with pytest.raises(NotImplementedError):
-        inf.build_posterior(sample_with="mcmc")
+        inf.build_posterior(sample_with="vi")
+    mcmc = inf.build_posterior(sample_with="mcmc", mcmc_parameters=dict(num_chains=4)).set_default_x(torch.zeros(2))
+    assert mcmc.num_chains == 4 and mcmc.potential(torch.zeros(3, 2)).shape == (3,)
+    pickle.loads(pickle.dumps(mcmc))                     # the parameter transform survives pickling
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # the sampler itself is a device kernel
+        mcmc.sample((5,), init_strategy="proposal", show_progress_bars=False)
     post = inf.build_posterior().set_default_x(torch.zeros(2))
     assert post.sample((10,), show_progress_bars=False).shape == (10, 2)
     post2 = pickle.loads(pickle.dumps(post))            # save_and_load_test.py:23-43
