@@ -26,6 +26,7 @@
 #ifndef TR_PF_HL
 #define TR_PF_HL 1          // request the next tile's h_last during this tile's last two phases
 #endif
+#define TR_LDK_FAST 50     // image row stride of the default hidden_features = 50: compiled-in fast path
 #ifndef TR_LA
 #define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
 #endif
@@ -208,35 +209,44 @@ __device__ __forceinline__ void grad_wave_sync(int* cnt, int target, int lane) {
 // The image keeps rows [out, 4*KS) zero (nsf_plan.cpp: rows_alloc), so K-steps past `out` need no
 // predicate; lanes that supply an A row for an in-feature slot >= in load column 0 instead (finite) and
 // the corresponding output slots are cleared after the loop.
-template <int KS, int MT>
-__device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
-                                            const f4 (&gb)[NSF_HT], f4 (&acc)[MT], int abl = 0) {
-  if (abl & 2) return;
+template <int KS, int MT, int LDK>
+__device__ __forceinline__ void gemm_T_breg_ldk(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                                const f4 (&gb)[NSF_HT], f4 (&acc)[MT]) {
+  const int ldk = LDK ? LDK : L.ldk;   // compile-time row stride: immediate offsets, two K-steps per ds_read2_b32
   const float* base[MT];
-  bool ok[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int f = 16 * mt + id.iperm;
-    ok[mt] = f < L.in;
-    base[mt] = lds + L.l_w + id.g * L.ldk + (ok[mt] ? f : 0);
+    base[mt] = lds + L.l_w + id.g * ldk + (f < L.in ? f : 0);
   }
-  const int kstride = 4 * L.ldk;
-  constexpr int LA = TR_LA;
-  float a[LA + 1][MT];
+  const int kstride = 4 * ldk;
+  // K-steps go in pairs: the loads of pair p+1 are requested before the MFMAs of pair p, and with a
+  // compile-time stride the two steps of a pair share one ds_read2_b32 per m-tile
+  constexpr int NP = (KS + 1) / 2;
+  float a[2][2][MT];
 #pragma unroll
-  for (int u = 0; u < LA; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[u][mt] = u < KS ? base[mt][u * kstride] : 0.f;
+    for (int mt = 0; mt < MT; ++mt) a[0][u][mt] = u < KS ? base[mt][u * kstride] : 0.f;
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    if (s + LA < KS) {
+  for (int p = 0; p < NP; ++p) {
+    if (p + 1 < NP) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[(s + LA) % (LA + 1)][mt] = base[mt][(s + LA) * kstride];
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          a[(p + 1) & 1][u][mt] = (2 * p + 2 + u < KS) ? base[mt][(2 * p + 2 + u) * kstride] : 0.f;
     }
-    const float bv = gb[s >> 2][s & 3];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(a[s % (LA + 1)][mt], bv, acc[mt]);
+    for (int u = 0; u < 2; ++u) {
+      const int s = 2 * p + u;
+      if (s < KS) {
+        const float bv = gb[s >> 2][s & 3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(a[p & 1][u][mt], bv, acc[mt]);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   // in-feature slots >= in accumulated a (finite) neighbouring weight column: clear them on the way out
@@ -245,6 +255,13 @@ __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[mt][r] = (16 * mt + 4 * r + id.g < L.in) ? acc[mt][r] : 0.f;
+}
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                            const f4 (&gb)[NSF_HT], f4 (&acc)[MT], int abl = 0) {
+  if (abl & 2) return;
+  if (L.ldk == TR_LDK_FAST) gemm_T_breg_ldk<KS, MT, TR_LDK_FAST>(lds, L, id, gb, acc);   // wave-uniform
+  else gemm_T_breg_ldk<KS, MT, 0>(lds, L, id, gb, acc);
 }
 
 // final_layer output for the backward chunk -> this wave's rows of the shared A tile
@@ -402,45 +419,52 @@ __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int pl
 // just wrote into the shared A tile).  Select-free like gemm_T_breg: the padding K slots (p >= P)
 // carry exact-zero g_p, so whatever finite weight they meet is harmless; output slots of in-features
 // >= H are cleared after the loop.
-template <int PT>
-__device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const LinDesc& LF, const NsfPlan& pl,
-                                          const ShapeDesc& S, const LaneId& id, const float* __restrict__ Arow,
-                                          int SA, int d0, f4 (&gh)[NSF_HT]) {
+template <int PT, int LDK>
+__device__ __forceinline__ void wft_chunk_ldk(const float* __restrict__ lds, const LinDesc& LF, const NsfPlan& pl,
+                                              const ShapeDesc& S, const LaneId& id, const float* __restrict__ Arow,
+                                              int SA, int d0, f4 (&gh)[NSF_HT]) {
   constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
   constexpr int KS = 4 * PT;
-  bool ok[NSF_HT];
   int col[NSF_HT];
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt) {
     const int f = 16 * mt + id.iperm;
-    ok[mt] = f < LF.in;
-    col[mt] = ok[mt] ? f : 0;
+    col[mt] = f < LF.in ? f : 0;
   }
-  const int kstride = 4 * LF.ldk;
+  const int ldk = LDK ? LDK : LF.ldk;
+  const int kstride = 4 * ldk;
 #pragma unroll
   for (int sl = 0; sl < DCHB; ++sl) {
     const int dd = d0 + sl;
     if (dd < S.d_tr) {
-      const float* wrow = lds + LF.l_w + (dd * pl.P + id.g) * LF.ldk;
+      const float* wrow = lds + LF.l_w + (dd * pl.P + id.g) * ldk;
       const float* brow = Arow + id.j * SA + sl * 16 * PT + id.g;
-      constexpr int LA = TR_LA;
-      float a[LA + 1][NSF_HT], bb[LA + 1];
+      const float* wcol[NSF_HT];
 #pragma unroll
-      for (int u = 0; u < LA; ++u) {
-        bb[u] = brow[4 * u];
+      for (int mt = 0; mt < NSF_HT; ++mt) wcol[mt] = wrow + col[mt];
+      constexpr int NP = KS / 2;   // KS = 4 PT is even
+      float a[2][2][NSF_HT], bb[2][2];
 #pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) a[u][mt] = wrow[u * kstride + col[mt]];
+      for (int u = 0; u < 2; ++u) {
+        bb[0][u] = brow[4 * u];
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) a[0][u][mt] = wcol[mt][u * kstride];
       }
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        if (s + LA < KS) {
-          bb[(s + LA) % (LA + 1)] = brow[4 * (s + LA)];
+      for (int p = 0; p < NP; ++p) {
+        if (p + 1 < NP) {
 #pragma unroll
-          for (int mt = 0; mt < NSF_HT; ++mt) a[(s + LA) % (LA + 1)][mt] = wrow[(s + LA) * kstride + col[mt]];
+          for (int u = 0; u < 2; ++u) {
+            bb[(p + 1) & 1][u] = brow[4 * (2 * p + 2 + u)];
+#pragma unroll
+            for (int mt = 0; mt < NSF_HT; ++mt) a[(p + 1) & 1][u][mt] = wcol[mt][(2 * p + 2 + u) * kstride];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = MFMA16(a[s % (LA + 1)][mt], bb[s % (LA + 1)], gh[mt]);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = MFMA16(a[p & 1][u][mt], bb[p & 1][u], gh[mt]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -449,6 +473,13 @@ __device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const L
   for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) gh[mt][r] = (16 * mt + 4 * r + id.g < LF.in) ? gh[mt][r] : 0.f;
+}
+template <int PT>
+__device__ __forceinline__ void wft_chunk(const float* __restrict__ lds, const LinDesc& LF, const NsfPlan& pl,
+                                          const ShapeDesc& S, const LaneId& id, const float* __restrict__ Arow,
+                                          int SA, int d0, f4 (&gh)[NSF_HT]) {
+  if (LF.ldk == TR_LDK_FAST) wft_chunk_ldk<PT, TR_LDK_FAST>(lds, LF, pl, S, id, Arow, SA, d0, gh);
+  else wft_chunk_ldk<PT, 0>(lds, LF, pl, S, id, Arow, SA, d0, gh);
 }
 
 // partial-gradient write-out of one weight tile (lane (g,j), reg r: out = out0+4g+r, in = 16nt+j)
@@ -480,7 +511,9 @@ __device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDe
 //   S0 | prologue | K0 | chunk steps 0..nch (K1..K_nch) | H | per block: X1 X2 X3 (X4) | Y1 | Y2
 // NBT = residual blocks; NBT == 0 selects the theta-dim-1 ContextSplineMap conditioner (compile time, so the
 // residual-net instantiations carry none of its code or registers).
-template <int K, int KSH, int NBT, int NCH>
+// NTW = n-tiles of the narrow input-side weight gradients (d W0, d Wc): 1 when their inputs (+ bias column) fit
+// 16 columns, which frees 12 accumulator registers in the grad waves.
+template <int K, int KSH, int NBT, int NCH, int NTW>
 __global__ void __launch_bounds__(128 * TR_NW, 2)
 nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const float* __restrict__ packed,
                      const float* __restrict__ zstats, const float* __restrict__ z_in,
@@ -806,13 +839,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     int* cnt = (int*)(lds + tp.o_cnt);
     int sync_target = 0;
     // weight-gradient accumulators owned by this wave (m-tile = wave) for the whole launch
-    f4 acc0[2], accC[NB][2], acc1[NB][4], acc2[NB][4], accF[NCH][4], accLU[1];
+    f4 acc0[NTW], accC[NB][NTW], acc1[NB][4], acc2[NB][4], accF[NCH][4], accLU[1];
   #pragma unroll
-    for (int i = 0; i < 2; ++i) acc0[i] = zero4;
+    for (int i = 0; i < NTW; ++i) acc0[i] = zero4;
   #pragma unroll
     for (int b = 0; b < NB; ++b) {
   #pragma unroll
-      for (int i = 0; i < 2; ++i) accC[b][i] = zero4;
+      for (int i = 0; i < NTW; ++i) accC[b][i] = zero4;
   #pragma unroll
       for (int i = 0; i < 4; ++i) { acc1[b][i] = zero4; acc2[b][i] = zero4; }
     }
@@ -885,7 +918,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           __syncthreads();                         // X1
           TS(21 + 8 * b);
           dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
-          dw_gemm<2, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
+          dw_gemm<NTW, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
           TS(22 + 8 * b);
           __syncthreads();                         // X2
           __syncthreads();                         // X3
@@ -900,7 +933,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #if TR_PF_HL
       fetch_hl(tile_nxt);   // next tile's h_last: lands under this tile's last two phases
 #endif
-      dw_gemm<2, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, 0, id, acc0, nt0, pl.ablate);
+      dw_gemm<NTW, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       TS(42);
       __syncthreads();                             // Y2
       if (gw < 2 && !cm) dw_gemm<1, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 16 * gw, id, accLU);
@@ -911,7 +944,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     float* part = partial + ((long long)t * gridDim.x + blockIdx.x) * tp.PLP;
     const int out0 = 16 * gw;
   #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) write_tile(part, L0, out0, nt, id, acc0[nt]);
+    for (int nt = 0; nt < NTW; ++nt) write_tile(part, L0, out0, nt, id, acc0[nt]);
     if (cm) {
   #pragma unroll
       for (int nt = 0; nt < 4; ++nt) write_tile(part, S.lin[1], out0, nt, id, acc1[0][nt]);   // hidden H->H layer
@@ -919,7 +952,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   #pragma unroll
       for (int b = 0; b < NB; ++b) {
   #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) write_tile(part, S.lin[1 + 3 * b], out0, nt, id, accC[b][nt]);
+        for (int nt = 0; nt < NTW; ++nt) write_tile(part, S.lin[1 + 3 * b], out0, nt, id, accC[b][nt]);
   #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           write_tile(part, S.lin[2 + 3 * b], out0, nt, id, acc1[b][nt]);
@@ -977,12 +1010,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 
 
 // ---- launch helpers
-template <int K, int KSH, int NB, int NCH>
+template <int K, int KSH, int NB, int NCH, int NTW>
 static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
                       const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
                       int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
                       const float* astash, long long* dbg, hipStream_t st) {
-  auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH>;
+  auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH, NTW>;
   const int lds_bytes = 4 * tp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
@@ -999,15 +1032,18 @@ int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* pac
 #define BWD_ARGS pl, tp, t, packed, zstats, z_in, x, gz_up, row_w, uni_w, n, x_rows, gz_dn, partial, grad_theta, \
                  astash, dbg, st
   const int nchmax = tp.nch[0] > tp.nch[1] ? tp.nch[0] : tp.nch[1];
+  // narrow input side (d W0 / d Wc fit one 16-column n-tile incl. the bias column): the common case
+  int in0max = pl.shape[0].in0 > pl.shape[1].in0 ? pl.shape[0].in0 : pl.shape[1].in0;
+  const bool wide = (in0max + 1 > 16) || (pl.C + 1 > 16);
 #define BWD_NCH(KS, NBV) \
   switch (nchmax) { \
-    case 1: return launch_bwd<K, KS, NBV, 1>(BWD_ARGS); \
-    case 2: case 3: return launch_bwd<K, KS, NBV, 3>(BWD_ARGS); \
-    default: return launch_bwd<K, KS, NBV, 4>(BWD_ARGS); \
+    case 1: return wide ? launch_bwd<K, KS, NBV, 1, 2>(BWD_ARGS) : launch_bwd<K, KS, NBV, 1, 1>(BWD_ARGS); \
+    case 2: case 3: return wide ? launch_bwd<K, KS, NBV, 3, 2>(BWD_ARGS) : launch_bwd<K, KS, NBV, 3, 1>(BWD_ARGS); \
+    default: return wide ? launch_bwd<K, KS, NBV, 4, 2>(BWD_ARGS) : launch_bwd<K, KS, NBV, 4, 1>(BWD_ARGS); \
   }
   if (pl.ctx_mlp) {   // theta-dim 1: one transformed dim => one chunk
-    if (pl.KSH == 13) return launch_bwd<K, 13, 0, 1>(BWD_ARGS);
-    return launch_bwd<K, 16, 0, 1>(BWD_ARGS);
+    if (pl.KSH == 13) return wide ? launch_bwd<K, 13, 0, 1, 2>(BWD_ARGS) : launch_bwd<K, 13, 0, 1, 1>(BWD_ARGS);
+    return wide ? launch_bwd<K, 16, 0, 1, 2>(BWD_ARGS) : launch_bwd<K, 16, 0, 1, 1>(BWD_ARGS);
   }
   if (pl.KSH == 13) { if (pl.NB <= 1) { BWD_NCH(13, 1) } else { BWD_NCH(13, 2) } }
   if (pl.NB <= 1) { BWD_NCH(16, 1) } else { BWD_NCH(16, 2) }
