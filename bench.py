@@ -125,10 +125,21 @@ def timed(step, steps, warmup, device, dist=None):
     return float(t.item()), dev_ms
 
 
-def roofline(flop_per_unit, units_per_step, steps, dev_ms):
+# HBM bytes per step at batch 65 536 from the separate rocprofv3 --pmc passes of this same command
+# (profiles/r1b_pmc_summary.txt: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch, summed over the step's
+# kernels).  bench.py cannot run the profiler on itself, so these are the committed measurements; they are
+# only attached when the workload matches the profiled one.
+PROFILED_TRAFFIC = {"log_prob": 10.7e6, "train": 1.7e9, "sample": None}
+
+
+def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
     achieved = flop_per_unit * units_per_step * steps / (dev_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "device_ms_per_step": dev_ms / steps}
+    traffic = PROFILED_TRAFFIC.get(kind) if units_per_step == BATCH else None
+    out = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "device_ms_per_step": dev_ms / steps}
+    if traffic is not None:
+        out["traffic_source"] = "profiles/r1b_pmc_summary.txt (bytes per step)"
+    return out
 
 
 def main():
@@ -172,7 +183,7 @@ def main():
         wall, dev_ms = timed(lp_step, args.steps, args.warmup, device, dist)
         results["log_prob"] = {"value": B * world * args.steps / wall, "unit": "evals/s",
                                "ms_per_step": wall / args.steps * 1e3,
-                               "roofline": roofline(F_EVAL, B, args.steps, dev_ms)}
+                               "roofline": roofline(F_EVAL, B, args.steps, dev_ms, "log_prob")}
     if args.mode in ("both", "sample"):
         # BASELINE configs[3] (M3): DirectPosterior.sample of 10^6 draws for one x_o, prior support check included
         from torch.distributions import Independent, Normal
@@ -252,7 +263,7 @@ def main():
         wall, dev_ms = timed(lambda: stepper.step(theta, x), args.steps, args.warmup, device, dist)
         results["train"] = {"value": B * world * args.steps / wall, "unit": "pairs/s",
                             "ms_per_step": wall / args.steps * 1e3,
-                            "roofline": roofline(F_TRAIN, B, args.steps, dev_ms)}
+                            "roofline": roofline(F_TRAIN, B, args.steps, dev_ms, "train")}
 
     if rank == 0:
         head = "train" if "train" in results else ("log_prob" if "log_prob" in results else "sample")

@@ -138,9 +138,17 @@ int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, flo
  * uniforms: (num_chains, 4 + dim) U[0,1) draws per tick from the caller's generator.
  * istate: (num_chains, 4) int32 {state, dim index, sweep, -}; fstate: (num_chains, 8) {cxi, wi, lx, ux, xi, logu}. */
 int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples, int32_t tuning, float max_width,
-                            const float* logp, const float* uniforms, float* x, float* next_param, float* width,
+                            const float* logp, const float* logp_offset /* optional (num_chains): subtracted */,
+                            const float* uniforms, float* x, float* next_param, float* width,
                             int32_t* order, int32_t* istate, float* fstate, float* samples, int32_t* done_count,
                             void* stream);
+
+/* Unconstrained -> constrained parameters for the transforms of mcmc_transform (sbi/utils/sbiutils.py:867-980)
+ * and the log|det| term of transformed_potential (sbi/utils/potentialutils.py:15-51) in one launch:
+ * kind 0 identity; kind 1 theta = p0 + p1 * u (z-scoring with the prior's mean p0 / std p1);
+ * kind 2 theta = p0 + p1 * sigmoid(u) (box [p0, p0 + p1]).  logabsdet_out = log|det d u / d theta|. */
+int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, const float* p0, const float* p1,
+                                const float* u, float* theta_out, float* logabsdet_out, void* stream);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
 int sbi_amd_nsf_abi_version(void);

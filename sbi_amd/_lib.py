@@ -75,7 +75,11 @@ _SIGNATURES = {
     "sbi_amd_mcmc_slice_tick": (
         c_int,
         [c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_mcmc_to_constrained": (
+        c_int,
+        [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_nsf_abi_version": (c_int, []),
     "sbi_amd_nsf_arch": (c_char_p, []),

@@ -16,7 +16,8 @@
 enum { ST_BEGIN = 0, ST_LOWER = 1, ST_UPPER = 2, ST_SAMPLE = 3, ST_DONE = 4 };
 
 __global__ void slice_tick_kernel(int C, int D, int num_samples, int tuning, float max_width,
-                                  const float* __restrict__ logp, const float* __restrict__ rnd,   // (C), (C, 4 + D)
+                                  const float* __restrict__ logp, const float* __restrict__ logp_offset,   // (C), (C)|null
+                                  const float* __restrict__ rnd,                                  // (C, 4 + D)
                                   float* __restrict__ x, float* __restrict__ next_param,           // (C, D) each
                                   float* __restrict__ width,                                       // (C, D)
                                   int* __restrict__ order, int* __restrict__ istate,                // (C, D), (C, 4): state, i, t, -
@@ -30,7 +31,7 @@ __global__ void slice_tick_kernel(int C, int D, int num_samples, int tuning, flo
   int i = istate[4 * c + 1], t = istate[4 * c + 2];
   float* fs = fstate + 8 * c;
   float cxi = fs[0], wi = fs[1], lx = fs[2], ux = fs[3], xi = fs[4], logu = fs[5];
-  const float lp = logp[c];
+  const float lp = logp_offset ? logp[c] - logp_offset[c] : logp[c];
   const float* u = rnd + (size_t)c * (4 + D);
   const int dim = order[(size_t)c * D + i];
   float* xp = x + (size_t)c * D;
@@ -104,15 +105,55 @@ __global__ void slice_tick_kernel(int C, int D, int num_samples, int tuning, flo
   fs[0] = cxi; fs[1] = wi; fs[2] = lx; fs[3] = ux; fs[4] = xi; fs[5] = logu;
 }
 
+// theta = T^-1(u) and log|det dT/dtheta| for the two parameter transforms `mcmc_transform` builds
+// (sbi/utils/sbiutils.py:867-980): kind 1 = z-scoring with the prior's mean / std (unbounded support),
+// kind 2 = logit map of a box [low, high] (biject_to(Independent(Uniform))); kind 0 = identity.
+__global__ void mcmc_to_constrained_kernel(int kind, int C, int D, const float* __restrict__ p0,
+                                           const float* __restrict__ p1, const float* __restrict__ u,
+                                           float* __restrict__ theta, float* __restrict__ lad) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float v = u[(size_t)c * D + d];
+    float th = v;
+    if (kind == 1) {          // u = (theta - loc) / scale
+      th = p0[d] + p1[d] * v;
+      acc -= logf(fabsf(p1[d]));
+    } else if (kind == 2) {   // theta = low + (high - low) * sigmoid(u)
+      const float sg = 1.f / (1.f + expf(-v));
+      th = p0[d] + p1[d] * sg;
+      // -log|d theta/d u| = -(log(high-low) + log sigmoid(u) + log sigmoid(-u)), softplus form for the tails
+      const float sp_pos = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));    // softplus(u)  = -log sigmoid(-u)
+      const float sp_neg = sp_pos - v;                                   // softplus(-u) = -log sigmoid(u)
+      acc -= logf(p1[d]) - sp_pos - sp_neg;
+    }
+    theta[(size_t)c * D + d] = th;
+  }
+  lad[c] = acc;
+}
+
+extern "C" int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, const float* p0,
+                                           const float* p1, const float* u, float* theta_out, float* logabsdet_out,
+                                           void* stream) {
+  if (kind < 0 || kind > 2 || num_chains < 1 || dim < 1 || !u || !theta_out || !logabsdet_out || (kind && (!p0 || !p1)))
+    return SBI_AMD_E_BADARG;
+  hipLaunchKernelGGL(mcmc_to_constrained_kernel, dim3((num_chains + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     kind, num_chains, dim, p0, p1, u, theta_out, logabsdet_out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples, int32_t tuning,
-                                       float max_width, const float* logp, const float* uniforms, float* x,
+                                       float max_width, const float* logp, const float* logp_offset,
+                                       const float* uniforms, float* x,
                                        float* next_param, float* width, int32_t* order, int32_t* istate,
                                        float* fstate, float* samples, int32_t* done_count, void* stream) {
   if (num_chains < 1 || dim < 1 || num_samples < 0 || tuning < 0 || !logp || !uniforms || !x || !next_param ||
       !width || !order || !istate || !fstate || !samples || !done_count)
     return SBI_AMD_E_BADARG;
   hipLaunchKernelGGL(slice_tick_kernel, dim3((num_chains + 255) / 256), dim3(256), 0, (hipStream_t)stream, num_chains,
-                     dim, num_samples, tuning, max_width, logp, uniforms, x, next_param, width, order, istate, fstate,
+                     dim, num_samples, tuning, max_width, logp, logp_offset, uniforms, x, next_param, width, order, istate,
+                     fstate,
                      samples, done_count);
   return (int)hipGetLastError();
 }

@@ -419,19 +419,6 @@ struct FinalLayerStream {
   }
 };
 
-template <int PT, int KSH>
-__device__ __forceinline__ void final_layer_chunk(const float* __restrict__ lds, float* __restrict__ pst,
-                                                  const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
-                                                  const f4 (&h)[NSF_HT], int d0) {
-  int nact = S.d_tr - d0;
-  nact = nact < pl.DCH ? nact : pl.DCH;
-  switch (nact) {   // wave-uniform
-    case 1: final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, d0); break;
-    case 2: final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, d0); break;
-    default: break;
-  }
-}
-
 // ---- rational-quadratic spline: one (row, dim) task per LANE PAIR (lane, lane^32) -------
 // Restates nflows 0.14 transforms/splines/rational_quadratic.py
 // (unconstrained_rational_quadratic_spline, tails="linear") with the constants sbi passes

@@ -16,16 +16,13 @@
 #include <stdlib.h>
 #include "nsf_device.h"
 
-#define TR_NW 4            // waves per workgroup
+#define TR_NW 4            // row waves per workgroup (+ as many grad waves)
 #define TR_ROWS 64         // rows per tile
 #define TR_MAXCH 4         // spline chunks per transform the accumulators are sized for
 #define TR_GRID_MAX 256    // persistent workgroups (one per CU)
 #define TR_SA 68           // row stride of the gradient tiles A0/A1
 #define TR_SB 68           // row stride of the activation tile B (column-interleaved, see stage_DB)
 #define TR_SS 48           // row stride of the static conditioner-input tile Bs
-#ifndef TR_PF_HL
-#define TR_PF_HL 1          // request the next tile's h_last during this tile's last two phases
-#endif
 #define TR_LDK_FAST 50     // image row stride of the default hidden_features = 50: compiled-in fast path
 #ifndef TR_LA
 #define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
@@ -619,8 +616,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           }
         }
         wave_lds_fence();
-        TS(50);
-        // conditioner-input row [z_id ; standardized context ; 1 ; 0 ...] -> static tile Bs (branch-free:
+          // conditioner-input row [z_id ; standardized context ; 1 ; 0 ...] -> static tile Bs (branch-free:
         // clamped reads + selects).  The context is x * (1/std): within 1 ulp of the forward kernel's
         // (x - mean) / std; it only feeds the B operand of d W0 / d Wc.
 #pragma unroll
@@ -639,7 +635,6 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 #pragma unroll
         for (int u = 8; u < 12; ++u) Bs[trow * SS + id.g + 4 * u] = 0.f;
       }
-      TS(51);
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T g_z, g_y = U^T g_u
       float gus_r[4] = {0.f, 0.f, 0.f, 0.f};     // g_u of dims 4 g + ii, kept for the LU parameter gradients
       if (cm) {   // no LULinear for theta-dim 1: the transform output IS the layer output
@@ -660,7 +655,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = o[ii];   // identity dims pass through
       }
       wave_lds_fence();
-      const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile * TR_NW + wave) * SLOTS) * 1024 +
+      // wave-tiles past the last row were never stashed by the forward pass: read the last real one instead
+      // (their rows carry zero weight, but 0 x stale NaN would still poison the weight gradients)
+      const long long nt16 = (n + 15) / 16;
+      const long long wt16 = (long long)tile * TR_NW + wave < nt16 ? (long long)tile * TR_NW + wave : nt16 - 1;
+      const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
                          id.lane;
       TS(1);
       __syncthreads();                             // K0: spline parameters of chunk 0 are in A0
@@ -858,13 +857,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     const LaneId id0 = id;
     f4 hl[NSF_HT];
     auto fetch_hl = [&](int tile_) {
-      const float* ast = astash + (((long long)t * ((n + 15) / 16) + (long long)tile_ * TR_NW + gw) * SLOTS) * 1024 +
+      const long long nt16 = (n + 15) / 16;   // clamp as the row waves do: unstashed wave-tiles hold stale memory
+      const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
+      const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
                          id0.lane;
       ast_load(ast, cm ? 1 : 4 * NB, hl);
     };
-#if TR_PF_HL
     fetch_hl(blockIdx.x);
-#endif
     for (int tile = blockIdx.x; tile < tp.ntiles; tile += gridDim.x) {
       LaneId id = id0;
       asm volatile("" : "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
@@ -874,9 +873,6 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       TS(0);
       // ---- prologue: h_last of the partner's rows (stash, D-fragment order = MFMA B operand; requested
       // during the previous tile), its activation-tile rows, and the spline parameters of chunk 0
-#if !TR_PF_HL
-      fetch_hl(tile);
-#endif
       stage_DB(Bt, SB, trow, id, hl, false);
       if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
       if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
@@ -930,9 +926,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       __syncthreads();                             // Y1
       TS(41);
-#if TR_PF_HL
       fetch_hl(tile_nxt);   // next tile's h_last: lands under this tile's last two phases
-#endif
       dw_gemm<NTW, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       TS(42);
       __syncthreads();                             // Y2

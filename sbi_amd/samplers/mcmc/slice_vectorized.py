@@ -55,13 +55,17 @@ class SliceSamplerVectorized:
         max_width = self.max_width if self.max_width != float("inf") else 3.0e38
         tick = 0
         while True:
-            logp = self._log_prob_fn(nxt).reshape(-1).to(torch.float32).contiguous()
+            out = self._log_prob_fn(nxt)
+            # a (log_prob, offset) pair keeps the potential's "- log|det|" out of a separate launch
+            logp, offset = out if isinstance(out, tuple) else (out, None)
+            logp = logp.reshape(-1).to(torch.float32).contiguous()
             if logp.numel() != C:
                 raise ValueError(f"log_prob_fn returned {logp.numel()} values for {C} chains")
             u = torch.rand(C, 4 + D, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.sbi_amd_mcmc_slice_tick(C, D, int(num_samples), self.tuning, max_width, _lib.ptr(logp),
-                                                 _lib.ptr(u), _lib.ptr(x), _lib.ptr(nxt), _lib.ptr(width),
+                                                 _lib.ptr(offset), _lib.ptr(u), _lib.ptr(x), _lib.ptr(nxt),
+                                                 _lib.ptr(width),
                                                  _lib.ptr(order), _lib.ptr(istate), _lib.ptr(fstate),
                                                  _lib.ptr(samples), _lib.ptr(done), _lib.current_stream(dev))
             _lib.check(rc, "mcmc_slice_tick")

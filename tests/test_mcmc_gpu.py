@@ -173,7 +173,7 @@ def test_tick_kernel_matches_tensorised_restatement_bit_for_bit():
         u = torch.rand(C, 4 + D, device=dev)
         logp = f(nxt).contiguous()
         assert torch.equal(logp, f(st["nxt"]))
-        rc = lib.sbi_amd_mcmc_slice_tick(C, D, NS, TUNE, MAXW, _lib.ptr(logp), _lib.ptr(u), _lib.ptr(x), _lib.ptr(nxt),
+        rc = lib.sbi_amd_mcmc_slice_tick(C, D, NS, TUNE, MAXW, _lib.ptr(logp), None, _lib.ptr(u), _lib.ptr(x), _lib.ptr(nxt),
                                          _lib.ptr(width), _lib.ptr(order), _lib.ptr(istate), _lib.ptr(fstate),
                                          _lib.ptr(samples), _lib.ptr(done), _lib.current_stream(torch.device(dev)))
         assert rc == 0

@@ -47,6 +47,9 @@ def test_loss_and_param_grad_match_autograd(cfg):
     gref = oracle_flat_grad(oracle, est)
 
     stepper = FusedTrainStep(est, distributed=False)
+    # the workspace is torch.empty memory: whatever the kernels do not write themselves (wave-tiles past the
+    # last row) must not leak into the result -- poison it
+    stepper._workspace(n).fill_(float("nan"))
     losses = stepper.loss_and_grad(theta.cuda(), x.cuda())
     torch.cuda.synchronize()
     got = stepper.grad.cpu()
