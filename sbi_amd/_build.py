@@ -43,6 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    flags += os.environ.get("SBI_AMD_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DNSF_PRIO_MODE=1)
 
     def compile_one(src: str):
         obj = objdir / (Path(src).stem + ".o")
