@@ -98,6 +98,12 @@ template int launch_bwd_k<10>(const NsfPlan&, const TrainPlan&, int, const float
 extern template int launch_bwd_k<5>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
                               const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
                               long long*, hipStream_t);
+extern template int launch_bwd_k<4>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
+                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
+                              long long*, hipStream_t);
+extern template int launch_bwd_k<16>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
+                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
+                              long long*, hipStream_t);
 extern template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
                               const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
                               long long*, hipStream_t);
@@ -157,7 +163,7 @@ extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const f
 #define CASE_K(KK) \
   case KK: rc = launch_bwd_k<KK>(pl, tp, t, packed, zstats, z_in, x, up, row_weight, uniform_weight, n, x_rows, dn, \
                                  partial, grad_theta_out, astash, (t == 0 && getenv("SBI_AMD_TIMELINE")) ? dbg : nullptr, st); break;
-      CASE_K(5) CASE_K(8) CASE_K(10)
+      CASE_K(4) CASE_K(5) CASE_K(8) CASE_K(10) CASE_K(16)
 #undef CASE_K
       default: rc = SBI_AMD_E_UNSUPPORTED;
     }

@@ -1,0 +1,8 @@
+// nsf_train_k16.hip -- num_bins = 16 instantiations of the backward kernel.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "nsf_train_kernel.h"
+
+template int launch_bwd_k<16>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
+                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
+                              long long*, hipStream_t);

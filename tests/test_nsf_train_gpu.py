@@ -26,6 +26,8 @@ CONFIGS = [
     dict(D=5, C=3, hidden_features=50, num_transforms=2),
     dict(D=4, C=4, num_bins=8, num_transforms=2),
     dict(D=6, C=2, num_bins=5, hidden_features=40, num_transforms=3),
+    dict(D=4, C=3, num_bins=4, num_transforms=2),
+    dict(D=5, C=4, num_bins=16, num_transforms=2),
     dict(D=1, C=3),
     # seed 2: with seed 1, row 91 enters the last transform exactly ON an fp32 knot, where the spline's second
     # derivative (hence d loss/d params) is two-valued and either bin is a correct answer
