@@ -87,40 +87,58 @@ __device__ __forceinline__ void pack_lu(float* __restrict__ img, const float* __
     img[S.l_U + idx] = u;
     img[S.l_L + idx] = l;
   }
-  // explicit inverses for the sampling direction (D <= 16): one thread per column, substitution in
-  // double, so the inverse pass is two dense mat-vecs instead of a serial per-row triangular solve
-  if (S.l_Ui >= 0 && tid < 16) {
-    const int c = tid;
-    auto Lm = [&](int i, int k) -> double { return (double)lower[i * (i - 1) / 2 + k]; };                 // k < i
-    auto Um = [&](int i, int k) -> double {                                                                 // k >= i
-      return k == i ? (double)(softplus_f(udiag[i]) + eps) : (double)upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
-    };
-    double xl[16], xu[16];
-    for (int i = 0; i < 16; ++i) { xl[i] = 0.0; xu[i] = 0.0; }
-    if (c < D) {
-      xl[c] = 1.0;
-      for (int i = c + 1; i < D; ++i) {
-        double a = 0.0;
-        for (int k = c; k < i; ++k) a -= Lm(i, k) * xl[k];
-        xl[i] = a;
-      }
-      xu[c] = 1.0 / Um(c, c);
-      for (int i = c - 1; i >= 0; --i) {
-        double a = 0.0;
-        for (int k = i + 1; k <= c; ++k) a -= Um(i, k) * xu[k];
-        xu[i] = a / Um(i, i);
-      }
-    }
-    for (int i = 0; i < 16; ++i) {
-      img[S.l_Li + i * 16 + c] = (float)xl[i];
-      img[S.l_Ui + i * 16 + c] = (float)xu[i];
-    }
-  }
   for (int idx = tid; idx < D; idx += nthreads) img[S.l_lub + idx] = bias[idx];
   if (tid == 0) {   // logabsdet of the LULinear = sum_i log(softplus(u_i) + eps)
     float a = 0.f;
     for (int i = 0; i < D; ++i) a += logf(softplus_f(udiag[i]) + eps);
     img[S.l_lub + D] = a;
+  }
+}
+
+// Explicit inverses for the sampling direction (D <= 16), by ONE workgroup: the 16 x 16 factors go through
+// LDS once (softplus on the diagonal evaluated D times, not D^3), then one thread per column substitutes in
+// double -- the inverse pass becomes two dense mat-vecs instead of a serial per-row triangular solve.
+__device__ __forceinline__ void pack_lu_inverse(float* __restrict__ img, const float* __restrict__ gl,
+                                                const ShapeDesc& S, int D, float eps, int ltid, int lthreads) {
+  __shared__ float sU[256], sL[256];
+  const int ntri = D * (D - 1) / 2;
+  const float* lower = gl + S.g_lu;
+  const float* upper = lower + ntri;
+  const float* udiag = upper + ntri;
+  for (int idx = ltid; idx < 256; idx += lthreads) {
+    const int i = idx >> 4, k = idx & 15;
+    float u = 0.f, l = 0.f;
+    if (i < D && k < D) {
+      if (k > i) u = upper[i * D - i * (i + 1) / 2 + (k - i - 1)];
+      else if (k == i) { u = softplus_f(udiag[i]) + eps; l = 1.f; }
+      else l = lower[i * (i - 1) / 2 + k];
+    }
+    sU[idx] = u;
+    sL[idx] = l;
+  }
+  __syncthreads();
+  __shared__ double xl[16][17], xu[16][17];   // [row][column]: dynamically indexed, so LDS rather than scratch
+  if (ltid < 16) {
+    const int c = ltid;
+    for (int i = 0; i < 16; ++i) { xl[i][c] = 0.0; xu[i][c] = 0.0; }
+    if (c < D) {
+      xl[c][c] = 1.0;
+      for (int i = c + 1; i < D; ++i) {
+        double a = 0.0;
+        for (int k = c; k < i; ++k) a -= (double)sL[i * 16 + k] * xl[k][c];
+        xl[i][c] = a;
+      }
+      xu[c][c] = 1.0 / (double)sU[c * 16 + c];
+      for (int i = c - 1; i >= 0; --i) {
+        double a = 0.0;
+        for (int k = i + 1; k <= c; ++k) a -= (double)sU[i * 16 + k] * xu[k][c];
+        xu[i][c] = a / (double)sU[i * 16 + i];
+      }
+    }
+    for (int i = 0; i < 16; ++i) {
+      img[S.l_Li + i * 16 + c] = (float)xl[i][c];
+      img[S.l_Ui + i * 16 + c] = (float)xu[i][c];
+    }
   }
 }
 

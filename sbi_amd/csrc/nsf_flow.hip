@@ -7,8 +7,14 @@
 __global__ void __launch_bounds__(512)
 nsf_pack_kernel(const NsfPlan pl, const float* __restrict__ params, float* __restrict__ packed) {
   const int t = blockIdx.x;
-  pack_layer(packed + (long long)t * pl.img_floats, params + pl.g_layer[t], pl, pl.shape[t & 1],
-             blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
+  const ShapeDesc& S = pl.shape[pl.ctx_mlp ? 0 : (t & 1)];
+  float* img = packed + (long long)t * pl.img_floats;
+  if (blockIdx.y == gridDim.y - 1 && S.l_Ui >= 0) {   // one workgroup of the row does the LU inverses instead
+    pack_lu_inverse(img, params + pl.g_layer[t], S, pl.D, pl.lu_eps, threadIdx.x, blockDim.x);
+    return;
+  }
+  const int packers = S.l_Ui >= 0 ? gridDim.y - 1 : gridDim.y;
+  pack_layer(img, params + pl.g_layer[t], pl, S, blockIdx.y * blockDim.x + threadIdx.x, packers * blockDim.x);
 }
 
 
