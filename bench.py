@@ -126,10 +126,10 @@ def timed(step, steps, warmup, device, dist=None):
 
 
 # HBM bytes per step at batch 65 536 from the separate rocprofv3 --pmc passes of this same command
-# (profiles/r1b_pmc_summary.txt: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch, summed over the step's
+# (profiles/r1c_pmc_summary.txt: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch, summed over the step's
 # kernels).  bench.py cannot run the profiler on itself, so these are the committed measurements; they are
 # only attached when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"log_prob": 10.7e6, "train": 1.7e9, "sample": None}
+PROFILED_TRAFFIC = {"log_prob": 9.6e6, "train": 1.7e9, "sample": None}
 
 
 def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
@@ -138,7 +138,7 @@ def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
     out = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "device_ms_per_step": dev_ms / steps}
     if traffic is not None:
-        out["traffic_source"] = "profiles/r1b_pmc_summary.txt (bytes per step)"
+        out["traffic_source"] = "profiles/r1c_pmc_summary.txt (bytes per step)"
     return out
 
 
