@@ -157,7 +157,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # SBI_AMD_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, all-reduce, barrier) with one rank
+    distributed = world > 1 or (os.environ.get("SBI_AMD_FORCE_DIST") == "1" and "RANK" in os.environ)
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
