@@ -133,3 +133,23 @@ def test_two_round_training_uses_atomic_loss(capsys):
         inf.train(num_atoms=5, training_batch_size=50, max_num_epochs=1, discard_prior_samples=True,
                   resume_training=False)
     assert inf.train_indices.numel() == int(0.9 * 200)
+
+
+def test_atomic_loss_matches_the_real_reference_method():
+    """Fixture from tools/make_golden_atomic.py: NPE_C._log_prob_proposal_posterior_atomic of the reference tree
+    run on an analytic conditional Gaussian, with the choices torch.multinomial drew."""
+    import os
+
+    from tools.make_golden_atomic import GaussianRegression   # the tiny estimator only; no reference import
+
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "atomic_reference.pt"), weights_only=False)
+    est = GaussianRegression(g["D"], g["C"])
+    est.load_state_dict(g["state"])
+    prior = torch.distributions.MultivariateNormal(torch.zeros(g["D"]), 2.0 * torch.eye(g["D"]))
+    for combined in (False, True):
+        ref = g["out"][combined]
+        lpp = atomic.log_prob_proposal_posterior_atomic(est, prior, g["theta"], g["x"], g["masks"], g["A"], combined,
+                                                        choices=ref["choices"])
+        assert torch.allclose(lpp, ref["lpp"], atol=1e-5, rtol=1e-5)
+        grads = torch.autograd.grad(-lpp.sum(), list(est.parameters()))
+        assert all(torch.allclose(a, b, atol=1e-4, rtol=1e-4) for a, b in zip(grads, ref["grads"]))
