@@ -606,23 +606,36 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
 // ---- LULinear on the per-wave state rows (nflows transforms/lu.py) ----------
 // dense D x D mat-vec on a per-wave row buffer for D <= 16: the row is pulled into registers
 // first and every LDS read is independent, so the loads pipeline instead of forming one
-// latency-bound chain per element.  out[ii] = sum_k M[i][k] v[k], i = g + 4 ii.
+// latency-bound chain per element (mat-vec itself: dense_mv16c below).
 // The per-wave row buffers are followed by further finite scratch, and M is zero padded to
 // 16 x 16, so neither needs a bounds check: entries past D meet a zero.
 __device__ __forceinline__ void row_to_regs16(const float* __restrict__ row, int D, float (&v)[16]) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) v[k] = row[k];
 }
+// 16 x 16 mat-vec with CONTIGUOUS outputs per lane group: out[ii] = sum_k M(4g + ii, k) v[k]
+// (TRANSPOSED: M(i,k) = m[k][i], a float4 per k; else M(i,k) = m[i][k], four float4 per output).
+// m is zero padded to 16 x 16 and 16-byte aligned (nsf_plan.cpp).
 template <bool TRANSPOSED>
-__device__ __forceinline__ void dense_mv16(const float* __restrict__ M, int D, const float (&v)[16], int g,
-                                           float (&out)[4]) {
+__device__ __forceinline__ void dense_mv16c(const float* __restrict__ m, const float (&v)[16], int g, float (&out)[4]) {
 #pragma unroll
-  for (int ii = 0; ii < 4; ++ii) {
-    const int i = g + 4 * ii;
-    float a = 0.f;
+  for (int ii = 0; ii < 4; ++ii) out[ii] = 0.f;
+  if (TRANSPOSED) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a = fmaf(TRANSPOSED ? M[k * 16 + i] : M[i * 16 + k], v[k], a);
-    out[ii] = a;
+    for (int k = 0; k < 16; ++k) {
+      const f4 w = *(const f4*)(m + k * 16 + 4 * g);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) out[ii] = fmaf(w[ii], v[k], out[ii]);
+    }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const f4 w = *(const f4*)(m + (4 * g + ii) * 16 + 4 * k4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[ii] = fmaf(w[u], v[4 * k4 + u], out[ii]);
+      }
   }
 }
 
@@ -631,19 +644,20 @@ __device__ __forceinline__ void lu_forward(const float* __restrict__ lds, const 
                                            const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
   const int D = pl.D;
   const int LUS = D <= 16 ? 16 : D;
-  if (D <= 16) {
+  if (D <= 16) {   // lane group g computes the contiguous dims 4g .. 4g+3: matrix rows as float4 reads
     float v[16], o[4];
     row_to_regs16(zs + id.j * pl.ZW, D, v);
-    dense_mv16<false>(lds + S.l_U, D, v, id.g, o);
+    dense_mv16c<false>(lds + S.l_U, v, id.g, o);
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
-      if (id.g + 4 * ii < D) us[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+      if (4 * id.g + ii < D) us[id.j * pl.ZW + 4 * id.g + ii] = o[ii];
     wave_lds_fence();
     row_to_regs16(us + id.j * pl.ZW, D, v);
-    dense_mv16<false>(lds + S.l_L, D, v, id.g, o);
+    dense_mv16c<false>(lds + S.l_L, v, id.g, o);
+    wave_lds_fence();
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
-      if (id.g + 4 * ii < D) zs[id.j * pl.ZW + id.g + 4 * ii] = o[ii] + lds[S.l_lub + id.g + 4 * ii];
+      if (4 * id.g + ii < D) zs[id.j * pl.ZW + 4 * id.g + ii] = o[ii] + lds[S.l_lub + 4 * id.g + ii];
     wave_lds_fence();
     return;
   }
@@ -669,16 +683,17 @@ __device__ __forceinline__ void lu_inverse(const float* __restrict__ lds, const 
     float v[16], o[4];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = zs[id.j * pl.ZW + k] - (k < D ? lds[S.l_lub + k] : 0.f);
-    dense_mv16<false>(lds + S.l_Li, D, v, id.g, o);
+    dense_mv16c<false>(lds + S.l_Li, v, id.g, o);
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
-      if (id.g + 4 * ii < D) us[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+      if (4 * id.g + ii < D) us[id.j * pl.ZW + 4 * id.g + ii] = o[ii];
     wave_lds_fence();
     row_to_regs16(us + id.j * pl.ZW, D, v);
-    dense_mv16<false>(lds + S.l_Ui, D, v, id.g, o);
+    dense_mv16c<false>(lds + S.l_Ui, v, id.g, o);
+    wave_lds_fence();
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
-      if (id.g + 4 * ii < D) zs[id.j * pl.ZW + id.g + 4 * ii] = o[ii];
+      if (4 * id.g + ii < D) zs[id.j * pl.ZW + 4 * id.g + ii] = o[ii];
     wave_lds_fence();
     return;
   }

@@ -166,32 +166,6 @@ __device__ __forceinline__ void load_D(const float* __restrict__ st, int SA, int
     for (int r = 0; r < 4; ++r) v[mt][r] = st[row * SA + 16 * mt + 4 * r + id.g];
 }
 
-// 16 x 16 mat-vec with CONTIGUOUS outputs per lane group: out[ii] = sum_k M(4g + ii, k) v[k]
-// (TRANSPOSED: M(i,k) = m[k][i], a float4 per k; else M(i,k) = m[i][k], four float4 per output).
-// m is zero padded to 16 x 16 and 16-byte aligned (nsf_plan.cpp).
-template <bool TRANSPOSED>
-__device__ __forceinline__ void dense_mv16c(const float* __restrict__ m, const float (&v)[16], int g, float (&out)[4]) {
-#pragma unroll
-  for (int ii = 0; ii < 4; ++ii) out[ii] = 0.f;
-  if (TRANSPOSED) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const f4 w = *(const f4*)(m + k * 16 + 4 * g);
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii) out[ii] = fmaf(w[ii], v[k], out[ii]);
-    }
-  } else {
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const f4 w = *(const f4*)(m + (4 * g + ii) * 16 + 4 * k4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) out[ii] = fmaf(w[u], v[4 * k4 + u], out[ii]);
-      }
-  }
-}
-
 // Rendezvous of the four grad waves only (the row waves are busy in their own phase): LDS counter,
 // monotonically increasing; `target` = 4 x (number of rendezvous so far).  DS ops of a wave execute
 // in order, so the tile reads issued before the increment have completed when it lands.
