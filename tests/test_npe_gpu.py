@@ -106,3 +106,35 @@ def test_sample_1m_draws_direct_posterior():
     post = DirectPosterior(est, prior, device="cuda").set_default_x(torch.zeros(1, 10))
     s = post.sample((1_000_000,), max_sampling_batch_size=1_000_000, show_progress_bars=False)
     assert s.shape == (1_000_000, 10) and bool(prior.support.check(s).all())
+
+
+def test_reference_ci_scenario_nsf_npe_c_dim4_wall_time():
+    """tests/linearGaussian_snpe_test.py:156-200 with density_estimator="nsf", NPE_C: theta-dim 4, 2 500
+    simulations, batch 100, train to convergence, 1 000 posterior samples, C2ST near chance.  The reference's CI
+    records 41.7 s for this test on a GitHub CPU runner (.test_durations:2075)."""
+    import time
+
+    dim, n = 4, 2500
+    torch.manual_seed(0)
+    shift, cov = -1.0 * torch.ones(dim), 0.3 * torch.eye(dim)
+    prior = MultivariateNormal(torch.zeros(dim, device="cuda"), torch.eye(dim, device="cuda"))
+    x_o = torch.zeros(1, dim)
+    target = true_posterior_linear_gaussian_mvn_prior(x_o, shift, cov, torch.zeros(dim), torch.eye(dim)).sample((1000,))
+    theta = prior.sample((n,)).cpu()
+    x = linear_gaussian(theta, shift, cov)
+    torch.manual_seed(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inf = NPE(prior=prior, density_estimator=NSFConfig(), device="cuda", show_progress_bars=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est = inf.append_simulations(theta, x).train(training_batch_size=100)
+    from sbi_amd.inference import DirectPosterior
+
+    post = DirectPosterior(prior=prior, posterior_estimator=est).set_default_x(x_o)
+    samples = post.sample((1000,), show_progress_bars=False).cpu()
+    wall = time.perf_counter() - t0
+    score = c2st(samples, target).item()
+    print(f"reference CI scenario: wall {wall:.2f} s (reference CI: 41.7 s), epochs {inf.summary['epochs_trained'][-1]}, "
+          f"c2st {score:.3f}")
+    assert 0.4 <= score <= 0.6
