@@ -156,7 +156,10 @@ __device__ __forceinline__ void pack_layer(float* __restrict__ img, const float*
   pack_linear(img, gl, S.lin[S.fin], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
   if (!pl.ctx_mlp) pack_lu(img, gl, S, pl.D, pl.lu_eps, tid, nthreads);
   else for (int idx = S.l_U + tid; idx < S.l_lub + pl.D + 1; idx += nthreads) img[idx] = 0.f;
-  for (int idx = S.l_lub + pl.D + 1 + tid; idx < pl.img_floats; idx += nthreads) img[idx] = 0.f;
+  // zero the padding behind the LU bias -- but not the explicit inverses a different workgroup writes
+  const int inv_lo = S.l_Ui >= 0 ? S.l_Ui : pl.img_floats, inv_hi = S.l_Ui >= 0 ? S.l_Li + 256 : pl.img_floats;
+  for (int idx = S.l_lub + pl.D + 1 + tid; idx < pl.img_floats; idx += nthreads)
+    if (idx < inv_lo || idx >= inv_hi) img[idx] = 0.f;
 }
 
 // stage one layer's image into LDS: coalesced 16-byte copies, all loads issued first

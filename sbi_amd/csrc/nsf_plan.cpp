@@ -100,10 +100,14 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
     { const int lus = D <= 16 ? 16 : D;   // dense U, L padded to 16 x 16 for D <= 16
       l = round_up(l, 4);   // 16-byte aligned: the backward kernel reads matrix rows as float4
       s->l_U = l; l += lus * lus;
-      s->l_L = l; l += lus * lus;
-      s->l_Ui = s->l_Li = -1;
-      if (!ctx_mlp && D <= 16) { s->l_Ui = l; l += 256; s->l_Li = l; l += 256; } }
+      s->l_L = l; l += lus * lus; }
     s->l_lub = l; l += D + 1;   // bias, then sum_i log U_ii
+    // everything above is what the training kernels stage; the explicit inverses (sampling direction only)
+    // come last so that the backward kernel can leave them out of its LDS image
+    l = round_up(l, 4);
+    if (l > pl->lds_w_train_floats) pl->lds_w_train_floats = l;
+    s->l_Ui = s->l_Li = -1;
+    if (!ctx_mlp && D <= 16) { s->l_Ui = l; l += 256; s->l_Li = l; l += 256; }
     s->lds_floats = round_up(l + 8, 4);
     if (s->lds_floats > pl->lds_w_floats) pl->lds_w_floats = s->lds_floats;
   }

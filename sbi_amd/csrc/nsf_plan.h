@@ -56,6 +56,7 @@ struct NsfPlan {
   int n_params;
   int img_floats;               // floats per layer in the packed weight image (= lds_w_floats)
   int lds_w_floats;             // LDS weight image size (max over parities)
+  int lds_w_train_floats;       // its prefix without the explicit LU inverses: what the backward kernel stages
   // per-wave scratch (float offsets relative to the wave's scratch base)
   int ZW, CW, CINW, PSW, DS, DCH;
   int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_pst2, sc_total;

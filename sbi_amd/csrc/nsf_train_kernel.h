@@ -22,7 +22,6 @@
 #define TR_GRID_MAX 256    // persistent workgroups (one per CU)
 #define TR_SA 68           // row stride of the gradient tiles A0/A1
 #define TR_SB 68           // row stride of the activation tile B (column-interleaved, see stage_DB)
-#define TR_SS 48           // row stride of the static conditioner-input tile Bs
 #define TR_LDK_FAST 50     // image row stride of the default hidden_features = 50: compiled-in fast path
 #ifndef TR_LA
 #define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
@@ -63,14 +62,22 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   }
   tp->SA = TR_SA;
   tp->SB = TR_SB;
-  tp->SS = TR_SS;   // [z_id ; context ; 1 ; 0...]: d W0 reads columns [0, 32), d Wc columns [d_id, d_id + 32)
+  {   // Bs row = [z_id ; context ; 1 ; 0...]: d W0 reads columns [0, 16 nt0), d Wc columns [d_id, d_id + 16 ntc).
+      // Stride = 8 (mod 16) keeps the four g groups of a read on (mostly) different banks.
+    const int in0max = d_id_max + pl.C;
+    const int nt0 = (in0max + 1 + 15) / 16, ntc = (pl.C + 1 + 15) / 16;
+    int need = 16 * nt0 > d_id_max + 16 * ntc ? 16 * nt0 : d_id_max + 16 * ntc;
+    tp->SS = (need + 7) / 8 * 8;
+    if (tp->SS % 16 == 0) tp->SS += 8;
+  }
   int w = 0;
   tp->w_zs = w; w += 16 * pl.ZW;
   tp->w_gys = w; w += 16 * pl.ZW;
   tp->w_gzs = w; w += 16 * pl.ZW;
-  tp->w_total = (w + 8 + 3) / 4 * 4;   // + slack: the 16-wide row reads run past a ZW-float row
+  tp->w_total = (w + 16 + 3) / 4 * 4;  // + slack: a 16-wide read of the LAST row of the LAST array runs 16 - ZW
+                                       // floats past it; unwritten LDS there could hold NaN (NaN x 0 = NaN)
   {
-    int o = pl.lds_w_floats;
+    int o = pl.lds_w_train_floats;   // the explicit LU inverses at the image tail are not staged
     tp->o_A0 = o; o += TR_ROWS * tp->SA;
     tp->o_A1 = o; o += TR_ROWS * tp->SA;
     tp->o_B = o; o += TR_ROWS * tp->SB;
@@ -149,6 +156,37 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
       load_b((s + LA) % (LA + 1), s + LA);
     }
     // pin the order: hipcc otherwise sinks every load next to its MFMA (load, wait, 2 MFMAs, load, ...)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      if (nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the same with a run-time activation-side stride (the small static tile Bs: d W0, d Wc)
+template <int NT, int SA>
+__device__ __forceinline__ void dw_gemm_rs(const float* __restrict__ Ast, const float* __restrict__ Bst, int SBr,
+                                           int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT,
+                                           int abl = 0) {
+  if (abl & 1) return;
+  constexpr int KS = TR_ROWS / 4, LA = TR_LA;
+  const float* ap = Ast + id.g * SA + acol0 + id.j;
+  const float* bp = Bst + id.g * SBr + bcol0 + id.j;
+  float a[LA + 1], b[LA + 1][NT];
+#pragma unroll
+  for (int u = 0; u < LA; ++u) {
+    a[u] = ap[4 * u * SA];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[u][nt] = bp[4 * u * SBr + 16 * nt];
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + LA < KS) {
+      a[(s + LA) % (LA + 1)] = ap[4 * (s + LA) * SA];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[(s + LA) % (LA + 1)][nt] = bp[4 * (s + LA) * SBr + 16 * nt];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -507,14 +545,15 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   const int par = cm ? 0 : (t & 1);
   const ShapeDesc& S = pl.shape[par];
   const int D = pl.D, C = pl.C;
-  constexpr int SA = TR_SA, SB = TR_SB, SS = TR_SS;
+  constexpr int SA = TR_SA, SB = TR_SB;
+  const int SS = tp.SS;
   const bool is_last = (t == pl.T - 1);
   float* Bt = lds + tp.o_B;
   float* Bs = lds + tp.o_Bs;
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
-  stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, blockDim.x);
+  stage_layer(lds, packed + (long long)t * pl.img_floats, pl.lds_w_train_floats, tid, blockDim.x);
   if (tid == 0) *(int*)(lds + tp.o_cnt) = 0;
   if (tid < 32) {
     lds[tp.o_xs + tid] = tid < C ? x_mean[tid] : 0.f;
@@ -604,10 +643,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           float v = (k == S.in0) ? 1.f : 0.f;
           v = (c >= 0 && c < C) ? ctx : v;
           v = (k < S.d_id) ? zid : v;
-          Bs[trow * SS + k] = v;
+          if (k < SS) Bs[trow * SS + k] = v;
         }
-#pragma unroll
-        for (int u = 8; u < 12; ++u) Bs[trow * SS + id.g + 4 * u] = 0.f;
+        for (int k = 32 + id.g; k < SS; k += 4) Bs[trow * SS + k] = 0.f;
       }
       // ---- LULinear backward wrt its input (needs no forward values): g_u = L^T g_z, g_y = U^T g_u
       float gus_r[4] = {0.f, 0.f, 0.f, 0.f};     // g_u of dims 4 g + ii, kept for the LU parameter gradients
@@ -888,7 +926,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           __syncthreads();                         // X1
           TS(21 + 8 * b);
           dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
-          dw_gemm<NTW, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
+          dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
           TS(22 + 8 * b);
           __syncthreads();                         // X2
           __syncthreads();                         // X3
@@ -901,7 +939,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       __syncthreads();                             // Y1
       TS(41);
       fetch_hl(tile_nxt);   // next tile's h_last: lands under this tile's last two phases
-      dw_gemm<NTW, TR_SA, TR_SS>(lds + o_AX, Bs, 16 * gw, 0, id, acc0, nt0, pl.ablate);
+      dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, 0, id, acc0, nt0, pl.ablate);
       TS(42);
       __syncthreads();                             // Y2
       if (gw < 2 && !cm) dw_gemm<1, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 16 * gw, id, accLU);
