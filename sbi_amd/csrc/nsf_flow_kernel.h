@@ -44,6 +44,12 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
 
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
   float cr[4] = {0.f, 0.f, 0.f, 0.f};   // standardized context of this lane (C <= 16)
+  if (pl.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): start from NaN-filled LDS, so that any read of a
+    // location the kernel did not write itself shows up in the results
+    const int total = pl.lds_w_floats + nw * pl.sc_total;
+    for (int i = tid; i < total; i += nthreads) lds[i] = __builtin_nanf("");
+    __syncthreads();
+  }
   for (int i = id.lane; i < pl.sc_total; i += 64) sc[i] = 0.f;   // no uninitialised LDS behind short rows
   // ---- load + z-score (PointwiseAffineTransform fwd / Standardize) ----
   {

@@ -553,6 +553,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
+  if (pl.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): NaN-filled LDS exposes reads of unwritten locations
+    for (int i = tid; i < tp.lds_floats; i += blockDim.x) lds[i] = __builtin_nanf("");
+    __syncthreads();
+  }
   stage_layer(lds, packed + (long long)t * pl.img_floats, pl.lds_w_train_floats, tid, blockDim.x);
   if (tid == 0) *(int*)(lds + tp.o_cnt) = 0;
   if (tid < 32) {
