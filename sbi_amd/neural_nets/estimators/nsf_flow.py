@@ -225,7 +225,7 @@ def packed_weights(net: NSFNet) -> Tensor:
     if n < 0:
         _lib.check(int(n), "nsf_packed_floats")
     packed = cache[1] if (cache is not None and cache[1].device == dev and cache[1].numel() == n) else \
-        torch.empty(int(n), dtype=torch.float32, device=dev)
+        torch.zeros(int(n), dtype=torch.float32, device=dev)   # alignment gaps of the image are never written
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_pack(cfg, _lib.ptr(fp), _lib.ptr(packed), _lib.current_stream(dev))
     _lib.check(rc, "nsf_pack")
