@@ -100,14 +100,17 @@ int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const
  * grad_out (P floats, OVERWRITTEN), w_n = row_weight[n] or `uniform_weight`
  * when row_weight is NULL (1/B gives the gradient of the batch mean,
  * trainers/base.py:1178-1181).  grad_theta_out (n,D) optional: w_n * d loss_n /
- * d theta_n (needed by MAP / gradient_ascent, base_posterior.py:216-323).
+ * d theta_n (needed by MAP / gradient_ascent, base_posterior.py:216-323).  grad_x_out (n,C) optional, needs
+ * x_rows == n: w_n * d loss_n / d x_n, the gradient a trainable embedding net in front of the flow
+ * back-propagates (flow.py:1395-1416 puts `standardizing_net -> embedding_net` there).
  * `workspace` must hold sbi_amd_nsf_train_workspace_floats(cfg, n) floats. */
 int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n);
 int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
                              const float* zstats,
                              const float* theta, const float* x, int64_t n, int64_t x_rows,
                              const float* row_weight, float uniform_weight, float* loss_out,
-                             float* grad_out, float* grad_theta_out, float* workspace, void* stream);
+                             float* grad_out, float* grad_theta_out, float* grad_x_out, float* workspace,
+                             void* stream);
 
 /* The same pass in two calls, for losses whose row weights depend on the log-probabilities themselves
  * (the atomic proposal-posterior loss of multi-round NPE-C, npe_c.py:356-440: w = d loss / d log p needs the
@@ -120,7 +123,7 @@ int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const float* packed
 int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
                                const float* zstats, const float* x, int64_t n, int64_t x_rows,
                                const float* row_weight, float uniform_weight, float* grad_out,
-                               float* grad_theta_out, float* workspace, void* stream);
+                               float* grad_theta_out, float* grad_x_out, float* workspace, void* stream);
 
 /* Fused global-norm clip + Adam on the flat buffer: replaces
  * clip_grad_norm_(max_norm) + torch.optim.Adam.step (trainers/base.py:1181-1187,

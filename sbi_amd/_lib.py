@@ -57,7 +57,7 @@ _SIGNATURES = {
     "sbi_amd_nsf_loss_fwd_bwd": (
         c_int,
         [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_nsf_train_forward": (
         c_int,
@@ -67,7 +67,7 @@ _SIGNATURES = {
     "sbi_amd_nsf_train_backward": (
         c_int,
         [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
-         c_void_p, c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_adam_clip_step": (
         c_int,

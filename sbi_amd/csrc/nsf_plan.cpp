@@ -186,5 +186,5 @@ extern "C" int64_t sbi_amd_nsf_lu_offset(const sbi_amd_nsf_config* cfg, int32_t 
   if (t < 0 || t >= pl.T) return SBI_AMD_E_BADARG;
   return pl.g_layer[t] + pl.shape[t & 1].g_lu;
 }
-extern "C" int sbi_amd_nsf_abi_version(void) { return 100; }
+extern "C" int sbi_amd_nsf_abi_version(void) { return 101; }
 extern "C" const char* sbi_amd_nsf_arch(void) { return "gfx950"; }

@@ -137,15 +137,17 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
 extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
                                           const float* zstats, const float* x, int64_t n, int64_t x_rows,
                                           const float* row_weight, float uniform_weight, float* grad_out,
-                                          float* grad_theta_out, float* workspace, void* stream) {
+                                          float* grad_theta_out, float* grad_x_out, float* workspace, void* stream) {
   if (!cfg || !params || !packed || !zstats || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
     return SBI_AMD_E_BADARG;
+  if (grad_x_out && x_rows != n) return SBI_AMD_E_BADARG;   // one context row per theta row (no reduction here)
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, TR_NW, &pl);
   if (rc) return rc;
   TrainPlan tp;
   rc = build_train_plan(pl, n, &tp);
   if (rc) return rc;
+  tp.grad_x = grad_x_out;
   hipStream_t st = (hipStream_t)stream;
   int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
   const int64_t ws_total = ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
@@ -178,8 +180,8 @@ extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const f
 extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
                                         const float* zstats, const float* theta, const float* x, int64_t n,
                                         int64_t x_rows, const float* row_weight, float uniform_weight,
-                                        float* loss_out, float* grad_out, float* grad_theta_out, float* workspace,
-                                        void* stream) {
+                                        float* loss_out, float* grad_out, float* grad_theta_out, float* grad_x_out,
+                                        float* workspace, void* stream) {
   if (!cfg || !params || !packed || !zstats || !theta || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
     return SBI_AMD_E_BADARG;
   int rc = sbi_amd_nsf_train_forward(cfg, packed, zstats, theta, x, n, x_rows, nullptr, workspace, stream);
@@ -194,5 +196,5 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
                        workspace + o_logp, loss_out, (long long)n);
   }
   return sbi_amd_nsf_train_backward(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
-                                    grad_theta_out, workspace, stream);
+                                    grad_theta_out, grad_x_out, workspace, stream);
 }

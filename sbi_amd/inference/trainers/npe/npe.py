@@ -320,7 +320,12 @@ class PosteriorEstimatorTrainer:
         val_idx = self.val_indices.to(self._device)
         rank, world = self._rank_world()
 
-        fused = (isinstance(net, NSFFlow) and torch.device(self._device).type == "cuda" and calibration_kernel is None)
+        # the fused optimizer step owns ONE flat parameter buffer: an embedding net with trainable weights takes the
+        # autograd path (bridge kernels incl. d loss / d embedded x + torch Adam over all parameters)
+        emb_trainable = any(p.requires_grad for p in net.embedding_net.parameters()) \
+            if getattr(net, "embedding_net", None) is not None else False
+        fused = (isinstance(net, NSFFlow) and torch.device(self._device).type == "cuda" and calibration_kernel is None
+                 and not emb_trainable)
         if not cfg.resume_training or (fused and self._stepper is None) or (not fused and self.optimizer is None):
             if fused:
                 from sbi_amd.inference.trainers.fused import FusedTrainStep

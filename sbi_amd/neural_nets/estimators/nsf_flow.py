@@ -273,8 +273,10 @@ def _sample_call(net: NSFNet, noise: Tensor, x: Tensor, want_ld: bool) -> Tuple[
 
 
 def loss_fwd_bwd(net: NSFNet, theta: Tensor, x: Tensor, row_weight: Optional[Tensor], uniform_weight: float,
-                 grad_out: Tensor, want_grad_theta: bool = False, workspace: Optional[Tensor] = None):
-    """Fused training pass: returns (per-row loss, grad_theta|None); fills grad_out (P,)."""
+                 grad_out: Tensor, want_grad_theta: bool = False, workspace: Optional[Tensor] = None,
+                 grad_x_out: Optional[Tensor] = None):
+    """Fused training pass: returns (per-row loss, grad_theta|None); fills grad_out (P,) and, if given, grad_x_out
+    (n, C: one context row per theta row)."""
     dev = _lib.require_device(theta, x, net.flat_params, net.zstats, grad_out, row_weight)
     lib = _lib.load()
     n = theta.shape[0]
@@ -291,7 +293,7 @@ def loss_fwd_bwd(net: NSFNet, theta: Tensor, x: Tensor, row_weight: Optional[Ten
         rc = lib.sbi_amd_nsf_loss_fwd_bwd(
             cfg, _lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
             _lib.ptr(row_weight), float(uniform_weight), _lib.ptr(loss), _lib.ptr(grad_out), _lib.ptr(gtheta),
-            _lib.ptr(workspace), _lib.current_stream(dev),
+            _lib.ptr(grad_x_out), _lib.ptr(workspace), _lib.current_stream(dev),
         )
     _lib.check(rc, "nsf_loss_fwd_bwd")
     return loss, gtheta
@@ -326,7 +328,7 @@ def train_forward(net: NSFNet, theta: Tensor, x: Tensor, workspace: Tensor) -> T
 
 
 def train_backward(net: NSFNet, x: Tensor, n: int, row_weight: Tensor, grad_out: Tensor, workspace: Tensor,
-                   want_grad_theta: bool = False) -> Optional[Tensor]:
+                   want_grad_theta: bool = False, grad_x_out: Optional[Tensor] = None) -> Optional[Tensor]:
     """Second half: grad_out (P,) = d( sum_n w_n * (-log p_n) ) / d params from the stash `train_forward` left."""
     dev = _lib.require_device(x, net.flat_params, net.zstats, grad_out, row_weight, workspace)
     lib = _lib.load()
@@ -335,8 +337,8 @@ def train_backward(net: NSFNet, x: Tensor, n: int, row_weight: Tensor, grad_out:
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_train_backward(
             net.hyper.c_config(), _lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(x), n,
-            x.shape[0], _lib.ptr(row_weight), 0.0, _lib.ptr(grad_out), _lib.ptr(gtheta), _lib.ptr(workspace),
-            _lib.current_stream(dev),
+            x.shape[0], _lib.ptr(row_weight), 0.0, _lib.ptr(grad_out), _lib.ptr(gtheta), _lib.ptr(grad_x_out),
+            _lib.ptr(workspace), _lib.current_stream(dev),
         )
     _lib.check(rc, "nsf_train_backward")
     return gtheta
@@ -374,29 +376,54 @@ class _NSFLogProbFn(torch.autograd.Function):
             raise RuntimeError("NSF parameters were modified in place between log_prob() and backward().")
         gparams = torch.empty_like(net.flat_params)
         w = (-grad_logp).contiguous().to(torch.float32)
+        gx = None
+        if ctx.needs_input_grad[1]:
+            if x.shape[0] != ctx.n:
+                raise RuntimeError("gradient wrt the condition needs one condition row per theta row")
+            gx = torch.empty_like(x)
         if not ctx.stashed:   # ws holds theta here: the one-call form raises the configuration error
-            _, gtheta = loss_fwd_bwd(net, ws, x, w, 0.0, gparams, want_grad_theta=ctx.needs_input_grad[0])
-            return gtheta, None, (gparams if ctx.needs_input_grad[2] else None), None
+            _, gtheta = loss_fwd_bwd(net, ws, x, w, 0.0, gparams, want_grad_theta=ctx.needs_input_grad[0],
+                                     grad_x_out=gx)
+            return gtheta, gx, (gparams if ctx.needs_input_grad[2] else None), None
         # kernel gradients are already weighted by w_n = -dL/dlogp_n
-        gtheta = train_backward(net, x, ctx.n, w, gparams, ws, want_grad_theta=ctx.needs_input_grad[0])
-        return gtheta, None, (gparams if ctx.needs_input_grad[2] else None), None
+        gtheta = train_backward(net, x, ctx.n, w, gparams, ws, want_grad_theta=ctx.needs_input_grad[0],
+                                grad_x_out=gx)
+        return gtheta, gx, (gparams if ctx.needs_input_grad[2] else None), None
 
 
 class NSFFlow(ConditionalDensityEstimator):
     r"""Neural Spline Flow :math:`p(\theta|x)` evaluated by the gfx950 kernels."""
 
-    def __init__(self, net: NSFNet, input_shape: torch.Size, condition_shape: torch.Size) -> None:
+    def __init__(self, net: NSFNet, input_shape: torch.Size, condition_shape: torch.Size,
+                 embedding_net: Optional[nn.Module] = None) -> None:
         super().__init__(net, input_shape=input_shape, condition_shape=condition_shape)
-        if len(torch.Size(input_shape)) != 1 or len(torch.Size(condition_shape)) != 1:
+        if len(torch.Size(input_shape)) != 1 or (len(torch.Size(condition_shape)) != 1 and embedding_net is None):
             raise NotImplementedError(
-                "sbi_amd NSF kernels take 1-D theta and (embedded) x events; embedding nets "
-                "are outside this path (SURVEY.md section 2 row 19)."
+                "sbi_amd NSF kernels take 1-D theta events and 1-D (embedded) x features; pass an embedding_net "
+                "for structured x."
             )
         self.net: NSFNet
+        # `standardizing_net -> embedding_net` in front of the flow (flow.py:1395-1416): ordinary PyTorch; the
+        # kernels consume its (B, C) output and return d loss / d output for autograd
+        self._embedding_net = embedding_net
 
     @property
     def embedding_net(self) -> nn.Module:
-        return nn.Identity()
+        return nn.Identity() if self._embedding_net is None else self._embedding_net
+
+    @property
+    def _cdim(self) -> int:
+        """feature width the kernels see"""
+        return self.net.hyper.C
+
+    def _embed(self, condition: Tensor) -> Tensor:
+        """(..., *condition_shape) -> (..., C)"""
+        if self._embedding_net is None:
+            return condition
+        nd = len(self.condition_shape)
+        lead = condition.shape[: condition.dim() - nd]
+        e = self._embedding_net(condition.reshape(-1, *self.condition_shape).float())
+        return e.reshape(*lead, self._cdim)
 
     # -- helpers ---------------------------------------------------------------------
     def _flatten_pair(self, input: Tensor, condition: Tensor) -> Tuple[Tensor, Tensor, int, int]:
@@ -407,16 +434,22 @@ class NSFFlow(ConditionalDensityEstimator):
         input, S, B, cond_has_sample = self._broadcast_dims(input, condition)
         D = self.input_shape[0]
         theta = input.expand(S, B, D).reshape(S * B, D)
+        emb = self._embed(condition)                      # (…, C): identity without an embedding net
         if cond_has_sample:
-            x = condition.expand(S, B, *self.condition_shape).reshape(S * B, self.condition_shape[0])
+            x = emb.expand(S, B, self._cdim).reshape(S * B, self._cdim)
         else:
-            x = condition.reshape(condition.shape[0], self.condition_shape[0])   # (1|B, C): n % x_rows does the broadcast
+            x = emb.reshape(emb.shape[0], self._cdim)     # (1|B, C): n % x_rows does the broadcast
+        if x.requires_grad and torch.is_grad_enabled() and x.shape[0] != S * B:
+            # the kernels return d loss / d x per theta row: give every row its own condition row and let
+            # autograd sum the copies
+            x = x[torch.arange(S * B, device=x.device) % x.shape[0]]
         return theta.contiguous().float(), x.contiguous().float(), S, B
 
     # -- estimator surface -----------------------------------------------------------
     def log_prob(self, input: Tensor, condition: Tensor, **kwargs) -> Tensor:
         theta, x, S, B = self._flatten_pair(input, condition)
-        needs_grad = torch.is_grad_enabled() and (theta.requires_grad or self.net.flat_params.requires_grad)
+        needs_grad = torch.is_grad_enabled() and (theta.requires_grad or x.requires_grad
+                                                  or self.net.flat_params.requires_grad)
         if needs_grad:
             lp = _NSFLogProbFn.apply(theta, x, self.net.flat_params, self.net)
         else:
@@ -430,16 +463,18 @@ class NSFFlow(ConditionalDensityEstimator):
         self._check_condition_shape(condition)
         bshape = torch.broadcast_shapes(input.shape[:-1], condition.shape[: condition.dim() - 1])
         theta = input.expand(bshape + (input.shape[-1],)).reshape(-1, input.shape[-1]).contiguous().float()
-        x = condition.expand(bshape + self.condition_shape).reshape(-1, self.condition_shape[0]).contiguous().float()
         with torch.no_grad():
+            emb = self._embed(condition)
+            x = emb.expand(bshape + (self._cdim,)).reshape(-1, self._cdim).contiguous().float()
             _, noise = _log_prob_call(self.net, theta, x, want_noise=True)
         return noise.reshape(bshape + (noise.shape[-1],))
 
     def sample_from_noise(self, noise: Tensor, condition: Tensor, with_logabsdet: bool = False):
         """theta = transform^{-1}(noise | condition); noise (N,D), condition (1|N, C)."""
         with torch.no_grad():
+            emb = self._embed(condition)
             theta, ld = _sample_call(self.net, noise.contiguous().float(),
-                                     condition.reshape(condition.shape[0], self.condition_shape[0]).contiguous().float(), with_logabsdet)
+                                     emb.reshape(emb.shape[0], self._cdim).contiguous().float(), with_logabsdet)
         return (theta, ld) if with_logabsdet else theta
 
     def sample(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tensor:

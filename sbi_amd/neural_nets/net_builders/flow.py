@@ -2,8 +2,9 @@
 
 Drop-in for sbi/neural_nets/net_builders/flow.py:333-460 restricted to what the
 HIP path implements: ResidualNet-conditioned RQ-spline couplings with linear
-tails + LULinear, alternating masks, z-scoring of both sides, identity
-embedding.  Unsupported options raise instead of silently degrading.
+tails + LULinear, alternating masks, z-scoring of both sides, optional embedding
+net in front (plain PyTorch; the kernels return the gradient wrt its output).
+Unsupported options raise instead of silently degrading.
 """
 
 from __future__ import annotations
@@ -54,11 +55,6 @@ def build_nsf(
         z_score_x, "build_nsf",
         "Use one of 'none', 'independent', 'structured'.",
     )
-    if not isinstance(embedding_net, nn.Identity):
-        raise NotImplementedError(
-            "sbi_amd.build_nsf: embedding nets are outside the accelerated path (SURVEY.md section 2 "
-            "row 19); embed x first and pass the embedded features."
-        )
     if dropout_probability != 0.0 or use_batch_norm:
         raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
     x_numel = batch_x[0].numel()
@@ -68,8 +64,28 @@ def build_nsf(
             "sbi_amd.build_nsf: the 1-D theta conditioner (ContextSplineMap, flow.py:1419-1478) is implemented "
             "for hidden_layers_spline_context=1 (the reference default)."
         )
-    if batch_x[0].dim() != 1 or batch_y[0].dim() != 1:
-        raise NotImplementedError("sbi_amd.build_nsf: theta and x events must be 1-D")
+    has_embedding = not isinstance(embedding_net, nn.Identity)
+    if batch_x[0].dim() != 1 or (batch_y[0].dim() != 1 and not has_embedding):
+        raise NotImplementedError("sbi_amd.build_nsf: theta events must be 1-D (and x events too unless an "
+                                  "embedding net maps them to feature vectors)")
+    embedding = None
+    if has_embedding:
+        # flow.py:1395-1416 (`get_embedding_net`): standardizing_net(batch_y) -> embedding_net runs in front of
+        # the flow as ordinary PyTorch modules; the kernels see the embedded features and hand back d loss / d
+        # features (grad_x_out) so the embedding trains through autograd.  No second z-scoring in the kernel.
+        zy, structured_y = z_score_parser(z_score_y)
+        mods = []
+        if zy:
+            mean, std = standardizing_stats(batch_y.detach().cpu().float(), structured_y)
+            mods.append(Standardize(mean, std))
+        mods.append(embedding_net)
+        embedding = nn.Sequential(*mods)
+        with torch.no_grad():
+            emb_out = embedding.to(batch_y.device)(batch_y[:2].float())
+        if emb_out.dim() != 2:
+            raise ValueError(f"The embedding net must return (batch, features); got shape {tuple(emb_out.shape)}")
+        y_numel = emb_out.shape[1]          # get_numel(batch_y, embedding_net=...) (nn_utils.py:17-47)
+        z_score_y = "none"
 
     D, C = x_numel, y_numel
     zstats = torch.cat([torch.zeros(D), torch.ones(D), torch.zeros(C), torch.ones(C)])
@@ -88,4 +104,16 @@ def build_nsf(
     hyper = NSFHyper(D=D, C=C, hidden_features=hidden_features, num_transforms=num_transforms,
                      num_bins=num_bins, num_blocks=num_blocks, tail_bound=float(tail_bound))
     net = NSFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy, dtype=kwargs.get("dtype", torch.float32))
-    return NSFFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape)
+    return NSFFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape, embedding_net=embedding)
+
+
+class Standardize(nn.Module):
+    """sbi/utils/sbiutils.py:418-428."""
+
+    def __init__(self, mean: Tensor, std: Tensor):
+        super().__init__()
+        self.register_buffer("_mean", torch.as_tensor(mean, dtype=torch.float32))
+        self.register_buffer("_std", torch.as_tensor(std, dtype=torch.float32))
+
+    def forward(self, tensor: Tensor) -> Tensor:
+        return (tensor - self._mean) / self._std

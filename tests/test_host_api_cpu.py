@@ -58,8 +58,11 @@ def test_builder_rejects_what_the_hip_path_does_not_implement():
     with pytest.raises(NotImplementedError):
         build_nsf(theta[:, :1], x, hidden_layers_spline_context=2)
     assert build_nsf(theta[:, :1], x).net.hyper.ctx_mlp
-    with pytest.raises(NotImplementedError):
-        build_nsf(theta, x, embedding_net=torch.nn.Linear(7, 3))
+    emb = build_nsf(theta, x, embedding_net=torch.nn.Linear(7, 3))       # embedded features feed the kernels
+    assert emb.net.hyper.C == 3 and emb.condition_shape == torch.Size([7])
+    assert not emb.net.z_score_x and isinstance(emb.embedding_net[0], torch.nn.Module)   # Standardize -> Linear
+    with pytest.raises(ValueError, match="batch, features"):
+        build_nsf(theta, x, embedding_net=torch.nn.Unflatten(1, (7, 1)))
     with pytest.raises(ValueError, match="Invalid z-scoring"):
         build_nsf(theta, x, z_score_y="bogus")
 
