@@ -275,34 +275,38 @@ __device__ __forceinline__ void gemm_T_breg(const float* __restrict__ lds, const
   else gemm_T_breg_ldk<KS, MT, 0>(lds, L, id, gb, acc);
 }
 
-// Gradient wrt the conditioner INPUT through a context layer Wc (C -> H): like gemm_T_breg, but the result is
-// produced in conditioner-input coordinates (slot f = d_id + c), so that it accumulates into the same
-// fragments as W0^T g_h0 and one pass writes d loss / d context.
-template <int KS, int MT>
-__device__ __forceinline__ void gemm_T_ctx(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
-                                           const f4 (&gb)[NSF_HT], f4 (&acc)[MT], int d_id) {
-  const float* base[MT];
+// d loss / d context contribution of one linear layer whose input contains the context at columns
+// [col0, col0 + C) (Wc: col0 = 0; W0: col0 = d_id): part = W[:, col0 + c]^T g for this wave's 16 rows, produced in
+// CONTEXT coordinates (slot = c) so that every contribution to grad_x[row][c] is made by the same lane and the
+// read-modify-writes of one launch are ordered by program order.  Only runs when the caller asked for grad_x.
+template <int KS>
+__device__ __forceinline__ void ctx_grad_update(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                                const f4 (&gb)[NSF_HT], int col0, int C, const float* __restrict__ xs,
+                                                float* __restrict__ grad_x_row, bool valid, bool overwrite) {
+  const float* base[2];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int c = 16 * mt + id.iperm - d_id;
-    base[mt] = lds + L.l_w + id.g * L.ldk + ((c >= 0 && c < L.in) ? c : 0);
+  for (int mt = 0; mt < 2; ++mt) {
+    const int c = 16 * mt + id.iperm;
+    base[mt] = lds + L.l_w + id.g * L.ldk + (c < C ? col0 + c : 0);
   }
   const int kstride = 4 * L.ldk;
-  f4 part[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) part[mt] = {0.f, 0.f, 0.f, 0.f};
+  f4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const float bv = gb[s >> 2][s & 3];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) part[mt] = MFMA16(base[mt][s * kstride], bv, part[mt]);
+    for (int mt = 0; mt < 2; ++mt) part[mt] = MFMA16(base[mt][s * kstride], bv, part[mt]);
   }
+  if (!valid) return;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = 16 * mt + 4 * r + id.g - d_id;
-      acc[mt][r] += (c >= 0 && c < L.in) ? part[mt][r] : 0.f;
+      const int c = 16 * mt + 4 * r + id.g;
+      if (c < C) {
+        const float v = part[mt][r] * xs[32 + c];     // through the kernel's own z-scoring: d c / d x = 1 / std
+        grad_x_row[c] = overwrite ? v : grad_x_row[c] + v;
+      }
     }
 }
 
@@ -760,11 +764,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       f4 gh[NSF_HT];
       load_D(lds + o_AX, SA, trow, id, gh);
       wave_lds_fence();
-      // d loss / d (conditioner input) of this transform, conditioner-input coordinates [z_id ; context]:
-      // W0^T g_h0 (always needed for the identity dims) + sum_b Wc_b^T g_c (only when the caller wants
-      // the gradient wrt the context, i.e. trains an embedding net)
-      f4 gcin[2] = {zero4, zero4};
+      // the caller trains an embedding net in front of the flow: also produce d loss / d context (launches run
+      // last -> first transform on one stream: the first contribution of the first launch overwrites)
       const bool want_gx = tp.grad_x != nullptr;
+      float* gx_row = want_gx ? tp.grad_x + (valid ? row : 0) * C : nullptr;
       {   // next tile's inputs (the last tile re-reads itself: harmless)
         const int nxt = tile + (int)gridDim.x;
         fetch_inputs(nxt < tp.ntiles ? nxt : tile, id);
@@ -805,7 +808,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
               }
             stage_D(lds + o_AY, SA, trow, id, ga, false);
             stage_D(lds + o_AX, SA, trow, id, gc, false);
-            if (want_gx) gemm_T_ctx<KSH, 2>(lds, S.lin[1 + 3 * b], id, gc, gcin, S.d_id);
+            if (want_gx)
+              ctx_grad_update<KSH>(lds, S.lin[1 + 3 * b], id, gc, 0, C, xs, gx_row, valid, is_last && b == NB - 1);
           }
           stage_DB(Bt, SB, trow, id, bt1, true);
           if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;      // bias column
@@ -850,37 +854,17 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       TS(40);
       __syncthreads();                             // Y1
       TS(41);
-      if (!want_gx) {
+      {
         f4 gin[1];
         gin[0] = zero4;
         gemm_T_breg<KSH, 1>(lds, L0, id, gh, gin, pl.ablate);
-        gcin[0] = gin[0];
-      } else {
-        f4 gin[2] = {zero4, zero4};
-        gemm_T_breg<KSH, 2>(lds, L0, id, gh, gin, pl.ablate);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gcin[mt][r] += gin[mt][r];
+        for (int r = 0; r < 4; ++r) {
+          const int k = 4 * r + id.g;     // identity feature slot
+          if (k < S.d_id) gys[id.j * pl.ZW + 2 * k + (1 - par)] += gin[0][r];
+        }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 4 * r + id.g;     // identity feature slot
-        if (k < S.d_id) gys[id.j * pl.ZW + 2 * k + (1 - par)] += gcin[0][r];
-      }
-      if (want_gx && valid) {   // context slots -> d loss / d x (raw x: through the kernel's own z-scoring)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * mt + 4 * r + id.g - S.d_id;
-            if (c >= 0 && c < C) {
-              float* dst = tp.grad_x + row * C + c;
-              const float v = gcin[mt][r] * xs[32 + c];
-              *dst = is_last ? v : *dst + v;      // launches run last -> first transform on one stream
-            }
-          }
-      }
+      if (want_gx) ctx_grad_update<KSH>(lds, L0, id, gh, S.d_id, C, xs, gx_row, valid, is_last && cm);
       // ---- LULinear parameter gradients as two more 16x16 tiles (AY / B are free after Y1):
       //   d U = g_u (x) y (+ the logabsdet row),  d L = g_z (x) u,  d bias = sum g_z
       if (!cm) {
