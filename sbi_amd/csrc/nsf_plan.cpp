@@ -93,6 +93,9 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
       }
       s->fin = 1 + 3 * NB;
     }
+    l = round_up(l, 4);   // the final layer (+ LU) is staged on its own by the backward kernel's overlay mode
+    if (l > pl->hidden_img_floats) pl->hidden_img_floats = l;
+    s->final_off = l;
     set_lin(&s->lin[s->fin], &g, &l, s->d_tr * pl->P, H, s->d_tr * 16 * pl->PT, pl->KSH);
     s->g_lu = g;
     if (!ctx_mlp) g += D * (D - 1) + 2 * D;   // lower, upper, unconstrained diag, bias

@@ -38,6 +38,7 @@ struct ShapeDesc {   // one per mask parity (even / odd transform index)
   int g_lu;                   // LULinear block offset relative to the layer block
   int l_U, l_L, l_lub;        // LDS offsets of expanded U[D][D], L[D][D], bias[D]
   int l_Ui, l_Li;             // explicit inverses U^-1, L^-1 (16 x 16, D <= 16 only; else -1)
+  int final_off;              // image offset (multiple of 4) where the final layer, U, L, LU bias start
   int n_params;               // floats in this layer block
   int lds_floats;             // size of the LDS image
 };
@@ -57,6 +58,7 @@ struct NsfPlan {
   int img_floats;               // floats per layer in the packed weight image (= lds_w_floats)
   int lds_w_floats;             // LDS weight image size (max over parities)
   int lds_w_train_floats;       // its prefix without the explicit LU inverses: what the backward kernel stages
+  int hidden_img_floats;        // its prefix up to the final layer (max over parities): the hidden-layer images
   // per-wave scratch (float offsets relative to the wave's scratch base)
   int ZW, CW, CINW, PSW, DS, DCH;
   int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_pst2, sc_total;

@@ -38,6 +38,8 @@ struct TrainPlan {
   int PLP;                 // floats per (workgroup, transform) partial-gradient slab
   int grid, ntiles;
   int lds_floats;
+  int overlay;             // 1: the weight region holds [final layer + LU] during the chunk steps and the hidden
+                           //    layers during the block phase (re-staged per tile) because both do not fit at once
   float* grad_x;           // optional output (n, C): d(sum w loss)/d x, accumulated over the transforms' launches
 };
 
@@ -77,8 +79,15 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   tp->w_gzs = w; w += 16 * pl.ZW;
   tp->w_total = (w + 16 + 3) / 4 * 4;  // + slack: a 16-wide read of the LAST row of the LAST array runs 16 - ZW
                                        // floats past it; unwritten LDS there could hold NaN (NaN x 0 = NaN)
-  {
-    int o = pl.lds_w_train_floats;   // the explicit LU inverses at the image tail are not staged
+  for (int ov = 0; ov < 2; ++ov) {
+    // ov = 0: the whole training image (explicit LU inverses at its tail excluded) stays resident;
+    // ov = 1: one region, sized for the larger of [hidden layers] and [final layer + LU], re-staged per tile
+    const int fin_min = pl.shape[0].final_off < pl.shape[1].final_off ? pl.shape[0].final_off : pl.shape[1].final_off;
+    int o = ov ? (pl.hidden_img_floats > pl.lds_w_train_floats - fin_min ? pl.hidden_img_floats
+                                                                         : pl.lds_w_train_floats - fin_min)
+               : pl.lds_w_train_floats;
+    o = (o + 3) / 4 * 4;
+    tp->overlay = ov;
     tp->o_A0 = o; o += TR_ROWS * tp->SA;
     tp->o_A1 = o; o += TR_ROWS * tp->SA;
     tp->o_B = o; o += TR_ROWS * tp->SB;
@@ -87,6 +96,7 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
     tp->o_xs = o; o += 64;
     tp->o_wave = o;
     tp->lds_floats = tp->o_wave + TR_NW * tp->w_total;
+    if (4ll * tp->lds_floats <= NSF_LDS_LIMIT_BYTES) break;
   }
   if (4ll * tp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
   int pmax = pl.shape[0].n_params > pl.shape[1].n_params ? pl.shape[0].n_params : pl.shape[1].n_params;
@@ -594,7 +604,14 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     for (int i = tid; i < tp.lds_floats; i += blockDim.x) lds[i] = __builtin_nanf("");
     __syncthreads();
   }
-  stage_layer(lds, packed + (long long)t * pl.img_floats, pl.lds_w_train_floats, tid, blockDim.x);
+  // Overlay mode (shapes whose whole image does not fit next to the tiles): the weight region holds
+  // [final layer, U, L] during the chunk steps and the hidden layers during the block phase, re-staged every
+  // tile; `ldsF` makes the final-layer / LU offsets of the plan valid in either mode.
+  const bool ov = tp.overlay != 0;
+  const float* img = packed + (long long)t * pl.img_floats;
+  const int F0 = ov ? S.final_off : 0;
+  const float* ldsF = lds - F0;
+  if (!ov) stage_layer(lds, img, pl.lds_w_train_floats, tid, blockDim.x);
   if (tid == 0) *(int*)(lds + tp.o_cnt) = 0;
   if (tid < 32) {
     lds[tp.o_xs + tid] = tid < C ? x_mean[tid] : 0.f;
@@ -657,6 +674,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
       const int trow = arow0 + id.j;
       __syncthreads();                             // S0: weights staged / previous tile fully consumed
+      if (ov) {
+        stage_layer(lds, img + F0, pl.lds_w_train_floats - F0, tid, blockDim.x);
+        __syncthreads();
+      }
       TS(0);
       // ---- P0: state, context, upstream gradient (prefetched) -> LDS
       {
@@ -695,13 +716,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       } else if (!(pl.ablate & 64)) {
         float v[16], o[4];
         row_to_regs16(gzs + id.j * pl.ZW, D, v);
-        dense_mv16c<true>(lds + S.l_L, v, id.g, gus_r);
+        dense_mv16c<true>(ldsF + S.l_L, v, id.g, gus_r);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
           if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = gus_r[ii];
         wave_lds_fence();
         row_to_regs16(gys + id.j * pl.ZW, D, v);
-        dense_mv16c<true>(lds + S.l_U, v, id.g, o);
+        dense_mv16c<true>(ldsF + S.l_U, v, id.g, o);
         wave_lds_fence();
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
@@ -756,10 +777,14 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       if (!cm && !(pl.ablate & 64)) {
         float v[16];
         row_to_regs16(zs + id.j * pl.ZW, D, v);
-        dense_mv16c<false>(lds + S.l_U, v, id.g, us_r);
+        dense_mv16c<false>(ldsF + S.l_U, v, id.g, us_r);
       }
       TS(8);
       __syncthreads();                             // H: g_h = Wf^T g_p of this wave's rows is in AX
+      if (ov) {   // nobody needs the final layer / LU any more this tile: the hidden layers take the region
+        stage_layer(lds, img, S.final_off, tid, blockDim.x);
+        __syncthreads();
+      }
       TS(9);
       f4 gh[NSF_HT];
       load_D(lds + o_AX, SA, trow, id, gh);
@@ -930,12 +955,16 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const int trow = 16 * gw + id.j;             // rows of the partner row wave
       const int tile_nxt = tile + (int)gridDim.x < tp.ntiles ? tile + (int)gridDim.x : tile;
       __syncthreads();                             // S0
+      if (ov) {
+        stage_layer(lds, img + F0, pl.lds_w_train_floats - F0, tid, blockDim.x);
+        __syncthreads();
+      }
       TS(0);
       // ---- prologue: h_last of the partner's rows (stash, D-fragment order = MFMA B operand; requested
       // during the previous tile), its activation-tile rows, and the spline parameters of chunk 0
       stage_DB(Bt, SB, trow, id, hl, false);
       if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
-      if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(lds, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
+      if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(ldsF, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
       f4 gh[NSF_HT];
   #pragma unroll
       for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
@@ -950,19 +979,23 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
             const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
             dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate);
             TS(13 + k);
-            if (!(pl.ablate & 2)) wft_chunk<PT>(lds, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
+            if (!(pl.ablate & 2)) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
           }
           TS(3 + 2 * k);
           if (k + 1 < nch) {
             if (k >= 1) { sync_target += 4; grad_wave_sync(cnt, sync_target, id.lane); }   // all d Wf reads of that tile done
             TS(17 + k);
             if (!(pl.ablate & 32))
-              final_layer_chunk_T<PT, KSH>(lds, lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, pl, tp, S, id,
+              final_layer_chunk_T<PT, KSH>(ldsF, lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, pl, tp, S, id,
                                            hl, (k + 1) * DCHB);
           }
           if (k == nch) stage_D(lds + o_AX, SA, trow, id, gh, false);   // hand g_h to the partner row wave
           TS(4 + 2 * k);
           __syncthreads();                         // K_{k+1} / H
+          if (ov && k == nch) {                    // mirrors the row waves: hidden layers take the weight region
+            stage_layer(lds, img, S.final_off, tid, blockDim.x);
+            __syncthreads();
+          }
         }
       }
       if (cm) {

@@ -29,6 +29,12 @@ CONFIGS = [
     dict(D=4, C=3, num_bins=4, num_transforms=2),
     dict(D=5, C=4, num_bins=16, num_transforms=2),
     dict(D=1, C=3),
+    # shapes whose weight image only fits LDS in the backward kernel's overlay mode (final layer + LU and the
+    # hidden layers take turns in one region)
+    dict(D=12, C=10, num_transforms=2),
+    dict(D=15, C=20, num_transforms=3),
+    dict(D=10, C=10, hidden_features=60, num_transforms=2),
+    dict(D=13, C=4, num_bins=8, num_transforms=2),
     # seed 2: with seed 1, row 91 enters the last transform exactly ON an fp32 knot, where the spline's second
     # derivative (hence d loss/d params) is two-valued and either bin is a correct answer
     dict(D=1, C=7, hidden_features=32, num_transforms=3, seed=2),
