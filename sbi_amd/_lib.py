@@ -37,6 +37,15 @@ class NSFConfigC(Structure):
     ]
 
 
+class FMPEConfigC(Structure):
+    """Mirror of ``struct sbi_amd_fmpe_config`` (include/sbi_amd_fmpe.h)."""
+
+    _fields_ = [
+        ("D", c_int32), ("C", c_int32), ("H", c_int32), ("L", c_int32), ("E", c_int32),
+        ("max_freq", c_float), ("noise_scale", c_float), ("ln_eps", c_float),
+    ]
+
+
 _SIGNATURES = {
     "sbi_amd_nsf_param_count": (c_int64, [POINTER(NSFConfigC)]),
     "sbi_amd_nsf_layer_offset": (c_int64, [POINTER(NSFConfigC), c_int32]),
@@ -82,6 +91,26 @@ _SIGNATURES = {
     "sbi_amd_mcmc_to_constrained": (
         c_int,
         [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_fmpe_param_count": (c_int64, [POINTER(FMPEConfigC)]),
+    "sbi_amd_fmpe_param_offset": (c_int64, [POINTER(FMPEConfigC), c_int32, c_int32]),
+    "sbi_amd_fmpe_packed_floats": (c_int64, [POINTER(FMPEConfigC)]),
+    "sbi_amd_fmpe_pack": (c_int, [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p]),
+    "sbi_amd_fmpe_velocity": (
+        c_int,
+        [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_void_p],
+    ),
+    "sbi_amd_fmpe_loss": (
+        c_int,
+        [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+         c_void_p, c_void_p],
+    ),
+    "sbi_amd_fmpe_train_workspace_floats": (c_int64, [POINTER(FMPEConfigC), c_int64]),
+    "sbi_amd_fmpe_loss_fwd_bwd": (
+        c_int,
+        [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+         c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_nsf_abi_version": (c_int, []),
     "sbi_amd_nsf_arch": (c_char_p, []),

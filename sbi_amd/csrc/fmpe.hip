@@ -1,0 +1,926 @@
+// fmpe.hip -- FMPE (flow matching) vector-field MLP on gfx950: velocity, CFM loss, loss + gradients.
+//
+// Reference behaviour (restated in oracle/fmpe_oracle.py, pinned to the real classes by tests/golden):
+//   VectorFieldMLP.forward            sbi/neural_nets/net_builders/vector_field_nets.py:683-719
+//   FlowMatchingEstimator.forward/loss sbi/neural_nets/estimators/flowmatching_estimator.py:206-347
+//
+// Execution model
+//   * one wavefront owns 16 batch rows for the whole network.  Every dense layer runs on
+//     v_mfma_f32_16x16x4_f32 in the transposed form  Y^T = W X^T  (M = output feature, N = batch row,
+//     K = input feature): lane (c = lane&15, g = lane>>4) holds, per 16-feature block, the four features
+//     16*blk + 4*g + {0..3} of row c.  That is at once the D fragment a layer produces and the B fragment the
+//     next one consumes (K-step r of block kb uses k = 16*kb + 4*g + r on both operands), so activations
+//     never leave registers; bias, GELU, the time embedding, the skip connection and LayerNorm are applied to
+//     the accumulators in place.
+//   * weights are the A operand: one ds_read_b128 per lane (row 16*ob + c of the zero-padded image, columns
+//     16*kb + 4*g ..+3) feeds four MFMAs; row stride = 16*KB + 4 floats (stride/4 odd: conflict free).
+//     The images do not fit LDS together (sbi's default net: 352 KB), so a workgroup (4 waves, 64 rows) stages
+//     them group by group from L2; two workgroups per CU overlap one's staging with the other's MFMAs.
+//   * training: the forward kernel stashes what the backward needs (pre-activations, normalised LayerNorm
+//     outputs, network inputs) in 1 KB blocks [16 rows][16 features] -- one coalesced 16-byte store per lane.
+//     The backward kernel walks the layers in reverse with W^T images (dX chain, LayerNorm / GELU backward in
+//     registers) and stores each linear's output gradient G transposed ([feature][row]); the weight-gradient
+//     kernel then contracts G^T X over rows with both operands straight from L2 (A by 16-byte loads), one
+//     workgroup per (row chunk, linear), partial sums per chunk, deterministic reduce.  LayerNorm outputs
+//     are stashed normalised (s_hat); the reduce turns  M = G^T s_hat, db  into  dW = M*gamma + db (x) beta.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "../../include/sbi_amd_fmpe.h"
+#include "../../include/sbi_amd_nsf.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define FM_MAX_L 8
+#define FM_MAX_LIN (6 + FM_MAX_L)
+#define FM_THREADS 256
+#define FM_ROWS 64
+#define FM_FWD_GROUP_FLOATS 17920   // 70 KB of weight image per staging group (2 workgroups per CU)
+#define FM_BWD_GROUP_FLOATS 17920
+#define FM_DW_TILES 32              // wave-tiles (16 rows) per weight-gradient chunk
+
+enum { J_IN = 0, J_CT = 1, J_TM = 2, J_MA = 3, J_MB = 4, J_L0 = 5 };
+
+struct FmLin {
+  int out, in, OB, KB;          // natural dims, 16-blocks
+  int g_w, g_ld, g_b;           // flat buffer: W[o][i] at g_w + o*g_ld + i; bias at g_b (-1: none)
+  int w_off, ldk, lw, lb;       // forward image: packed offset, row stride; LDS offsets of W / bias inside its group
+  int t_off, ldt, ltw, ltg;     // backward image (W^T [in][out]): packed offset, stride; LDS offsets of W^T / gamma
+  int fg_first, fg_off, fg_floats;   // forward staging group that starts at this linear
+  int bg_first, bg_off, bg_floats;   // backward staging group that starts at this linear
+  int s_x, s_g;                 // stash slots (in blocks): X natural, G transposed
+  int x_gelu;                   // X = GELU(stashed pre-activation)
+  int ln_fix;                   // >= 0: X was s_hat of that layer; dW = M*gamma + db (x) beta
+};
+
+struct FmPlan {
+  int D, C, H, L, E, HB, DB, CB, EB, NL, P;
+  float noise_scale, ln_eps, log_max_freq_over_E;
+  FmLin lin[FM_MAX_LIN];
+  int g_ln;                      // flat offset of layers_norm.0.weight (then bias, then layer 1 ...)
+  int packed_floats;
+  int lds_fwd_floats, lds_bwd_floats;
+  // stash slots in blocks of 256 floats, per wave-tile
+  int s_in, s_c, s_te, s_ie, s_ce, s_h0, s_u, s_sh, s_rstd, s_diff;     // s_u + l*HB, s_sh + l*HB
+  int g_v, g_u, g_te, g_h0, g_ie, g_ce;
+  int SB;                        // blocks per wave-tile
+};
+
+static int round_up(int a, int m) { return (a + m - 1) / m * m; }
+
+static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
+  memset(pl, 0, sizeof(*pl));
+  const int D = cfg->D, C = cfg->C, H = cfg->H, L = cfg->L, E = cfg->E;
+  if (D < 1 || D > 128 || C < 1 || C > 128 || H < 16 || H > 128 || L < 1 || L > FM_MAX_L || E < 2 || E > 64 ||
+      (E & 1))
+    return SBI_AMD_E_UNSUPPORTED;
+  pl->D = D; pl->C = C; pl->H = H; pl->L = L; pl->E = E;
+  pl->HB = H <= 64 ? 4 : (H <= 112 ? 7 : 8);
+  pl->DB = (D + 15) / 16; pl->CB = (C + 15) / 16; pl->EB = (E + 15) / 16;
+  pl->NL = 6 + L;
+  pl->noise_scale = cfg->noise_scale; pl->ln_eps = cfg->ln_eps;
+  pl->log_max_freq_over_E = logf(cfg->max_freq) / (float)E;
+  const int HB = pl->HB;
+  // ---- flat offsets
+  int o = 0;
+  auto lin = [&](int j, int out, int in, int ld, int col0, bool bias) {
+    FmLin& l = pl->lin[j];
+    l.out = out; l.in = in; l.OB = j == pl->NL - 1 ? pl->DB : HB;
+    l.KB = j == J_IN ? pl->DB : j == J_CT ? pl->CB : j == J_TM ? pl->EB : HB;
+    l.g_ld = ld; l.g_w = o + col0; l.g_b = -1; l.ln_fix = -1;
+    if (bias) { l.g_b = o + out * ld; }
+  };
+  lin(J_IN, H, D, D, 0, true); o += H * D + H;
+  lin(J_CT, H, C, C, 0, true); o += H * C + H;
+  lin(J_MA, H, H, 2 * H, 0, true); lin(J_MB, H, H, 2 * H, H, false); o += 2 * H * H + H;
+  lin(J_TM, H, E, E, 0, true); o += H * E + H;
+  for (int l = 0; l < L; ++l) { lin(J_L0 + l, H, H, H, 0, true); o += H * H + H; }
+  pl->g_ln = o; o += 2 * H * L;
+  lin(J_L0 + L, D, H, H, 0, true); o += D * H + D;
+  pl->P = o;
+  // ---- stash slots
+  int s = 0;
+  pl->s_in = s; s += pl->DB; pl->s_c = s; s += pl->CB; pl->s_te = s; s += pl->EB;
+  pl->s_ie = s; s += HB; pl->s_ce = s; s += HB; pl->s_h0 = s; s += HB;
+  pl->s_u = s; s += L * HB; pl->s_sh = s; s += L * HB; pl->s_rstd = s; s += 1; pl->s_diff = s; s += pl->DB;
+  pl->g_v = s; s += pl->DB; pl->g_u = s; s += L * HB; pl->g_te = s; s += HB; pl->g_h0 = s; s += HB;
+  pl->g_ie = s; s += HB; pl->g_ce = s; s += HB;
+  pl->SB = s;
+  pl->lin[J_IN].s_x = pl->s_in; pl->lin[J_IN].s_g = pl->g_ie;
+  pl->lin[J_CT].s_x = pl->s_c; pl->lin[J_CT].s_g = pl->g_ce;
+  pl->lin[J_TM].s_x = pl->s_te; pl->lin[J_TM].s_g = pl->g_te;
+  pl->lin[J_MA].s_x = pl->s_ie; pl->lin[J_MA].s_g = pl->g_h0; pl->lin[J_MA].x_gelu = 1;
+  pl->lin[J_MB].s_x = pl->s_ce; pl->lin[J_MB].s_g = pl->g_h0; pl->lin[J_MB].x_gelu = 1;
+  for (int l = 0; l < L; ++l) {
+    FmLin& q = pl->lin[J_L0 + l];
+    q.s_g = pl->g_u + l * HB;
+    if (l == 0) { q.s_x = pl->s_h0; q.x_gelu = 1; } else { q.s_x = pl->s_sh + (l - 1) * HB; q.ln_fix = l - 1; }
+  }
+  pl->lin[J_L0 + L].s_x = pl->s_sh + (L - 1) * HB; pl->lin[J_L0 + L].s_g = pl->g_v; pl->lin[J_L0 + L].ln_fix = L - 1;
+  // ---- packed images.  forward order: IN MA CT MB TM L0.. OUT; image = W[16*OB][ldk] + bias, gamma, beta [16*OB]
+  const int order_n = pl->NL;
+  int fo[FM_MAX_LIN];
+  for (int j = 0; j < order_n; ++j) fo[j] = j;
+  fo[0] = J_IN; fo[1] = J_MA; fo[2] = J_CT; fo[3] = J_MB; fo[4] = J_TM;   // execution order of the forward kernel
+  int p = 0;
+  {
+    int gstart = 0, goff = 0;
+    for (int k = 0; k < order_n; ++k) {
+      FmLin& l = pl->lin[fo[k]];
+      l.ldk = 16 * l.KB + 4;
+      const int sz = round_up(16 * l.OB * l.ldk + 3 * 16 * l.OB, 4);
+      if (sz > FM_FWD_GROUP_FLOATS) return SBI_AMD_E_LDS;
+      if (k == 0 || p + sz - goff > FM_FWD_GROUP_FLOATS) {
+        if (k) { pl->lin[fo[gstart]].fg_floats = p - goff; }
+        gstart = k; goff = p; l.fg_first = 1; l.fg_off = p;
+      }
+      l.w_off = p; l.lw = p - goff; l.lb = l.lw + 16 * l.OB * l.ldk;
+      p += sz;
+      if (p - goff > pl->lds_fwd_floats) pl->lds_fwd_floats = p - goff;
+    }
+    pl->lin[fo[gstart]].fg_floats = p - goff;
+  }
+  // backward order: OUT L(L-1) .. L0 MA MB; image = W^T[16*KB][ldt] + gamma [16*OB]
+  {
+    int bo[FM_MAX_LIN], nb = 0;
+    bo[nb++] = J_L0 + L;
+    for (int l = L - 1; l >= 0; --l) bo[nb++] = J_L0 + l;
+    bo[nb++] = J_MA; bo[nb++] = J_MB;
+    int gstart = 0, goff = p;
+    for (int k = 0; k < nb; ++k) {
+      FmLin& l = pl->lin[bo[k]];
+      l.ldt = 16 * l.OB + 4;
+      const int sz = round_up(16 * l.KB * l.ldt + 16 * l.OB, 4);
+      if (sz > FM_BWD_GROUP_FLOATS) return SBI_AMD_E_LDS;
+      if (k == 0 || p + sz - goff > FM_BWD_GROUP_FLOATS) {
+        if (k) { pl->lin[bo[gstart]].bg_floats = p - goff; }
+        gstart = k; goff = p; l.bg_first = 1; l.bg_off = p;
+      }
+      l.t_off = p; l.ltw = p - goff; l.ltg = l.ltw + 16 * l.KB * l.ldt;
+      p += sz;
+      if (p - goff > pl->lds_bwd_floats) pl->lds_bwd_floats = p - goff;
+    }
+    pl->lin[bo[gstart]].bg_floats = p - goff;
+  }
+  pl->packed_floats = p;
+  return 0;
+}
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+__device__ __forceinline__ f4 gelu4(f4 v) { return f4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])}; }
+__device__ __forceinline__ f4 gelu_grad4(f4 v) {
+  return f4{gelu_grad_f(v[0]), gelu_grad_f(v[1]), gelu_grad_f(v[2]), gelu_grad_f(v[3])};
+}
+
+__device__ __forceinline__ void fm_stage(float* __restrict__ lds, const float* __restrict__ src, int floats, int tid) {
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(lds);
+  const int n4 = floats >> 2;
+  int idx = tid;
+  for (; idx + 3 * FM_THREADS < n4; idx += 4 * FM_THREADS) {
+    const float4 a = s4[idx], b = s4[idx + FM_THREADS], c = s4[idx + 2 * FM_THREADS], d = s4[idx + 3 * FM_THREADS];
+    d4[idx] = a; d4[idx + FM_THREADS] = b; d4[idx + 2 * FM_THREADS] = c; d4[idx + 3 * FM_THREADS] = d;
+  }
+  for (; idx < n4; idx += FM_THREADS) d4[idx] = s4[idx];
+}
+
+// stash blocks: natural [row][16 feats] (one b128 per lane) and transposed [feat][row]
+__device__ __forceinline__ void st_nat(float* __restrict__ wtb, int blk, int c, int g, f4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f4*>(wtb + blk * 256 + c * 16 + 4 * g));
+}
+__device__ __forceinline__ f4 ld_nat(const float* __restrict__ wtb, int blk, int c, int g) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f4*>(wtb + blk * 256 + c * 16 + 4 * g));
+}
+__device__ __forceinline__ void st_tr(float* __restrict__ wtb, int blk, int c, int g, f4 v) {
+  float* p = wtb + blk * 256 + (4 * g) * 16 + c;
+  p[0] = v[0]; p[16] = v[1]; p[32] = v[2]; p[48] = v[3];
+}
+
+// acc[ob] += W[16*ob.., 16*kb..] * (one 16-feature block of B held as f4)
+template <int OB>
+__device__ __forceinline__ void gemm_blk(const float* __restrict__ wl /* lds + lw + c*ld + 4*g */, int ld, int kb,
+                                         f4 b, f4 (&acc)[OB]) {
+  f4 a[OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) a[ob] = *reinterpret_cast<const f4*>(wl + ob * 16 * ld + 16 * kb);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) acc[ob] = MFMA16(a[ob][r], b[r], acc[ob]);
+}
+
+// acc[ob] += W * B for B = KB register blocks; A fragments of block kb+1 are loaded under the MFMAs of block kb
+template <int OB, int KB>
+__device__ __forceinline__ void gemm_rr(const float* __restrict__ wl, int ld, const f4 (&b)[KB], f4 (&acc)[OB]) {
+  f4 a[2][OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) a[0][ob] = *reinterpret_cast<const f4*>(wl + ob * 16 * ld);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+        a[(kb + 1) & 1][ob] = *reinterpret_cast<const f4*>(wl + ob * 16 * ld + 16 * (kb + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) acc[ob] = MFMA16(a[kb & 1][ob][r], b[kb][r], acc[ob]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ float sum_over_g(float v) {   // lanes c, c+16, c+32, c+48
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float sum_over_c(float v) {   // the 16 lanes of one g
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+
+struct FmArgs {
+  const float* packed; const float* zstats; const float* theta; const float* x; const float* times;
+  const float* noise; const float* row_weight; float uniform_weight;
+  long long n; int x_rows, t_rows;
+  float* loss_out; float* v_out; float* stash; float* ln_part;
+  int ntiles;
+};
+
+// LDS tail after the weight group: mean_0[D] std_0[D] vstd[D] xmean[C] xinv[C] (floats)
+#define FM_ZS_FLOATS (3 * 128 + 2 * 128)
+
+// ---------------------------------------------------------------- forward
+// MODE 0: velocity, 1: loss only, 2: loss + stash (training)
+template <int HB, int MODE>
+__global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, const FmArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  float* zs = lds + pl.lds_fwd_floats;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int D = pl.D, C = pl.C, H = pl.H;
+  float* z_mean = zs; float* z_std = zs + 128; float* z_vstd = zs + 256; float* z_xm = zs + 384; float* z_xi = zs + 512;
+  for (int i = tid; i < 128; i += FM_THREADS) {
+    const float m = i < D ? a.zstats[i] : 0.f, s = i < D ? a.zstats[D + i] : 1.f;
+    z_mean[i] = m; z_std[i] = s; z_vstd[i] = sqrtf(1.0f + s * s);
+    z_xm[i] = i < C ? a.zstats[2 * D + i] : 0.f;
+    z_xi[i] = i < C ? 1.0f / a.zstats[2 * D + C + i] : 0.f;
+  }
+  const float invH = 1.0f / (float)H;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const long long wt = (long long)tile * 4 + wave;
+    const long long row_raw = wt * 16 + c;
+    const bool valid = row_raw < a.n;
+    const long long row = valid ? row_raw : a.n - 1;
+    float* wtb = MODE == 2 ? a.stash + wt * (long long)pl.SB * 256 : nullptr;
+    const float t = a.times[a.t_rows == 1 ? 0 : row];
+    const float om = 1.0f - t;
+    const float* th = a.theta + row * D;
+    const float* nz = MODE == 0 ? nullptr : a.noise + row * D;
+    const float* xr = a.x + (a.x_rows == 1 ? 0 : row) * C;
+
+#define FM_ENTER(J)                                                        \
+  {                                                                        \
+    const FmLin& q_ = pl.lin[J];                                           \
+    if (q_.fg_first) {                                                     \
+      __syncthreads();                                                     \
+      fm_stage(lds, a.packed + q_.fg_off, q_.fg_floats, tid);              \
+      __syncthreads();                                                     \
+    }                                                                      \
+  }
+    f4 acc[HB], temb[HB], h[HB];
+    // ---- input layer: theta_t -> time-dependent z-score -> Linear(D, H); then the first half of the merge
+    FM_ENTER(J_IN);
+    {
+      const FmLin& q = pl.lin[J_IN];
+      f4 ie[HB];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) ie[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
+      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      for (int kb = 0; kb < pl.DB; ++kb) {
+        f4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 16 * kb + 4 * g + i;
+          float val = 0.f;
+          if (f < D) {
+            float tt = th[f];
+            if (MODE != 0) tt = om * tt + (t + pl.noise_scale) * nz[f];
+            const float sd = om * z_std[f];
+            val = (tt - om * z_mean[f]) / sqrtf(sd * sd + t * t + 1e-6f);
+          }
+          v[i] = val;
+        }
+        if (MODE == 2) st_nat(wtb, pl.s_in + kb, c, g, v);
+        gemm_blk<HB>(wl, q.ldk, kb, v, ie);
+      }
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+        if (MODE == 2) st_nat(wtb, pl.s_ie + ob, c, g, ie[ob]);
+        h[ob] = gelu4(ie[ob]);
+      }
+    }
+    // merge: Linear(2H, H) on GELU([ie, ce]) as two K = H products
+    FM_ENTER(J_MA);
+    {
+      const FmLin& q = pl.lin[J_MA];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
+      gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+    }
+    // ---- condition layer: standardised x -> Linear(C, H); second half of the merge
+    FM_ENTER(J_CT);
+    {
+      const FmLin& q = pl.lin[J_CT];
+      f4 ce[HB];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) ce[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
+      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      for (int kb = 0; kb < pl.CB; ++kb) {
+        f4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 16 * kb + 4 * g + i;
+          v[i] = f < C ? (xr[f] - z_xm[f]) * z_xi[f] : 0.f;
+        }
+        if (MODE == 2) st_nat(wtb, pl.s_c + kb, c, g, v);
+        gemm_blk<HB>(wl, q.ldk, kb, v, ce);
+      }
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+        if (MODE == 2) st_nat(wtb, pl.s_ce + ob, c, g, ce[ob]);
+        h[ob] = gelu4(ce[ob]);
+      }
+    }
+    FM_ENTER(J_MB);
+    {
+      const FmLin& q = pl.lin[J_MB];
+      gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+    }
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) {
+      if (MODE == 2) st_nat(wtb, pl.s_h0 + ob, c, g, acc[ob]);
+      h[ob] = gelu4(acc[ob]);
+    }
+    // ---- time embedding: sin/cos features -> Linear(E, H)
+    FM_ENTER(J_TM);
+    {
+      const FmLin& q = pl.lin[J_TM];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) temb[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
+      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      for (int kb = 0; kb < pl.EB; ++kb) {
+        f4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 16 * kb + 4 * g + i;
+          float val = 0.f;
+          if (e < pl.E) {
+            const float w = expf(-(float)(e & ~1) * pl.log_max_freq_over_E);
+            const float ang = t * w;
+            val = (e & 1) ? cosf(ang) : sinf(ang);
+          }
+          v[i] = val;
+        }
+        if (MODE == 2) st_nat(wtb, pl.s_te + kb, c, g, v);
+        gemm_blk<HB>(wl, q.ldk, kb, v, temb);
+      }
+    }
+    // ---- residual blocks: h <- LayerNorm(GELU(W h + b) + temb + h)
+    for (int l = 0; l < pl.L; ++l) {
+      FM_ENTER(J_L0 + l);
+      const FmLin& q = pl.lin[J_L0 + l];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
+      gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      float s1 = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+        if (MODE == 2) st_nat(wtb, pl.s_u + l * HB + ob, c, g, acc[ob]);
+        acc[ob] = gelu4(acc[ob]) + temb[ob] + h[ob];
+        s1 += (acc[ob][0] + acc[ob][1]) + (acc[ob][2] + acc[ob][3]);
+      }
+      const float mu = sum_over_g(s1) * invH;
+      float s2 = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = (16 * ob + 4 * g + i) < H ? acc[ob][i] - mu : 0.f;
+          acc[ob][i] = d;
+          s2 += d * d;
+        }
+      }
+      const float rstd = 1.0f / sqrtf(sum_over_g(s2) * invH + pl.ln_eps);
+      if (MODE == 2 && g == 0) wtb[pl.s_rstd * 256 + l * 16 + c] = rstd;
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+        const f4 sh = acc[ob] * rstd;
+        if (MODE == 2) st_nat(wtb, pl.s_sh + l * HB + ob, c, g, sh);
+        const f4 gam = *reinterpret_cast<const f4*>(lds + q.lb + 16 * HB + 16 * ob + 4 * g);
+        const f4 bet = *reinterpret_cast<const f4*>(lds + q.lb + 32 * HB + 16 * ob + 4 * g);
+        h[ob] = sh * gam + bet;
+      }
+    }
+    // ---- output layer + loss / velocity
+    FM_ENTER(J_L0 + pl.L);
+    {
+      const FmLin& q = pl.lin[J_L0 + pl.L];
+      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      float lsum = 0.f;
+      for (int ob = 0; ob < pl.DB; ++ob) {
+        f4 o0 = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g), o1 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) {
+          const f4 av = *reinterpret_cast<const f4*>(wl + ob * 16 * q.ldk + 16 * kb);
+          if (kb & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o1 = MFMA16(av[r], h[kb][r], o1);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0 = MFMA16(av[r], h[kb][r], o0);
+          }
+        }
+        o0 += o1;
+        f4 diff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 16 * ob + 4 * g + i;
+          if (MODE == 0) {
+            if (f < D && valid) a.v_out[row * D + f] = o0[i] * z_vstd[f] - z_mean[f];
+          } else {
+            float d = 0.f;
+            if (f < D) d = o0[i] - ((nz[f] - th[f]) + z_mean[f]) / z_vstd[f];
+            diff[i] = d;
+            lsum += d * d;
+          }
+        }
+        if (MODE == 2) st_nat(wtb, pl.s_diff + ob, c, g, diff);
+      }
+      if (MODE != 0) {
+        lsum = sum_over_g(lsum);
+        if (g == 0 && valid) a.loss_out[row] = lsum / (float)D;
+      }
+    }
+  }
+#undef FM_ENTER
+}
+
+// ---------------------------------------------------------------- backward (dX chain)
+template <int HB>
+__global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, const FmArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int D = pl.D, H = pl.H, L = pl.L;
+  const float invH = 1.0f / (float)H;
+  float* lnp = a.ln_part + ((long long)blockIdx.x * 4 + wave) * (long long)(L * 2 * 16 * HB);
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const long long wt = (long long)tile * 4 + wave;
+    const long long row_raw = wt * 16 + c;
+    const bool valid = row_raw < a.n;
+    float* wtb = a.stash + wt * (long long)pl.SB * 256;
+    float wrow = 0.f;
+    if (valid) wrow = (a.row_weight ? a.row_weight[row_raw] : a.uniform_weight) * (2.0f / (float)D);
+
+#define FM_BENTER(J)                                                       \
+  {                                                                        \
+    const FmLin& q_ = pl.lin[J];                                           \
+    if (q_.bg_first) {                                                     \
+      __syncthreads();                                                     \
+      fm_stage(lds, a.packed + q_.bg_off, q_.bg_floats, tid);              \
+      __syncthreads();                                                     \
+    }                                                                      \
+  }
+    f4 gh[HB], gte[HB], acc[HB];
+    // ---- output layer: g_v = 2 w (out - target) / D ; g_h = W_o^T g_v
+    FM_BENTER(J_L0 + L);
+    {
+      const FmLin& q = pl.lin[J_L0 + L];
+      const float* wl = lds + q.ltw + c * q.ldt + 4 * g;
+#pragma unroll
+      for (int ib = 0; ib < HB; ++ib) { gh[ib] = f4{0.f, 0.f, 0.f, 0.f}; gte[ib] = f4{0.f, 0.f, 0.f, 0.f}; }
+      for (int ob = 0; ob < pl.DB; ++ob) {
+        const f4 gv = ld_nat(wtb, pl.s_diff + ob, c, g) * wrow;
+        st_tr(wtb, pl.g_v + ob, c, g, gv);
+        gemm_blk<HB>(wl, q.ldt, ob, gv, gh);
+      }
+    }
+    // ---- residual blocks in reverse
+    for (int l = L - 1; l >= 0; --l) {
+      FM_BENTER(J_L0 + l);
+      const FmLin& q = pl.lin[J_L0 + l];
+      const float rstd = wtb[pl.s_rstd * 256 + l * 16 + c];
+      f4 sh[HB];
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+        sh[ob] = ld_nat(wtb, pl.s_sh + l * HB + ob, c, g);
+        const f4 gam = *reinterpret_cast<const f4*>(lds + q.ltg + 16 * ob + 4 * g);
+        // LayerNorm parameter gradients: reduce over this wave's 16 rows, one add per feature into the
+        // wave's private partial (single writer: deterministic)
+        const f4 pg = gh[ob] * sh[ob];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float tg = sum_over_c(pg[i]), tb = sum_over_c(gh[ob][i]);
+          if (c == 0) {
+            unsafeAtomicAdd(lnp + (l * 2 + 0) * 16 * HB + 16 * ob + 4 * g + i, tg);
+            unsafeAtomicAdd(lnp + (l * 2 + 1) * 16 * HB + 16 * ob + 4 * g + i, tb);
+          }
+        }
+        gh[ob] = gh[ob] * gam;      // g_hat (zero on padded features: gamma is zero padded)
+        m1 += (gh[ob][0] + gh[ob][1]) + (gh[ob][2] + gh[ob][3]);
+        const f4 p2 = gh[ob] * sh[ob];
+        m2 += (p2[0] + p2[1]) + (p2[2] + p2[3]);
+      }
+      m1 = sum_over_g(m1) * invH;
+      m2 = sum_over_g(m2) * invH;
+      f4 gu[HB];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) {
+        f4 gs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          gs[i] = (16 * ob + 4 * g + i) < H ? rstd * (gh[ob][i] - m1 - sh[ob][i] * m2) : 0.f;
+        gte[ob] += gs;
+        acc[ob] = gs;                                   // skip connection
+        const f4 u = ld_nat(wtb, pl.s_u + l * HB + ob, c, g);
+        gu[ob] = gs * gelu_grad4(u);
+        st_tr(wtb, pl.g_u + l * HB + ob, c, g, gu[ob]);
+      }
+      gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gu, acc);
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) gh[ob] = acc[ob];
+    }
+    // ---- h = GELU(h0); merge layer; input / condition layers
+    f4 gh0[HB];
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) {
+      gh0[ob] = gh[ob] * gelu_grad4(ld_nat(wtb, pl.s_h0 + ob, c, g));
+      st_tr(wtb, pl.g_h0 + ob, c, g, gh0[ob]);
+      st_tr(wtb, pl.g_te + ob, c, g, gte[ob]);
+    }
+    FM_BENTER(J_MA);
+    {
+      const FmLin& q = pl.lin[J_MA];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
+      gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob)
+        st_tr(wtb, pl.g_ie + ob, c, g, acc[ob] * gelu_grad4(ld_nat(wtb, pl.s_ie + ob, c, g)));
+    }
+    FM_BENTER(J_MB);
+    {
+      const FmLin& q = pl.lin[J_MB];
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
+      gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob)
+        st_tr(wtb, pl.g_ce + ob, c, g, acc[ob] * gelu_grad4(ld_nat(wtb, pl.s_ce + ob, c, g)));
+    }
+  }
+#undef FM_BENTER
+}
+
+// ---------------------------------------------------------------- weight gradients: dW_j = G_j^T X_j over a row chunk
+__global__ void __launch_bounds__(FM_THREADS) fm_dw_kernel(const FmPlan pl, const float* __restrict__ stash,
+                                                           long long nwt, float* __restrict__ partials) {
+  const int j = blockIdx.y;
+  const FmLin& q = pl.lin[j];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int obh = wave & 1, kbh = wave >> 1;
+  const int hob = (q.OB + 1) / 2, hkb = (q.KB + 1) / 2;
+  const int ob0 = obh ? hob : 0, nob = obh ? q.OB - hob : hob;
+  const int kb0 = kbh ? hkb : 0, nkb = kbh ? q.KB - hkb : hkb;
+  const bool want_bias = kbh == 0 && q.g_b >= 0;
+  f4 acc[4][4], accb[4];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    accb[qq] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[qq][p] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long long wt0 = (long long)blockIdx.x * FM_DW_TILES;
+  const long long wt1 = wt0 + FM_DW_TILES < nwt ? wt0 + FM_DW_TILES : nwt;
+  for (long long wt = wt0; wt < wt1; ++wt) {
+    const float* wtb = stash + wt * (long long)pl.SB * 256;
+    f4 av[4], bv[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+      av[qq] = qq < nob ? *reinterpret_cast<const f4*>(wtb + (q.s_g + ob0 + qq) * 256 + c * 16 + 4 * g)
+                        : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f4 v = f4{0.f, 0.f, 0.f, 0.f};
+      if (p < nkb) {
+        const float* xb = wtb + (q.s_x + kb0 + p) * 256 + (4 * g) * 16 + c;
+        v = f4{xb[0], xb[16], xb[32], xb[48]};
+        if (q.x_gelu) v = gelu4(v);
+      }
+      bv[p] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        if (qq < nob) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < nkb) acc[qq][p] = MFMA16(av[qq][r], bv[p][r], acc[qq][p]);
+          if (want_bias) accb[qq] = MFMA16(av[qq][r], 1.0f, accb[qq]);
+        }
+      }
+    }
+  }
+  float* part = partials + (long long)blockIdx.x * pl.P;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    if (qq >= nob) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = 16 * (ob0 + qq) + 4 * g + i;
+      if (o >= q.out) continue;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int in = 16 * (kb0 + p) + c;
+        if (p < nkb && in < q.in) part[q.g_w + o * q.g_ld + in] = acc[qq][p][i];
+      }
+      if (want_bias && c == 0) part[q.g_b + o] = accb[qq][i];
+    }
+  }
+}
+
+// grad[idx] = sum over chunks (linear weights / biases) or over the backward waves' partials (LayerNorm)
+__global__ void __launch_bounds__(256) fm_reduce_kernel(const FmPlan pl, const float* __restrict__ partials, int nchunk,
+                                                        const float* __restrict__ ln_part, int nln,
+                                                        float* __restrict__ grad) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= pl.P) return;
+  float s = 0.f;
+  const int H = pl.H;
+  if (idx >= pl.g_ln && idx < pl.g_ln + 2 * H * pl.L) {
+    const int r = idx - pl.g_ln, l = r / (2 * H), k = (r - l * 2 * H) / H, f = r - l * 2 * H - k * H;
+    const long long stride = (long long)pl.L * 2 * 16 * pl.HB;
+    const float* p = ln_part + (l * 2 + k) * 16 * pl.HB + f;
+    for (int i = 0; i < nln; ++i) s += p[i * stride];
+  } else {
+    for (int i = 0; i < nchunk; ++i) s += partials[(long long)i * pl.P + idx];
+  }
+  grad[idx] = s;
+}
+
+// linears fed by a LayerNorm output: X was s_hat, so  dW[o][i] = gamma[i] M[o][i] + beta[i] db[o]
+__global__ void __launch_bounds__(256) fm_lnfix_kernel(const FmPlan pl, const float* __restrict__ params,
+                                                       float* __restrict__ grad) {
+  const FmLin& q = pl.lin[blockIdx.y];
+  if (q.ln_fix < 0) return;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= q.out * q.in) return;
+  const int o = idx / q.in, i = idx - o * q.in;
+  const float gam = params[pl.g_ln + q.ln_fix * 2 * pl.H + i], bet = params[pl.g_ln + q.ln_fix * 2 * pl.H + pl.H + i];
+  float* w = grad + q.g_w + o * q.g_ld + i;
+  *w = gam * *w + bet * grad[q.g_b + o];
+}
+
+// ---------------------------------------------------------------- packing
+__global__ void __launch_bounds__(256) fm_pack_kernel(const FmPlan pl, const float* __restrict__ params,
+                                                      float* __restrict__ packed) {
+  const int j = blockIdx.x;
+  const FmLin& q = pl.lin[j];
+  const int tid = threadIdx.x;
+  const int rows = 16 * q.OB;
+  for (int idx = tid; idx < rows * q.ldk; idx += 256) {
+    const int o = idx / q.ldk, i = idx - o * q.ldk;
+    packed[q.w_off + idx] = (o < q.out && i < q.in) ? params[q.g_w + o * q.g_ld + i] : 0.f;
+  }
+  const bool is_layer = j >= J_L0 && j < J_L0 + pl.L;
+  const int l = j - J_L0;
+  for (int idx = tid; idx < 3 * rows; idx += 256) {
+    const int k = idx / rows, o = idx - k * rows;
+    float v = 0.f;
+    if (o < q.out) {
+      if (k == 0) v = q.g_b >= 0 ? params[q.g_b + o] : 0.f;
+      else if (is_layer) v = params[pl.g_ln + l * 2 * pl.H + (k - 1) * pl.H + o];
+    }
+    packed[q.w_off + rows * q.ldk + idx] = v;
+  }
+  if (j == J_IN || j == J_CT || j == J_TM) return;
+  const int trows = 16 * q.KB;
+  for (int idx = tid; idx < trows * q.ldt; idx += 256) {
+    const int i = idx / q.ldt, o = idx - i * q.ldt;
+    packed[q.t_off + idx] = (o < q.out && i < q.in) ? params[q.g_w + o * q.g_ld + i] : 0.f;
+  }
+  for (int o = tid; o < rows; o += 256)
+    packed[q.t_off + trows * q.ldt + o] = (is_layer && o < q.out) ? params[pl.g_ln + l * 2 * pl.H + o] : 0.f;
+}
+
+// ---------------------------------------------------------------- host side
+static int fm_grid(int ntiles) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  const int g = 2 * cus;
+  return ntiles < g ? ntiles : g;
+}
+
+template <int MODE>
+static int fm_launch_fwd(const FmPlan& pl, const FmArgs& a, hipStream_t st) {
+  const size_t lds = 4ull * (pl.lds_fwd_floats + FM_ZS_FLOATS);
+  const int grid = fm_grid(a.ntiles);
+#define FM_FWD_CASE(HBV)                                                                                        \
+  case HBV: {                                                                                                   \
+    hipError_t e = hipFuncSetAttribute((const void*)fm_fwd_kernel<HBV, MODE>,                                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    if (e != hipSuccess) return (int)e;                                                                         \
+    hipLaunchKernelGGL((fm_fwd_kernel<HBV, MODE>), dim3(grid), dim3(FM_THREADS), lds, st, pl, a);               \
+    break;                                                                                                      \
+  }
+  switch (pl.HB) {
+    FM_FWD_CASE(4)
+    FM_FWD_CASE(7)
+    FM_FWD_CASE(8)
+    default: return SBI_AMD_E_UNSUPPORTED;
+  }
+#undef FM_FWD_CASE
+  return (int)hipGetLastError();
+}
+
+static int fm_launch_bwd(const FmPlan& pl, const FmArgs& a, int grid, hipStream_t st) {
+  const size_t lds = 4ull * pl.lds_bwd_floats;
+#define FM_BWD_CASE(HBV)                                                                                        \
+  case HBV: {                                                                                                   \
+    hipError_t e = hipFuncSetAttribute((const void*)fm_bwd_kernel<HBV>,                                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    if (e != hipSuccess) return (int)e;                                                                         \
+    hipLaunchKernelGGL((fm_bwd_kernel<HBV>), dim3(grid), dim3(FM_THREADS), lds, st, pl, a);                     \
+    break;                                                                                                      \
+  }
+  switch (pl.HB) {
+    FM_BWD_CASE(4)
+    FM_BWD_CASE(7)
+    FM_BWD_CASE(8)
+    default: return SBI_AMD_E_UNSUPPORTED;
+  }
+#undef FM_BWD_CASE
+  return (int)hipGetLastError();
+}
+
+struct FmWs { long long stash, partials, ln_part, total; int nchunk, nln_max; long long nwt; int ntiles; };
+static FmWs fm_ws_layout(const FmPlan& pl, long long n) {
+  FmWs w;
+  w.ntiles = (int)((n + FM_ROWS - 1) / FM_ROWS);
+  w.nwt = (long long)w.ntiles * 4;
+  w.nchunk = (int)((w.nwt + FM_DW_TILES - 1) / FM_DW_TILES);
+  w.nln_max = 4 * 2 * 1024;   // backward waves: 4 per workgroup, at most 2 workgroups per CU, CUs <= 1024
+  w.stash = 0;
+  w.partials = w.stash + w.nwt * (long long)pl.SB * 256;
+  w.ln_part = w.partials + (long long)w.nchunk * pl.P;
+  w.total = w.ln_part + (long long)w.nln_max * pl.L * 2 * 16 * pl.HB;
+  return w;
+}
+
+extern "C" {
+
+int64_t sbi_amd_fmpe_param_count(const sbi_amd_fmpe_config* cfg) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  return rc ? rc : pl.P;
+}
+
+int64_t sbi_amd_fmpe_param_offset(const sbi_amd_fmpe_config* cfg, int32_t kind, int32_t layer) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (layer < 0 || layer >= pl.L) return SBI_AMD_E_BADARG;
+  switch (kind) {
+    case 0: return pl.lin[J_IN].g_w;
+    case 1: return pl.lin[J_IN].g_b;
+    case 2: return pl.lin[J_CT].g_w;
+    case 3: return pl.lin[J_CT].g_b;
+    case 4: return pl.lin[J_MA].g_w;
+    case 5: return pl.lin[J_MA].g_b;
+    case 6: return pl.lin[J_TM].g_w;
+    case 7: return pl.lin[J_TM].g_b;
+    case 8: return pl.lin[J_L0 + layer].g_w;
+    case 9: return pl.lin[J_L0 + layer].g_b;
+    case 10: return pl.g_ln + layer * 2 * pl.H;
+    case 11: return pl.g_ln + layer * 2 * pl.H + pl.H;
+    case 12: return pl.lin[J_L0 + pl.L].g_w;
+    case 13: return pl.lin[J_L0 + pl.L].g_b;
+    default: return SBI_AMD_E_BADARG;
+  }
+}
+
+int64_t sbi_amd_fmpe_packed_floats(const sbi_amd_fmpe_config* cfg) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  return rc ? rc : pl.packed_floats;
+}
+
+int sbi_amd_fmpe_pack(const sbi_amd_fmpe_config* cfg, const float* params, float* packed, void* stream) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (!params || !packed) return SBI_AMD_E_BADARG;
+  hipLaunchKernelGGL(fm_pack_kernel, dim3(pl.NL), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
+  return (int)hipGetLastError();
+}
+
+int sbi_amd_fmpe_velocity(const sbi_amd_fmpe_config* cfg, const float* packed, const float* zstats,
+                          const float* theta_t, const float* x, int64_t x_rows, const float* times,
+                          int64_t t_rows, int64_t n, float* v_out, void* stream) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (!packed || !zstats || !theta_t || !x || !times || !v_out || n < 0) return SBI_AMD_E_BADARG;
+  if ((x_rows != 1 && x_rows != n) || (t_rows != 1 && t_rows != n)) return SBI_AMD_E_BADARG;
+  if (n == 0) return 0;
+  FmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = packed; a.zstats = zstats; a.theta = theta_t; a.x = x; a.times = times; a.n = n;
+  a.x_rows = (int)(x_rows == 1 ? 1 : 2); a.t_rows = (int)(t_rows == 1 ? 1 : 2);
+  if (n == 1) { a.x_rows = 1; a.t_rows = 1; }
+  a.v_out = v_out; a.ntiles = (int)((n + FM_ROWS - 1) / FM_ROWS);
+  return fm_launch_fwd<0>(pl, a, (hipStream_t)stream);
+}
+
+int sbi_amd_fmpe_loss(const sbi_amd_fmpe_config* cfg, const float* packed, const float* zstats, const float* theta,
+                      const float* x, int64_t x_rows, const float* times, const float* noise, int64_t n,
+                      float* loss_out, void* stream) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (!packed || !zstats || !theta || !x || !times || !noise || !loss_out || n < 0) return SBI_AMD_E_BADARG;
+  if (x_rows != 1 && x_rows != n) return SBI_AMD_E_BADARG;
+  if (n == 0) return 0;
+  FmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = packed; a.zstats = zstats; a.theta = theta; a.x = x; a.times = times; a.noise = noise; a.n = n;
+  a.x_rows = (x_rows == 1 || n == 1) ? 1 : 2; a.t_rows = n == 1 ? 1 : 2;
+  a.loss_out = loss_out; a.ntiles = (int)((n + FM_ROWS - 1) / FM_ROWS);
+  return fm_launch_fwd<1>(pl, a, (hipStream_t)stream);
+}
+
+int64_t sbi_amd_fmpe_train_workspace_floats(const sbi_amd_fmpe_config* cfg, int64_t n) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (n <= 0) return SBI_AMD_E_BADARG;
+  return fm_ws_layout(pl, n).total;
+}
+
+int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* params, const float* packed,
+                              const float* zstats, const float* theta, const float* x, int64_t x_rows,
+                              const float* times, const float* noise, int64_t n, const float* row_weight,
+                              float uniform_weight, float* loss_out, float* grad_out, float* workspace,
+                              void* stream) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (!params || !packed || !zstats || !theta || !x || !times || !noise || !loss_out || !grad_out || !workspace ||
+      n <= 0)
+    return SBI_AMD_E_BADARG;
+  if (x_rows != 1 && x_rows != n) return SBI_AMD_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const FmWs w = fm_ws_layout(pl, n);
+  FmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = packed; a.zstats = zstats; a.theta = theta; a.x = x; a.times = times; a.noise = noise; a.n = n;
+  a.x_rows = (x_rows == 1 || n == 1) ? 1 : 2; a.t_rows = n == 1 ? 1 : 2;
+  a.row_weight = row_weight; a.uniform_weight = uniform_weight;
+  a.loss_out = loss_out; a.stash = workspace + w.stash; a.ln_part = workspace + w.ln_part; a.ntiles = w.ntiles;
+  rc = fm_launch_fwd<2>(pl, a, st);
+  if (rc) return rc;
+  const int bgrid = fm_grid(w.ntiles);
+  const int nln = bgrid * 4;
+  if (nln > w.nln_max) return SBI_AMD_E_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(workspace + w.ln_part, 0, 4ull * nln * pl.L * 2 * 16 * pl.HB, st);
+  if (e != hipSuccess) return (int)e;
+  rc = fm_launch_bwd(pl, a, bgrid, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fm_dw_kernel, dim3(w.nchunk, pl.NL), dim3(FM_THREADS), 0, st, pl, workspace + w.stash, w.nwt,
+                     workspace + w.partials);
+  hipLaunchKernelGGL(fm_reduce_kernel, dim3((pl.P + 255) / 256), dim3(256), 0, st, pl, workspace + w.partials,
+                     w.nchunk, workspace + w.ln_part, nln, grad_out);
+  const int wmax = (pl.H > pl.D ? pl.H : pl.D) * pl.H;
+  hipLaunchKernelGGL(fm_lnfix_kernel, dim3((wmax + 255) / 256, pl.NL), dim3(256), 0, st, pl, params, grad_out);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

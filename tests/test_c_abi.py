@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/sbi_amd_nsf.h declares (no
+"""The C-ABI library loads and exports every symbol include/*.h declares (no
 compute calls here: those need a GPU).  Host-only entry points are exercised."""
 
 import ctypes
@@ -14,9 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sbi_amd_nsf.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sbi_amd_\w+)\s*\(", text)))
+    syms = set()
+    for header in ("sbi_amd_nsf.h", "sbi_amd_fmpe.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(sbi_amd_\w+)\s*\(", text))
+    return sorted(syms)
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -25,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     syms = declared_symbols()
     assert len(syms) >= 10
     for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/sbi_amd_nsf.h but not exported"
+        assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.exported_symbols()), "ctypes binding and header disagree"
 
 
