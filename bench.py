@@ -99,6 +99,35 @@ def cpu_baseline(mode, budget_s=12.0):
                       f"torch {torch.__version__} CPU fp32"}
 
 
+def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
+    """Oracle FMPE training step (loss + backward + clip + Adam, eager PyTorch) on host cores."""
+    from oracle.fmpe_oracle import FMPEOracle
+
+    cores = min(os.cpu_count() or 1, int(os.environ.get("SBI_AMD_CPU_THREADS", "32")))
+    torch.set_num_threads(cores)
+    h = fm.net.hyper
+    o = FMPEOracle(h.D, h.C, H=h.hidden_features, L=h.num_layers)
+    o.load_reference_state_dict({k: v.cpu() for k, v in fm.net.reference_state_dict().items()})
+    n = 16384
+    th, xx = theta[:n].cpu(), x[:n].cpu()
+    opt = torch.optim.Adam(o.parameters(), lr=5e-4)
+
+    def step():
+        opt.zero_grad()
+        o.loss(th, xx, torch.rand(n), torch.randn(n, h.D)).mean().backward()
+        torch.nn.utils.clip_grad_norm_(o.parameters(), 5.0)
+        opt.step()
+
+    step()
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        step()
+        k += 1
+    dt = time.perf_counter() - t0
+    return {"value": k * n / dt, "unit": "train pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{k} x {n}-row oracle FMPE train steps ({dt:.1f} s), torch {torch.__version__} CPU fp32"}
+
+
 def timed(step, steps, warmup, device, dist=None):
     """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
     for _ in range(warmup):
@@ -147,7 +176,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample", "atomic", "mcmc"],
+    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample", "atomic", "mcmc", "fmpe"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--draws", type=int, default=1_000_000, help="posterior draws per step in the sample leg")
@@ -232,6 +261,42 @@ def main():
                               "us_per_tick": dt / ticks * 1e6, "log_prob_evals_per_s": ticks * chains / dt,
                               "config": {"workload": f"{chains} chains x {nd // chains} kept sweeps (+10 warm-up, "
                                                      f"+50 width-tuning sweeps), theta-dim {D}, one x_o"}}))
+        return
+    if args.mode == "fmpe":
+        # SURVEY 8f-1 / BASELINE configs[4]: one FMPE training step (default vector-field MLP, theta-dim 50) on
+        # `--batch` pairs per GPU: draws of t and theta_1, fused CFM loss fwd + bwd, [all-reduce], clip + Adam
+        from sbi_amd.inference.trainers.fused import FusedFMPEStep
+        from sbi_amd.neural_nets.estimators.flowmatching_estimator import build_flow_matching_estimator
+
+        DF = 50
+        g = torch.Generator().manual_seed(rank)
+        th_f = torch.randn(B, DF, generator=g) * (0.1**0.5)
+        x_f = (th_f + (0.1**0.5) * torch.randn(B, DF, generator=g)).to(device)
+        th_f = th_f.to(device)
+        torch.manual_seed(1)
+        fm = build_flow_matching_estimator(th_f[:4096].cpu(), x_f[:4096].cpu()).to(device)
+        if distributed:
+            dist.broadcast(fm.net.flat_params.data, src=0)
+        stepper = FusedFMPEStep(fm, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+        wall, dev_ms = timed(lambda: stepper.step(th_f, x_f), args.steps, args.warmup, device, dist)
+        h = fm.net.hyper
+        H, L, E = h.hidden_features, h.num_layers, h.time_embedding_dim
+        f_fwd = 2.0 * (DF * H + DF * H + 2 * H * H + E * H + L * H * H + H * DF)   # dense FLOP per row, forward
+        if rank == 0:
+            out = {
+                "metric": "FMPE train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
+                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[4] step: FMPE default vector-field MLP (hidden {H}, "
+                                       f"{L} layers, {h.param_count()} parameters), theta-dim {DF}, x-dim {DF}, "
+                                       f"batch {B} per GPU, synthetic linear-Gaussian", "parallelism": f"dp{world}"},
+                "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms)}
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = fmpe_cpu_baseline(fm, th_f, x_f)
+            print(json.dumps(out))
+        if distributed:
+            dist.destroy_process_group()
         return
     if args.mode == "atomic":
         # one multi-round NPE-C step (atomic proposal-posterior loss, 10 atoms) on `--batch` pairs

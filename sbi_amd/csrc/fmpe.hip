@@ -168,11 +168,30 @@ static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
 }
 
 // ---------------------------------------------------------------- device helpers
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// GELU(v) = v Phi(v) and its derivative Phi(v) + v phi(v), with Phi from the Abramowitz-Stegun 7.1.26 erfc
+// (|error| < 1.5e-7 on erf, i.e. < 1e-7 |v| on GELU): one v_exp_f32, one v_rcp_f32 and a degree-5 Horner chain
+// instead of libm's erff.  The tail side is computed without cancellation (Phi(v) = erfc(|x|)/2 for v < 0).
+__device__ __forceinline__ void gelu_core(float v, float& cdf, float& ex) {
+  const float x = fabsf(v) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+  ex = __expf(-x * x);                           // = exp(-v^2 / 2)
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float half_erfc = 0.5f * p * t * ex;     // erfc(|x|) / 2
+  cdf = v < 0.f ? half_erfc : 1.0f - half_erfc;
+}
+__device__ __forceinline__ float gelu_f(float v) {
+  float cdf, ex;
+  gelu_core(v, cdf, ex);
+  return v * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float v) {
-  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
-  return cdf + v * pdf;
+  float cdf, ex;
+  gelu_core(v, cdf, ex);
+  return cdf + v * 0.3989422804014327f * ex;
 }
 __device__ __forceinline__ f4 gelu4(f4 v) { return f4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])}; }
 __device__ __forceinline__ f4 gelu_grad4(f4 v) {
@@ -597,90 +616,171 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
 }
 
 // ---------------------------------------------------------------- weight gradients: dW_j = G_j^T X_j over a row chunk
+// One workgroup per (row chunk, linear).  Each of its 4 waves accumulates the WHOLE dW (OB x KB blocks, up to
+// 8 x 8 f4 accumulators: one wave per SIMD) over every fourth wave-tile of the chunk, so each stash block is
+// read once: A fragments by one 16-byte load per lane from the transposed G blocks, B fragments from the natural
+// X blocks.  Operands of the next wave-tile are in flight under the MFMAs of the current one.  The four waves'
+// sums are combined through LDS in a fixed order and written as the chunk's partial.
+template <int NB>
 __global__ void __launch_bounds__(FM_THREADS) fm_dw_kernel(const FmPlan pl, const float* __restrict__ stash,
                                                            long long nwt, float* __restrict__ partials) {
+  extern __shared__ __align__(16) float lds[];
   const int j = blockIdx.y;
   const FmLin& q = pl.lin[j];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-  const int obh = wave & 1, kbh = wave >> 1;
-  const int hob = (q.OB + 1) / 2, hkb = (q.KB + 1) / 2;
-  const int ob0 = obh ? hob : 0, nob = obh ? q.OB - hob : hob;
-  const int kb0 = kbh ? hkb : 0, nkb = kbh ? q.KB - hkb : hkb;
-  const bool want_bias = kbh == 0 && q.g_b >= 0;
-  f4 acc[4][4], accb[4];
+  const int OB = q.OB, KB = q.KB;
+  const bool want_bias = q.g_b >= 0;
+  constexpr bool PF = NB <= 7;     // 8 x 8 accumulators leave no room for a second operand set
+  f4 acc[NB][NB];
+  float accb[NB];                  // bias gradient: per-lane row sums of the A fragments (feature c, rows 4g..4g+3)
 #pragma unroll
-  for (int qq = 0; qq < 4; ++qq) {
-    accb[qq] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int ob = 0; ob < NB; ++ob) {
+    accb[ob] = 0.f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[qq][p] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < NB; ++kb) acc[ob][kb] = f4{0.f, 0.f, 0.f, 0.f};
   }
-  const long long wt0 = (long long)blockIdx.x * FM_DW_TILES;
-  const long long wt1 = wt0 + FM_DW_TILES < nwt ? wt0 + FM_DW_TILES : nwt;
-  for (long long wt = wt0; wt < wt1; ++wt) {
-    const float* wtb = stash + wt * (long long)pl.SB * 256;
-    f4 av[4], bv[4];
+  const long long wt0 = (long long)blockIdx.x * FM_DW_TILES + wave;
+  const long long wt1 = (long long)(blockIdx.x + 1) * FM_DW_TILES < nwt ? (long long)(blockIdx.x + 1) * FM_DW_TILES : nwt;
+  const long long wstride = (long long)pl.SB * 256;
+  const float* gbase = stash + q.s_g * 256 + c * 16 + 4 * g;        // transposed G: [feature c][rows 4g..]
+  const float* xbase = stash + q.s_x * 256 + (4 * g) * 16 + c;      // natural X: [rows 4g..][feature c]
+  f4 av[NB], bv[NB], avn[PF ? NB : 1], bvn[PF ? NB : 1];
+  auto load_ops = [&](long long wt, f4 (&a_)[NB], f4 (&b_)[NB]) {
+    const float* ga = gbase + wt * wstride;
+    const float* xb = xbase + wt * wstride;
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq)
-      av[qq] = qq < nob ? *reinterpret_cast<const f4*>(wtb + (q.s_g + ob0 + qq) * 256 + c * 16 + 4 * g)
-                        : f4{0.f, 0.f, 0.f, 0.f};
+    for (int ob = 0; ob < NB; ++ob)
+      if (ob < OB) a_[ob] = *reinterpret_cast<const f4*>(ga + ob * 256);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      f4 v = f4{0.f, 0.f, 0.f, 0.f};
-      if (p < nkb) {
-        const float* xb = wtb + (q.s_x + kb0 + p) * 256 + (4 * g) * 16 + c;
-        v = f4{xb[0], xb[16], xb[32], xb[48]};
-        if (q.x_gelu) v = gelu4(v);
-      }
-      bv[p] = v;
+    for (int kb = 0; kb < NB; ++kb)
+      if (kb < KB) b_[kb] = f4{xb[kb * 256], xb[kb * 256 + 16], xb[kb * 256 + 32], xb[kb * 256 + 48]};
+  };
+  if (PF && wt0 < wt1) load_ops(wt0, av, bv);
+  for (long long wt = wt0; wt < wt1; wt += 4) {
+    if constexpr (PF) {
+      if (wt + 4 < wt1) load_ops(wt + 4, avn, bvn);
+    } else {
+      load_ops(wt, av, bv);
+    }
+    if (q.x_gelu) {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+        if (kb < KB) bv[kb] = gelu4(bv[kb]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        if (qq < nob) {
+      for (int ob = 0; ob < NB; ++ob) {
+        if (ob < OB) {
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            if (p < nkb) acc[qq][p] = MFMA16(av[qq][r], bv[p][r], acc[qq][p]);
-          if (want_bias) accb[qq] = MFMA16(av[qq][r], 1.0f, accb[qq]);
+          for (int kb = 0; kb < NB; ++kb)
+            if (kb < KB) acc[ob][kb] = MFMA16(av[ob][r], bv[kb][r], acc[ob][kb]);
         }
       }
     }
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+      if (ob < OB) accb[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
+    if constexpr (PF) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { av[b] = avn[b]; bv[b] = bvn[b]; }
+    }
   }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) accb[ob] = sum_over_g(accb[ob]);   // every lane: total of feature 16*ob + c
+  // ---- combine the four waves: (2,3) -> LDS, (0,1) add; 1 -> LDS, 0 adds and stores
+  const int per_wave = NB * NB * 256 + NB * 64;        // floats: acc blocks [blk][lane][4] + bias [ob][lane]
+  auto spill = [&](float* dst) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      if (ob >= OB) continue;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+        if (kb < KB) *reinterpret_cast<f4*>(dst + ((ob * NB + kb) * 64 + lane) * 4) = acc[ob][kb];
+      dst[NB * NB * 256 + ob * 64 + lane] = accb[ob];
+    }
+  };
+  auto absorb = [&](const float* src) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      if (ob >= OB) continue;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+        if (kb < KB) acc[ob][kb] += *reinterpret_cast<const f4*>(src + ((ob * NB + kb) * 64 + lane) * 4);
+      accb[ob] += src[NB * NB * 256 + ob * 64 + lane];
+    }
+  };
+  if (wave >= 2) spill(lds + (wave - 2) * per_wave);
+  __syncthreads();
+  if (wave < 2) absorb(lds + wave * per_wave);
+  __syncthreads();
+  if (wave == 1) spill(lds);
+  __syncthreads();
+  if (wave != 0) return;
+  absorb(lds);
   float* part = partials + (long long)blockIdx.x * pl.P;
 #pragma unroll
-  for (int qq = 0; qq < 4; ++qq) {
-    if (qq >= nob) continue;
+  for (int ob = 0; ob < NB; ++ob) {
+    if (ob >= OB) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int o = 16 * (ob0 + qq) + 4 * g + i;
+      const int o = 16 * ob + 4 * g + i;
       if (o >= q.out) continue;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int in = 16 * (kb0 + p) + c;
-        if (p < nkb && in < q.in) part[q.g_w + o * q.g_ld + in] = acc[qq][p][i];
+      for (int kb = 0; kb < NB; ++kb) {
+        const int in = 16 * kb + c;
+        if (kb < KB && in < q.in) part[q.g_w + o * q.g_ld + in] = acc[ob][kb][i];
       }
-      if (want_bias && c == 0) part[q.g_b + o] = accb[qq][i];
     }
+    if (want_bias && g == 0 && 16 * ob + c < q.out) part[q.g_b + 16 * ob + c] = accb[ob];
   }
 }
 
-// grad[idx] = sum over chunks (linear weights / biases) or over the backward waves' partials (LayerNorm)
+// grad[idx] = sum over row chunks of the weight-gradient partials (LayerNorm slots are written by fm_ln_reduce_kernel)
 __global__ void __launch_bounds__(256) fm_reduce_kernel(const FmPlan pl, const float* __restrict__ partials, int nchunk,
-                                                        const float* __restrict__ ln_part, int nln,
                                                         float* __restrict__ grad) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= pl.P) return;
-  float s = 0.f;
-  const int H = pl.H;
-  if (idx >= pl.g_ln && idx < pl.g_ln + 2 * H * pl.L) {
-    const int r = idx - pl.g_ln, l = r / (2 * H), k = (r - l * 2 * H) / H, f = r - l * 2 * H - k * H;
-    const long long stride = (long long)pl.L * 2 * 16 * pl.HB;
-    const float* p = ln_part + (l * 2 + k) * 16 * pl.HB + f;
-    for (int i = 0; i < nln; ++i) s += p[i * stride];
-  } else {
-    for (int i = 0; i < nchunk; ++i) s += partials[(long long)i * pl.P + idx];
+  if (idx >= pl.g_ln && idx < pl.g_ln + 2 * pl.H * pl.L) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < nchunk; i += 4) {
+    s0 += partials[(long long)i * pl.P + idx];
+    s1 += partials[(long long)(i + 1) * pl.P + idx];
+    s2 += partials[(long long)(i + 2) * pl.P + idx];
+    s3 += partials[(long long)(i + 3) * pl.P + idx];
   }
-  grad[idx] = s;
+  for (; i < nchunk; ++i) s0 += partials[(long long)i * pl.P + idx];
+  grad[idx] = (s0 + s1) + (s2 + s3);
+}
+
+// LayerNorm gamma / beta gradients: one workgroup per (layer, gamma|beta, 16-feature block) sums the backward
+// waves' partials: thread (f = tid & 15, pg = tid >> 4) takes partials pg, pg + 16, ...; fixed-order LDS finish
+__global__ void __launch_bounds__(256) fm_ln_reduce_kernel(const FmPlan pl, const float* __restrict__ ln_part, int nln,
+                                                           float* __restrict__ grad) {
+  __shared__ float red[16][17];
+  const int blk = blockIdx.x;                    // (l * 2 + k) * HB + ob
+  const int lk = blk / pl.HB, ob = blk - lk * pl.HB;
+  const int f = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const long long stride = (long long)pl.L * 2 * 16 * pl.HB;
+  const float* p = ln_part + lk * 16 * pl.HB + 16 * ob + f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = pg;
+  for (; i + 48 < nln; i += 64) {
+    s0 += p[i * stride];
+    s1 += p[(i + 16) * stride];
+    s2 += p[(i + 32) * stride];
+    s3 += p[(i + 48) * stride];
+  }
+  for (; i < nln; i += 16) s0 += p[i * stride];
+  red[pg][f] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pg == 0) {
+    float t = 0.f;
+    for (int q = 0; q < 16; ++q) t += red[q][f];
+    const int feat = 16 * ob + f;
+    if (feat < pl.H) grad[pl.g_ln + (lk >> 1) * 2 * pl.H + (lk & 1) * pl.H + feat] = t;
+  }
 }
 
 // linears fed by a LayerNorm output: X was s_hat, so  dW[o][i] = gamma[i] M[o][i] + beta[i] db[o]
@@ -701,15 +801,15 @@ __global__ void __launch_bounds__(256) fm_pack_kernel(const FmPlan pl, const flo
                                                       float* __restrict__ packed) {
   const int j = blockIdx.x;
   const FmLin& q = pl.lin[j];
-  const int tid = threadIdx.x;
+  const int tid = blockIdx.y * 256 + threadIdx.x, nth = gridDim.y * 256;
   const int rows = 16 * q.OB;
-  for (int idx = tid; idx < rows * q.ldk; idx += 256) {
+  for (int idx = tid; idx < rows * q.ldk; idx += nth) {
     const int o = idx / q.ldk, i = idx - o * q.ldk;
     packed[q.w_off + idx] = (o < q.out && i < q.in) ? params[q.g_w + o * q.g_ld + i] : 0.f;
   }
   const bool is_layer = j >= J_L0 && j < J_L0 + pl.L;
   const int l = j - J_L0;
-  for (int idx = tid; idx < 3 * rows; idx += 256) {
+  for (int idx = tid; idx < 3 * rows; idx += nth) {
     const int k = idx / rows, o = idx - k * rows;
     float v = 0.f;
     if (o < q.out) {
@@ -720,11 +820,11 @@ __global__ void __launch_bounds__(256) fm_pack_kernel(const FmPlan pl, const flo
   }
   if (j == J_IN || j == J_CT || j == J_TM) return;
   const int trows = 16 * q.KB;
-  for (int idx = tid; idx < trows * q.ldt; idx += 256) {
+  for (int idx = tid; idx < trows * q.ldt; idx += nth) {
     const int i = idx / q.ldt, o = idx - i * q.ldt;
     packed[q.t_off + idx] = (o < q.out && i < q.in) ? params[q.g_w + o * q.g_ld + i] : 0.f;
   }
-  for (int o = tid; o < rows; o += 256)
+  for (int o = tid; o < rows; o += nth)
     packed[q.t_off + trows * q.ldt + o] = (is_layer && o < q.out) ? params[pl.g_ln + l * 2 * pl.H + o] : 0.f;
 }
 
@@ -838,7 +938,7 @@ int sbi_amd_fmpe_pack(const sbi_amd_fmpe_config* cfg, const float* params, float
   int rc = fm_build_plan(cfg, &pl);
   if (rc) return rc;
   if (!params || !packed) return SBI_AMD_E_BADARG;
-  hipLaunchKernelGGL(fm_pack_kernel, dim3(pl.NL), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
+  hipLaunchKernelGGL(fm_pack_kernel, dim3(pl.NL, 8), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
   return (int)hipGetLastError();
 }
 
@@ -914,10 +1014,32 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
   if (e != hipSuccess) return (int)e;
   rc = fm_launch_bwd(pl, a, bgrid, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(fm_dw_kernel, dim3(w.nchunk, pl.NL), dim3(FM_THREADS), 0, st, pl, workspace + w.stash, w.nwt,
-                     workspace + w.partials);
+  {
+    int nb = pl.HB;
+    if (pl.DB > nb) nb = pl.DB;
+    if (pl.CB > nb) nb = pl.CB;
+    nb = nb <= 4 ? 4 : (nb <= 7 ? 7 : 8);
+    const size_t dlds = 4ull * 2 * (nb * nb * 256 + nb * 64);
+#define FM_DW_CASE(NBV)                                                                                         \
+  case NBV: {                                                                                                   \
+    hipError_t e2 = hipFuncSetAttribute((const void*)fm_dw_kernel<NBV>,                                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);                 \
+    if (e2 != hipSuccess) return (int)e2;                                                                       \
+    hipLaunchKernelGGL((fm_dw_kernel<NBV>), dim3(w.nchunk, pl.NL), dim3(FM_THREADS), dlds, st, pl,              \
+                       workspace + w.stash, w.nwt, workspace + w.partials);                                     \
+    break;                                                                                                      \
+  }
+    switch (nb) {
+      FM_DW_CASE(4)
+      FM_DW_CASE(7)
+      FM_DW_CASE(8)
+    }
+#undef FM_DW_CASE
+  }
   hipLaunchKernelGGL(fm_reduce_kernel, dim3((pl.P + 255) / 256), dim3(256), 0, st, pl, workspace + w.partials,
-                     w.nchunk, workspace + w.ln_part, nln, grad_out);
+                     w.nchunk, grad_out);
+  hipLaunchKernelGGL(fm_ln_reduce_kernel, dim3(pl.L * 2 * pl.HB), dim3(256), 0, st, pl, workspace + w.ln_part, nln,
+                     grad_out);
   const int wmax = (pl.H > pl.D ? pl.H : pl.D) * pl.H;
   hipLaunchKernelGGL(fm_lnfix_kernel, dim3((wmax + 255) / 256, pl.NL), dim3(256), 0, st, pl, params, grad_out);
   return (int)hipGetLastError();

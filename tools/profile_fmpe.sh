@@ -1,0 +1,31 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/profile_fmpe.sh <tag>  -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc.txt}
+tag=${1:-fmpe}
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py --mode fmpe > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --mode fmpe --steps 30 --warmup 5 --no-cpu-baseline > $out/trace.log 2>&1
+cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  t=$(echo $grp | tr ' ' '_' | cut -c1-30)
+  rocprofv3 --pmc $grp --output-format csv -d $out/pmc_$t -- python $R/bench.py --mode fmpe --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_$t.log 2>&1
+done
+python - <<PY > $out/pmc.txt
+import glob, csv, collections
+print("# rocprofv3 --pmc passes (one counter group per pass, no trace domains), bench.py --mode fmpe --steps 3 --warmup 1")
+print("# sums over ALL launches of the run; FETCH_SIZE / WRITE_SIZE in KB (gfx950: FETCH_SIZE counts wide coalesced reads at 1/2)")
+for f in sorted(glob.glob("$out/pmc_*/*/*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:44]; agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[(k, r["Counter_Name"])] += 1
+    for k, d in agg.items():
+        if k.startswith("void at::") or k.startswith("__amd"): continue
+        print(k, {c: round(v) for c, v in d.items()}, "launches", max(calls[(k, c)] for c in d))
+PY
+rm -rf $out/trace $out/pmc_*/
+head -12 $out/kernel_stats.csv
+cat $out/pmc.txt
