@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../include/sbi_amd_fmpe.h"
 #include "../../include/sbi_amd_nsf.h"
 
@@ -65,6 +67,8 @@ struct FmPlan {
   int s_in, s_c, s_te, s_ie, s_ce, s_h0, s_u, s_sh, s_rstd, s_diff;     // s_u + l*HB, s_sh + l*HB
   int g_v, g_u, g_te, g_h0, g_ie, g_ce;
   int SB;                        // blocks per wave-tile
+  int ablate;                    // timing experiments only (env SBI_AMD_FM_ABLATE): 1 no stash traffic,
+                                 // 2 no weight staging, 4 no GELU, 8 no hidden-layer MFMAs; results invalid
 };
 
 static int round_up(int a, int m) { return (a + m - 1) / m * m; }
@@ -164,6 +168,7 @@ static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
     pl->lin[bo[gstart]].bg_floats = p - goff;
   }
   pl->packed_floats = p;
+  if (const char* e = getenv("SBI_AMD_FM_ABLATE")) pl->ablate = atoi(e);
   return 0;
 }
 
@@ -297,7 +302,6 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
     z_xi[i] = i < C ? 1.0f / a.zstats[2 * D + C + i] : 0.f;
   }
   const float invH = 1.0f / (float)H;
-
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const long long wt = (long long)tile * 4 + wave;
     const long long row_raw = wt * 16 + c;
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
     const FmLin& q_ = pl.lin[J];                                           \
     if (q_.fg_first) {                                                     \
       __syncthreads();                                                     \
-      fm_stage(lds, a.packed + q_.fg_off, q_.fg_floats, tid);              \
+      if (!(pl.ablate & 2)) fm_stage(lds, a.packed + q_.fg_off, q_.fg_floats, tid); \
       __syncthreads();                                                     \
     }                                                                      \
   }
@@ -342,12 +346,12 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
           }
           v[i] = val;
         }
-        if (MODE == 2) st_nat(wtb, pl.s_in + kb, c, g, v);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_in + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, ie);
       }
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        if (MODE == 2) st_nat(wtb, pl.s_ie + ob, c, g, ie[ob]);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_ie + ob, c, g, ie[ob]);
         h[ob] = gelu4(ie[ob]);
       }
     }
@@ -374,12 +378,12 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
           const int f = 16 * kb + 4 * g + i;
           v[i] = f < C ? (xr[f] - z_xm[f]) * z_xi[f] : 0.f;
         }
-        if (MODE == 2) st_nat(wtb, pl.s_c + kb, c, g, v);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_c + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, ce);
       }
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        if (MODE == 2) st_nat(wtb, pl.s_ce + ob, c, g, ce[ob]);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_ce + ob, c, g, ce[ob]);
         h[ob] = gelu4(ce[ob]);
       }
     }
@@ -390,7 +394,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
     }
 #pragma unroll
     for (int ob = 0; ob < HB; ++ob) {
-      if (MODE == 2) st_nat(wtb, pl.s_h0 + ob, c, g, acc[ob]);
+      if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_h0 + ob, c, g, acc[ob]);
       h[ob] = gelu4(acc[ob]);
     }
     // ---- time embedding: sin/cos features -> Linear(E, H)
@@ -413,7 +417,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
           }
           v[i] = val;
         }
-        if (MODE == 2) st_nat(wtb, pl.s_te + kb, c, g, v);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_te + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, temb);
       }
     }
@@ -423,12 +427,12 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
       const FmLin& q = pl.lin[J_L0 + l];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
-      gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
       float s1 = 0.f;
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        if (MODE == 2) st_nat(wtb, pl.s_u + l * HB + ob, c, g, acc[ob]);
-        acc[ob] = gelu4(acc[ob]) + temb[ob] + h[ob];
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_u + l * HB + ob, c, g, acc[ob]);
+        acc[ob] = ((pl.ablate & 4) ? acc[ob] : gelu4(acc[ob])) + temb[ob] + h[ob];
         s1 += (acc[ob][0] + acc[ob][1]) + (acc[ob][2] + acc[ob][3]);
       }
       const float mu = sum_over_g(s1) * invH;
@@ -447,7 +451,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
         const f4 sh = acc[ob] * rstd;
-        if (MODE == 2) st_nat(wtb, pl.s_sh + l * HB + ob, c, g, sh);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_sh + l * HB + ob, c, g, sh);
         const f4 gam = *reinterpret_cast<const f4*>(lds + q.lb + 16 * HB + 16 * ob + 4 * g);
         const f4 bet = *reinterpret_cast<const f4*>(lds + q.lb + 32 * HB + 16 * ob + 4 * g);
         h[ob] = sh * gam + bet;
@@ -486,7 +490,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
             lsum += d * d;
           }
         }
-        if (MODE == 2) st_nat(wtb, pl.s_diff + ob, c, g, diff);
+        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_diff + ob, c, g, diff);
       }
       if (MODE != 0) {
         lsum = sum_over_g(lsum);
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
     const FmLin& q_ = pl.lin[J];                                           \
     if (q_.bg_first) {                                                     \
       __syncthreads();                                                     \
-      fm_stage(lds, a.packed + q_.bg_off, q_.bg_floats, tid);              \
+      if (!(pl.ablate & 2)) fm_stage(lds, a.packed + q_.bg_off, q_.bg_floats, tid); \
       __syncthreads();                                                     \
     }                                                                      \
   }
@@ -533,7 +537,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
       for (int ib = 0; ib < HB; ++ib) { gh[ib] = f4{0.f, 0.f, 0.f, 0.f}; gte[ib] = f4{0.f, 0.f, 0.f, 0.f}; }
       for (int ob = 0; ob < pl.DB; ++ob) {
         const f4 gv = ld_nat(wtb, pl.s_diff + ob, c, g) * wrow;
-        st_tr(wtb, pl.g_v + ob, c, g, gv);
+        if (!(pl.ablate & 1)) st_tr(wtb, pl.g_v + ob, c, g, gv);
         gemm_blk<HB>(wl, q.ldt, ob, gv, gh);
       }
     }
@@ -576,10 +580,10 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
         gte[ob] += gs;
         acc[ob] = gs;                                   // skip connection
         const f4 u = ld_nat(wtb, pl.s_u + l * HB + ob, c, g);
-        gu[ob] = gs * gelu_grad4(u);
-        st_tr(wtb, pl.g_u + l * HB + ob, c, g, gu[ob]);
+        gu[ob] = (pl.ablate & 4) ? gs * u : gs * gelu_grad4(u);
+        if (!(pl.ablate & 1)) st_tr(wtb, pl.g_u + l * HB + ob, c, g, gu[ob]);
       }
-      gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gu, acc);
+      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gu, acc);
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) gh[ob] = acc[ob];
     }
