@@ -36,11 +36,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define FM_MAX_L 8
 #define FM_MAX_LIN (6 + FM_MAX_L)
-#define FM_THREADS 256
-#define FM_ROWS 64
+#define FM_THREADS 512              // forward / backward kernels: 8 waves x 16 rows
+#define FM_WAVES 8
+#define FM_ROWS 128
+#define FM_DW_THREADS 256
 #define FM_FWD_GROUP_FLOATS 17920   // 70 KB of weight image per staging group (2 workgroups per CU)
 #define FM_BWD_GROUP_FLOATS 17920
-#define FM_DW_TILES 32              // wave-tiles (16 rows) per weight-gradient chunk
+#define FM_DW_TILES 64              // wave-tiles (16 rows) per weight-gradient chunk
 
 enum { J_IN = 0, J_CT = 1, J_TM = 2, J_MA = 3, J_MB = 4, J_L0 = 5 };
 
@@ -49,11 +51,11 @@ struct FmLin {
   int g_w, g_ld, g_b;           // flat buffer: W[o][i] at g_w + o*g_ld + i; bias at g_b (-1: none)
   int w_off, ldk, lw, lb;       // forward image: packed offset, row stride; LDS offsets of W / bias inside its group
   int t_off, ldt, ltw, ltg;     // backward image (W^T [in][out]): packed offset, stride; LDS offsets of W^T / gamma
-  int fg_first, fg_off, fg_floats;   // forward staging group that starts at this linear
-  int bg_first, bg_off, bg_floats;   // backward staging group that starts at this linear
+  int fg_first, bg_first;       // this linear opens a new forward / backward staging group
   int s_x, s_g;                 // stash slots (in blocks): X natural, G transposed
   int x_gelu;                   // X = GELU(stashed pre-activation)
   int ln_fix;                   // >= 0: X was s_hat of that layer; dW = M*gamma + db (x) beta
+  int pf_w, pf_b;               // offsets in a chunk's partial (fragment layout): OB*KB blocks of 256, then OB*16 bias
 };
 
 struct FmPlan {
@@ -62,11 +64,14 @@ struct FmPlan {
   FmLin lin[FM_MAX_LIN];
   int g_ln;                      // flat offset of layers_norm.0.weight (then bias, then layer 1 ...)
   int packed_floats;
-  int lds_fwd_floats, lds_bwd_floats;
+  int lds_fwd_floats, lds_bwd_floats;   // size of ONE staging buffer (largest group, multiple of 256 floats)
+  int nfg, nbg;                         // number of forward / backward staging groups
+  int fgrp_off[FM_MAX_LIN], fgrp_floats[FM_MAX_LIN], bgrp_off[FM_MAX_LIN], bgrp_floats[FM_MAX_LIN];
   // stash slots in blocks of 256 floats, per wave-tile
   int s_in, s_c, s_te, s_ie, s_ce, s_h0, s_u, s_sh, s_rstd, s_diff;     // s_u + l*HB, s_sh + l*HB
   int g_v, g_u, g_te, g_h0, g_ie, g_ce;
   int SB;                        // blocks per wave-tile
+  int PF;                        // floats per weight-gradient partial (fragment layout)
   int ablate;                    // timing experiments only (env SBI_AMD_FM_ABLATE): 1 no stash traffic,
                                  // 2 no weight staging, 4 no GELU, 8 no hidden-layer MFMAs; results invalid
 };
@@ -129,21 +134,26 @@ static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
   fo[0] = J_IN; fo[1] = J_MA; fo[2] = J_CT; fo[3] = J_MB; fo[4] = J_TM;   // execution order of the forward kernel
   int p = 0;
   {
-    int gstart = 0, goff = 0;
+    int goff = 0;
     for (int k = 0; k < order_n; ++k) {
       FmLin& l = pl->lin[fo[k]];
       l.ldk = 16 * l.KB + 4;
       const int sz = round_up(16 * l.OB * l.ldk + 3 * 16 * l.OB, 4);
       if (sz > FM_FWD_GROUP_FLOATS) return SBI_AMD_E_LDS;
       if (k == 0 || p + sz - goff > FM_FWD_GROUP_FLOATS) {
-        if (k) { pl->lin[fo[gstart]].fg_floats = p - goff; }
-        gstart = k; goff = p; l.fg_first = 1; l.fg_off = p;
+        if (k) {   // close the previous group: 1 KB granules (one global_load_lds per wave and granule)
+          p = goff + round_up(p - goff, 256);
+          pl->fgrp_floats[pl->nfg - 1] = p - goff;
+        }
+        goff = p; l.fg_first = 1; pl->fgrp_off[pl->nfg++] = p;
       }
       l.w_off = p; l.lw = p - goff; l.lb = l.lw + 16 * l.OB * l.ldk;
       p += sz;
-      if (p - goff > pl->lds_fwd_floats) pl->lds_fwd_floats = p - goff;
     }
-    pl->lin[fo[gstart]].fg_floats = p - goff;
+    p = goff + round_up(p - goff, 256);
+    pl->fgrp_floats[pl->nfg - 1] = p - goff;
+    for (int k = 0; k < pl->nfg; ++k)
+      if (pl->fgrp_floats[k] > pl->lds_fwd_floats) pl->lds_fwd_floats = pl->fgrp_floats[k];
   }
   // backward order: OUT L(L-1) .. L0 MA MB; image = W^T[16*KB][ldt] + gamma [16*OB]
   {
@@ -151,23 +161,33 @@ static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
     bo[nb++] = J_L0 + L;
     for (int l = L - 1; l >= 0; --l) bo[nb++] = J_L0 + l;
     bo[nb++] = J_MA; bo[nb++] = J_MB;
-    int gstart = 0, goff = p;
+    int goff = p;
     for (int k = 0; k < nb; ++k) {
       FmLin& l = pl->lin[bo[k]];
       l.ldt = 16 * l.OB + 4;
       const int sz = round_up(16 * l.KB * l.ldt + 16 * l.OB, 4);
       if (sz > FM_BWD_GROUP_FLOATS) return SBI_AMD_E_LDS;
       if (k == 0 || p + sz - goff > FM_BWD_GROUP_FLOATS) {
-        if (k) { pl->lin[bo[gstart]].bg_floats = p - goff; }
-        gstart = k; goff = p; l.bg_first = 1; l.bg_off = p;
+        if (k) {
+          p = goff + round_up(p - goff, 256);
+          pl->bgrp_floats[pl->nbg - 1] = p - goff;
+        }
+        goff = p; l.bg_first = 1; pl->bgrp_off[pl->nbg++] = p;
       }
       l.t_off = p; l.ltw = p - goff; l.ltg = l.ltw + 16 * l.KB * l.ldt;
       p += sz;
-      if (p - goff > pl->lds_bwd_floats) pl->lds_bwd_floats = p - goff;
     }
-    pl->lin[bo[gstart]].bg_floats = p - goff;
+    p = goff + round_up(p - goff, 256);
+    pl->bgrp_floats[pl->nbg - 1] = p - goff;
+    for (int k = 0; k < pl->nbg; ++k)
+      if (pl->bgrp_floats[k] > pl->lds_bwd_floats) pl->lds_bwd_floats = pl->bgrp_floats[k];
   }
   pl->packed_floats = p;
+  for (int j = 0; j < pl->NL; ++j) {
+    FmLin& l = pl->lin[j];
+    l.pf_w = pl->PF; pl->PF += l.OB * l.KB * 256;
+    l.pf_b = pl->PF; pl->PF += l.OB * 16;
+  }
   if (const char* e = getenv("SBI_AMD_FM_ABLATE")) pl->ablate = atoi(e);
   return 0;
 }
@@ -203,17 +223,54 @@ __device__ __forceinline__ f4 gelu_grad4(f4 v) {
   return f4{gelu_grad_f(v[0]), gelu_grad_f(v[1]), gelu_grad_f(v[2]), gelu_grad_f(v[3])};
 }
 
-__device__ __forceinline__ void fm_stage(float* __restrict__ lds, const float* __restrict__ src, int floats, int tid) {
-  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
-  float4* d4 = reinterpret_cast<float4*>(lds);
-  const int n4 = floats >> 2;
-  int idx = tid;
-  for (; idx + 3 * FM_THREADS < n4; idx += 4 * FM_THREADS) {
-    const float4 a = s4[idx], b = s4[idx + FM_THREADS], c = s4[idx + 2 * FM_THREADS], d = s4[idx + 3 * FM_THREADS];
-    d4[idx] = a; d4[idx + FM_THREADS] = b; d4[idx + 2 * FM_THREADS] = c; d4[idx + 3 * FM_THREADS] = d;
-  }
-  for (; idx < n4; idx += FM_THREADS) d4[idx] = s4[idx];
+// Asynchronous weight staging: global_load_lds_dwordx4 writes 1 KB per wave instruction straight into LDS
+// (destination = wave-uniform base + lane * 16 B), no registers involved.  Group images are padded to 1 KB.
+__device__ __forceinline__ void fm_stage_async(float* __restrict__ lds_dst, const float* __restrict__ src, int floats,
+                                               int wave, int lane) {
+  const int nch = floats >> 8;
+  for (int ch = wave; ch < nch; ch += FM_WAVES)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ch * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
 }
+// Staging pipeline shared by the forward and backward kernels: two LDS buffers; while the linears of the group
+// in one buffer are computed, the next group (cyclically: the first group of the next tile after the last) is
+// in flight into the other.  One workgroup barrier per group.
+struct FmPipe {
+  float* lds;
+  const float* packed;
+  const int* goff;
+  const int* gfloats;
+  int ngroups, buf_floats, cur, par, wave, lane, started, off;
+  __device__ __forceinline__ void prefetch_next() {
+    if (off) return;
+    const int nxt = cur + 1 == ngroups ? 0 : cur + 1;
+    fm_stage_async(lds + (par ^ 1) * buf_floats, packed + goff[nxt], gfloats[nxt], wave, lane);
+  }
+  __device__ __forceinline__ void init(float* lds_, const float* packed_, const int* goff_, const int* gfloats_,
+                                       int ngroups_, int buf_floats_, int wave_, int lane_, int off_) {
+    lds = lds_; packed = packed_; goff = goff_; gfloats = gfloats_; ngroups = ngroups_; buf_floats = buf_floats_;
+    cur = 0; par = 0; wave = wave_; lane = lane_; started = 0; off = off_;
+    fm_stage_async(lds, packed + goff[0], gfloats[0], wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    prefetch_next();
+  }
+  // called before a linear that opens a group; returns the LDS base of the resident group
+  __device__ __forceinline__ void enter(int opens_group) {
+    if (opens_group) {
+      if (started) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next group has landed ...
+        __syncthreads();                                   // ... for every wave, and all are done with this one
+        cur = cur + 1 == ngroups ? 0 : cur + 1;
+        par ^= 1;
+        prefetch_next();
+      }
+      started = 1;
+    }
+  }
+  __device__ __forceinline__ const float* base() const { return lds + par * buf_floats; }
+  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
 
 // stash blocks: natural [row][16 feats] (one b128 per lane) and transposed [feat][row]
 __device__ __forceinline__ void st_nat(float* __restrict__ wtb, int blk, int c, int g, f4 v) {
@@ -281,6 +338,7 @@ struct FmArgs {
   long long n; int x_rows, t_rows;
   float* loss_out; float* v_out; float* stash; float* ln_part;
   int ntiles;
+  long long* timeline;   // debug (env SBI_AMD_FM_TIMELINE): s_memtime stamps of workgroup 0, wave 0
 };
 
 // LDS tail after the weight group: mean_0[D] std_0[D] vstd[D] xmean[C] xinv[C] (floats)
@@ -289,9 +347,9 @@ struct FmArgs {
 // ---------------------------------------------------------------- forward
 // MODE 0: velocity, 1: loss only, 2: loss + stash (training)
 template <int HB, int MODE>
-__global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, const FmArgs a) {
+__global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, const FmArgs a) {
   extern __shared__ __align__(16) float lds[];
-  float* zs = lds + pl.lds_fwd_floats;
+  float* zs = lds + 2 * pl.lds_fwd_floats;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int D = pl.D, C = pl.C, H = pl.H;
   float* z_mean = zs; float* z_std = zs + 128; float* z_vstd = zs + 256; float* z_xm = zs + 384; float* z_xi = zs + 512;
@@ -302,8 +360,13 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
     z_xi[i] = i < C ? 1.0f / a.zstats[2 * D + C + i] : 0.f;
   }
   const float invH = 1.0f / (float)H;
+  FmPipe pipe;
+  pipe.init(lds, a.packed, pl.fgrp_off, pl.fgrp_floats, pl.nfg, pl.lds_fwd_floats, wave, lane, pl.ablate & 2);
+  const float* wb = lds;
+  int titer = -1;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const long long wt = (long long)tile * 4 + wave;
+    ++titer;
+    const long long wt = (long long)tile * FM_WAVES + wave;
     const long long row_raw = wt * 16 + c;
     const bool valid = row_raw < a.n;
     const long long row = valid ? row_raw : a.n - 1;
@@ -314,24 +377,23 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
     const float* nz = MODE == 0 ? nullptr : a.noise + row * D;
     const float* xr = a.x + (a.x_rows == 1 ? 0 : row) * C;
 
-#define FM_ENTER(J)                                                        \
-  {                                                                        \
-    const FmLin& q_ = pl.lin[J];                                           \
-    if (q_.fg_first) {                                                     \
-      __syncthreads();                                                     \
-      if (!(pl.ablate & 2)) fm_stage(lds, a.packed + q_.fg_off, q_.fg_floats, tid); \
-      __syncthreads();                                                     \
-    }                                                                      \
+#define FM_TS(K) if (a.timeline && blockIdx.x == 0 && tid == 0) a.timeline[titer * 32 + (K)] = __builtin_readcyclecounter();
+#define FM_ENTER(J)                 \
+  {                                 \
+    pipe.enter(pl.lin[J].fg_first); \
+    wb = pipe.base();               \
   }
     f4 acc[HB], temb[HB], h[HB];
     // ---- input layer: theta_t -> time-dependent z-score -> Linear(D, H); then the first half of the merge
+    FM_TS(0);
     FM_ENTER(J_IN);
+    FM_TS(1);
     {
       const FmLin& q = pl.lin[J_IN];
       f4 ie[HB];
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob) ie[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
-      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      for (int ob = 0; ob < HB; ++ob) ie[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
+      const float* wl = wb + q.lw + c * q.ldk + 4 * g;
       for (int kb = 0; kb < pl.DB; ++kb) {
         f4 v;
 #pragma unroll
@@ -356,21 +418,25 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
       }
     }
     // merge: Linear(2H, H) on GELU([ie, ce]) as two K = H products
+    FM_TS(2);
     FM_ENTER(J_MA);
+    FM_TS(3);
     {
       const FmLin& q = pl.lin[J_MA];
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
-      gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
+      gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
     }
     // ---- condition layer: standardised x -> Linear(C, H); second half of the merge
+    FM_TS(4);
     FM_ENTER(J_CT);
+    FM_TS(5);
     {
       const FmLin& q = pl.lin[J_CT];
       f4 ce[HB];
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob) ce[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
-      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      for (int ob = 0; ob < HB; ++ob) ce[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
+      const float* wl = wb + q.lw + c * q.ldk + 4 * g;
       for (int kb = 0; kb < pl.CB; ++kb) {
         f4 v;
 #pragma unroll
@@ -387,10 +453,12 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
         h[ob] = gelu4(ce[ob]);
       }
     }
+    FM_TS(6);
     FM_ENTER(J_MB);
+    FM_TS(7);
     {
       const FmLin& q = pl.lin[J_MB];
-      gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
     }
 #pragma unroll
     for (int ob = 0; ob < HB; ++ob) {
@@ -398,12 +466,14 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
       h[ob] = gelu4(acc[ob]);
     }
     // ---- time embedding: sin/cos features -> Linear(E, H)
+    FM_TS(8);
     FM_ENTER(J_TM);
+    FM_TS(9);
     {
       const FmLin& q = pl.lin[J_TM];
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob) temb[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
-      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      for (int ob = 0; ob < HB; ++ob) temb[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
+      const float* wl = wb + q.lw + c * q.ldk + 4 * g;
       for (int kb = 0; kb < pl.EB; ++kb) {
         f4 v;
 #pragma unroll
@@ -423,11 +493,13 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
     }
     // ---- residual blocks: h <- LayerNorm(GELU(W h + b) + temb + h)
     for (int l = 0; l < pl.L; ++l) {
+      FM_TS(10 + 2 * l);
       FM_ENTER(J_L0 + l);
+      FM_TS(11 + 2 * l);
       const FmLin& q = pl.lin[J_L0 + l];
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g);
-      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(lds + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
+      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
       float s1 = 0.f;
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
@@ -452,19 +524,21 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
       for (int ob = 0; ob < HB; ++ob) {
         const f4 sh = acc[ob] * rstd;
         if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_sh + l * HB + ob, c, g, sh);
-        const f4 gam = *reinterpret_cast<const f4*>(lds + q.lb + 16 * HB + 16 * ob + 4 * g);
-        const f4 bet = *reinterpret_cast<const f4*>(lds + q.lb + 32 * HB + 16 * ob + 4 * g);
+        const f4 gam = *reinterpret_cast<const f4*>(wb + q.lb + 16 * HB + 16 * ob + 4 * g);
+        const f4 bet = *reinterpret_cast<const f4*>(wb + q.lb + 32 * HB + 16 * ob + 4 * g);
         h[ob] = sh * gam + bet;
       }
     }
     // ---- output layer + loss / velocity
+    FM_TS(10 + 2 * pl.L);
     FM_ENTER(J_L0 + pl.L);
+    FM_TS(11 + 2 * pl.L);
     {
       const FmLin& q = pl.lin[J_L0 + pl.L];
-      const float* wl = lds + q.lw + c * q.ldk + 4 * g;
+      const float* wl = wb + q.lw + c * q.ldk + 4 * g;
       float lsum = 0.f;
       for (int ob = 0; ob < pl.DB; ++ob) {
-        f4 o0 = *reinterpret_cast<const f4*>(lds + q.lb + 16 * ob + 4 * g), o1 = f4{0.f, 0.f, 0.f, 0.f};
+        f4 o0 = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g), o1 = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < HB; ++kb) {
           const f4 av = *reinterpret_cast<const f4*>(wl + ob * 16 * q.ldk + 16 * kb);
@@ -497,42 +571,44 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_fwd_kernel(const FmPlan pl, 
         if (g == 0 && valid) a.loss_out[row] = lsum / (float)D;
       }
     }
+    FM_TS(12 + 2 * pl.L);
   }
+  pipe.drain();
 #undef FM_ENTER
+#undef FM_TS
 }
 
 // ---------------------------------------------------------------- backward (dX chain)
 template <int HB>
-__global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, const FmArgs a) {
+__global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, const FmArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int D = pl.D, H = pl.H, L = pl.L;
   const float invH = 1.0f / (float)H;
-  float* lnp = a.ln_part + ((long long)blockIdx.x * 4 + wave) * (long long)(L * 2 * 16 * HB);
+  float* lnp = a.ln_part + ((long long)blockIdx.x * FM_WAVES + wave) * (long long)(L * 2 * 16 * HB);
+  FmPipe pipe;
+  pipe.init(lds, a.packed, pl.bgrp_off, pl.bgrp_floats, pl.nbg, pl.lds_bwd_floats, wave, lane, pl.ablate & 2);
+  const float* wb = lds;
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const long long wt = (long long)tile * 4 + wave;
+    const long long wt = (long long)tile * FM_WAVES + wave;
     const long long row_raw = wt * 16 + c;
     const bool valid = row_raw < a.n;
     float* wtb = a.stash + wt * (long long)pl.SB * 256;
     float wrow = 0.f;
     if (valid) wrow = (a.row_weight ? a.row_weight[row_raw] : a.uniform_weight) * (2.0f / (float)D);
 
-#define FM_BENTER(J)                                                       \
-  {                                                                        \
-    const FmLin& q_ = pl.lin[J];                                           \
-    if (q_.bg_first) {                                                     \
-      __syncthreads();                                                     \
-      if (!(pl.ablate & 2)) fm_stage(lds, a.packed + q_.bg_off, q_.bg_floats, tid); \
-      __syncthreads();                                                     \
-    }                                                                      \
+#define FM_BENTER(J)                \
+  {                                 \
+    pipe.enter(pl.lin[J].bg_first); \
+    wb = pipe.base();               \
   }
     f4 gh[HB], gte[HB], acc[HB];
     // ---- output layer: g_v = 2 w (out - target) / D ; g_h = W_o^T g_v
     FM_BENTER(J_L0 + L);
     {
       const FmLin& q = pl.lin[J_L0 + L];
-      const float* wl = lds + q.ltw + c * q.ldt + 4 * g;
+      const float* wl = wb + q.ltw + c * q.ldt + 4 * g;
 #pragma unroll
       for (int ib = 0; ib < HB; ++ib) { gh[ib] = f4{0.f, 0.f, 0.f, 0.f}; gte[ib] = f4{0.f, 0.f, 0.f, 0.f}; }
       for (int ob = 0; ob < pl.DB; ++ob) {
@@ -551,7 +627,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
         sh[ob] = ld_nat(wtb, pl.s_sh + l * HB + ob, c, g);
-        const f4 gam = *reinterpret_cast<const f4*>(lds + q.ltg + 16 * ob + 4 * g);
+        const f4 gam = *reinterpret_cast<const f4*>(wb + q.ltg + 16 * ob + 4 * g);
         // LayerNorm parameter gradients: reduce over this wave's 16 rows, one add per feature into the
         // wave's private partial (single writer: deterministic)
         const f4 pg = gh[ob] * sh[ob];
@@ -583,7 +659,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
         gu[ob] = (pl.ablate & 4) ? gs * u : gs * gelu_grad4(u);
         if (!(pl.ablate & 1)) st_tr(wtb, pl.g_u + l * HB + ob, c, g, gu[ob]);
       }
-      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gu, acc);
+      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gu, acc);
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) gh[ob] = acc[ob];
     }
@@ -600,7 +676,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
       const FmLin& q = pl.lin[J_MA];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
-      gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
+      gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob)
         st_tr(wtb, pl.g_ie + ob, c, g, acc[ob] * gelu_grad4(ld_nat(wtb, pl.s_ie + ob, c, g)));
@@ -610,12 +686,13 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
       const FmLin& q = pl.lin[J_MB];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
-      gemm_rr<HB, HB>(lds + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
+      gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob)
         st_tr(wtb, pl.g_ce + ob, c, g, acc[ob] * gelu_grad4(ld_nat(wtb, pl.s_ce + ob, c, g)));
     }
   }
+  pipe.drain();
 #undef FM_BENTER
 }
 
@@ -626,7 +703,7 @@ __global__ void __launch_bounds__(FM_THREADS, 2) fm_bwd_kernel(const FmPlan pl, 
 // X blocks.  Operands of the next wave-tile are in flight under the MFMAs of the current one.  The four waves'
 // sums are combined through LDS in a fixed order and written as the chunk's partial.
 template <int NB>
-__global__ void __launch_bounds__(FM_THREADS) fm_dw_kernel(const FmPlan pl, const float* __restrict__ stash,
+__global__ void __launch_bounds__(FM_DW_THREADS) fm_dw_kernel(const FmPlan pl, const float* __restrict__ stash,
                                                            long long nwt, float* __restrict__ partials) {
   extern __shared__ __align__(16) float lds[];
   const int j = blockIdx.y;
@@ -652,30 +729,32 @@ __global__ void __launch_bounds__(FM_THREADS) fm_dw_kernel(const FmPlan pl, cons
   auto load_ops = [&](long long wt, f4 (&a_)[NB], f4 (&b_)[NB]) {
     const float* ga = gbase + wt * wstride;
     const float* xb = xbase + wt * wstride;
+    // every block slot is loaded unconditionally (slots past OB / KB re-read the last real block): a static
+    // number of loads per iteration lets the compiler keep the prefetch in flight (s_waitcnt vmcnt(N), N > 0)
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob)
-      if (ob < OB) a_[ob] = *reinterpret_cast<const f4*>(ga + ob * 256);
+    for (int ob = 0; ob < NB; ++ob) a_[ob] = *reinterpret_cast<const f4*>(ga + (ob < OB ? ob : OB - 1) * 256);
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
-      if (kb < KB) b_[kb] = f4{xb[kb * 256], xb[kb * 256 + 16], xb[kb * 256 + 32], xb[kb * 256 + 48]};
+    for (int kb = 0; kb < NB; ++kb) {
+      const float* xk = xb + (kb < KB ? kb : KB - 1) * 256;
+      b_[kb] = f4{xk[0], xk[16], xk[32], xk[48]};
+    }
   };
   if (PF && wt0 < wt1) load_ops(wt0, av, bv);
   for (long long wt = wt0; wt < wt1; wt += 4) {
     if constexpr (PF) {
-      if (wt + 4 < wt1) load_ops(wt + 4, avn, bvn);
+      if (wt + 4 < wt1) load_ops((pl.ablate & 32) ? wt0 : wt + 4, avn, bvn);
     } else {
       load_ops(wt, av, bv);
     }
     if (q.x_gelu) {
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb)
-        if (kb < KB) bv[kb] = gelu4(bv[kb]);
+      for (int kb = 0; kb < NB; ++kb) bv[kb] = gelu4(bv[kb]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob) {
-        if (ob < OB) {
+        if (ob < OB && !((pl.ablate & 16) && ob > 0)) {
 #pragma unroll
           for (int kb = 0; kb < NB; ++kb)
             if (kb < KB) acc[ob][kb] = MFMA16(av[ob][r], bv[kb][r], acc[ob][kb]);
@@ -683,8 +762,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_dw_kernel(const FmPlan pl, cons
       }
     }
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob)
-      if (ob < OB) accb[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
+    for (int ob = 0; ob < NB; ++ob) accb[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
     if constexpr (PF) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) { av[b] = avn[b]; bv[b] = bvn[b]; }
@@ -722,40 +800,46 @@ __global__ void __launch_bounds__(FM_THREADS) fm_dw_kernel(const FmPlan pl, cons
   __syncthreads();
   if (wave != 0) return;
   absorb(lds);
-  float* part = partials + (long long)blockIdx.x * pl.P;
+  // partial in FRAGMENT layout (one 1 KB store per block); fm_reduce_kernel maps it to the flat gradient
+  float* part = partials + (long long)blockIdx.x * pl.PF;
 #pragma unroll
   for (int ob = 0; ob < NB; ++ob) {
     if (ob >= OB) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = 16 * ob + 4 * g + i;
-      if (o >= q.out) continue;
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) {
-        const int in = 16 * kb + c;
-        if (kb < KB && in < q.in) part[q.g_w + o * q.g_ld + in] = acc[ob][kb][i];
-      }
-    }
-    if (want_bias && g == 0 && 16 * ob + c < q.out) part[q.g_b + 16 * ob + c] = accb[ob];
+    for (int kb = 0; kb < NB; ++kb)
+      if (kb < KB) *reinterpret_cast<f4*>(part + q.pf_w + ((ob * KB + kb) * 64 + lane) * 4) = acc[ob][kb];
+    if (g == 0) part[q.pf_b + ob * 16 + c] = accb[ob];
   }
 }
 
-// grad[idx] = sum over row chunks of the weight-gradient partials (LayerNorm slots are written by fm_ln_reduce_kernel)
+// Sums the chunks' fragment-layout partials (coalesced) and scatters each element to its place in the flat
+// gradient: block (ob, kb), lane (c, g), register i  ->  dW[16*ob + 4*g + i][16*kb + c]
 __global__ void __launch_bounds__(256) fm_reduce_kernel(const FmPlan pl, const float* __restrict__ partials, int nchunk,
                                                         float* __restrict__ grad) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= pl.P) return;
-  if (idx >= pl.g_ln && idx < pl.g_ln + 2 * pl.H * pl.L) return;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= pl.PF) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int i = 0;
   for (; i + 3 < nchunk; i += 4) {
-    s0 += partials[(long long)i * pl.P + idx];
-    s1 += partials[(long long)(i + 1) * pl.P + idx];
-    s2 += partials[(long long)(i + 2) * pl.P + idx];
-    s3 += partials[(long long)(i + 3) * pl.P + idx];
+    s0 += partials[(long long)i * pl.PF + e];
+    s1 += partials[(long long)(i + 1) * pl.PF + e];
+    s2 += partials[(long long)(i + 2) * pl.PF + e];
+    s3 += partials[(long long)(i + 3) * pl.PF + e];
   }
-  for (; i < nchunk; ++i) s0 += partials[(long long)i * pl.P + idx];
-  grad[idx] = (s0 + s1) + (s2 + s3);
+  for (; i < nchunk; ++i) s0 += partials[(long long)i * pl.PF + e];
+  const float sum = (s0 + s1) + (s2 + s3);
+  int j = 0;
+  while (j + 1 < pl.NL && e >= pl.lin[j + 1].pf_w) ++j;
+  const FmLin& q = pl.lin[j];
+  if (e < q.pf_b) {
+    const int r = e - q.pf_w, blk = r >> 8, lane = (r & 255) >> 2, ii = r & 3;
+    const int ob = blk / q.KB, kb = blk - ob * q.KB;
+    const int o = 16 * ob + 4 * (lane >> 4) + ii, in = 16 * kb + (lane & 15);
+    if (o < q.out && in < q.in) grad[q.g_w + o * q.g_ld + in] = sum;
+  } else {
+    const int o = e - q.pf_b;
+    if (o < q.out && q.g_b >= 0) grad[q.g_b + o] = sum;
+  }
 }
 
 // LayerNorm gamma / beta gradients: one workgroup per (layer, gamma|beta, 16-feature block) sums the backward
@@ -839,13 +923,12 @@ static int fm_grid(int ntiles) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
-  const int g = 2 * cus;
-  return ntiles < g ? ntiles : g;
+  return ntiles < cus ? ntiles : cus;   // one 8-wave workgroup per CU
 }
 
 template <int MODE>
 static int fm_launch_fwd(const FmPlan& pl, const FmArgs& a, hipStream_t st) {
-  const size_t lds = 4ull * (pl.lds_fwd_floats + FM_ZS_FLOATS);
+  const size_t lds = 4ull * (2 * pl.lds_fwd_floats + FM_ZS_FLOATS);
   const int grid = fm_grid(a.ntiles);
 #define FM_FWD_CASE(HBV)                                                                                        \
   case HBV: {                                                                                                   \
@@ -866,7 +949,7 @@ static int fm_launch_fwd(const FmPlan& pl, const FmArgs& a, hipStream_t st) {
 }
 
 static int fm_launch_bwd(const FmPlan& pl, const FmArgs& a, int grid, hipStream_t st) {
-  const size_t lds = 4ull * pl.lds_bwd_floats;
+  const size_t lds = 4ull * 2 * pl.lds_bwd_floats;
 #define FM_BWD_CASE(HBV)                                                                                        \
   case HBV: {                                                                                                   \
     hipError_t e = hipFuncSetAttribute((const void*)fm_bwd_kernel<HBV>,                                         \
@@ -889,12 +972,12 @@ struct FmWs { long long stash, partials, ln_part, total; int nchunk, nln_max; lo
 static FmWs fm_ws_layout(const FmPlan& pl, long long n) {
   FmWs w;
   w.ntiles = (int)((n + FM_ROWS - 1) / FM_ROWS);
-  w.nwt = (long long)w.ntiles * 4;
+  w.nwt = (long long)w.ntiles * FM_WAVES;
   w.nchunk = (int)((w.nwt + FM_DW_TILES - 1) / FM_DW_TILES);
-  w.nln_max = 4 * 2 * 1024;   // backward waves: 4 per workgroup, at most 2 workgroups per CU, CUs <= 1024
+  w.nln_max = FM_WAVES * 1024;   // backward waves: 8 per workgroup, one workgroup per CU, CUs <= 1024
   w.stash = 0;
   w.partials = w.stash + w.nwt * (long long)pl.SB * 256;
-  w.ln_part = w.partials + (long long)w.nchunk * pl.P;
+  w.ln_part = w.partials + (long long)w.nchunk * pl.PF;
   w.total = w.ln_part + (long long)w.nln_max * pl.L * 2 * 16 * pl.HB;
   return w;
 }
@@ -1009,10 +1092,30 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
   a.x_rows = (x_rows == 1 || n == 1) ? 1 : 2; a.t_rows = n == 1 ? 1 : 2;
   a.row_weight = row_weight; a.uniform_weight = uniform_weight;
   a.loss_out = loss_out; a.stash = workspace + w.stash; a.ln_part = workspace + w.ln_part; a.ntiles = w.ntiles;
+  static long long* tl_dev = nullptr;
+  if (getenv("SBI_AMD_FM_TIMELINE")) {
+    if (!tl_dev) { hipMalloc(&tl_dev, 8 * 32 * 8); }
+    hipMemsetAsync(tl_dev, 0, 8 * 32 * 8, st);
+    a.timeline = tl_dev;
+  }
   rc = fm_launch_fwd<2>(pl, a, st);
   if (rc) return rc;
+  if (a.timeline) {
+    static int shown = 0;
+    if (++shown == 20) {
+      long long h[8 * 32];
+      hipStreamSynchronize(st);
+      hipMemcpy(h, tl_dev, sizeof(h), hipMemcpyDeviceToHost);
+      for (int it = 0; it < 3; ++it) {
+        fprintf(stderr, "fwd timeline tile-iter %d:", it);
+        for (int k = 1; k < 32 && h[it * 32 + k]; ++k) fprintf(stderr, " %lld", h[it * 32 + k] - h[it * 32 + k - 1]);
+        fprintf(stderr, "\n");
+      }
+    }
+    a.timeline = nullptr;
+  }
   const int bgrid = fm_grid(w.ntiles);
-  const int nln = bgrid * 4;
+  const int nln = bgrid * FM_WAVES;
   if (nln > w.nln_max) return SBI_AMD_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(workspace + w.ln_part, 0, 4ull * nln * pl.L * 2 * 16 * pl.HB, st);
   if (e != hipSuccess) return (int)e;
@@ -1029,7 +1132,7 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
     hipError_t e2 = hipFuncSetAttribute((const void*)fm_dw_kernel<NBV>,                                         \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);                 \
     if (e2 != hipSuccess) return (int)e2;                                                                       \
-    hipLaunchKernelGGL((fm_dw_kernel<NBV>), dim3(w.nchunk, pl.NL), dim3(FM_THREADS), dlds, st, pl,              \
+    hipLaunchKernelGGL((fm_dw_kernel<NBV>), dim3(w.nchunk, pl.NL), dim3(FM_DW_THREADS), dlds, st, pl,              \
                        workspace + w.stash, w.nwt, workspace + w.partials);                                     \
     break;                                                                                                      \
   }
@@ -1040,7 +1143,7 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
     }
 #undef FM_DW_CASE
   }
-  hipLaunchKernelGGL(fm_reduce_kernel, dim3((pl.P + 255) / 256), dim3(256), 0, st, pl, workspace + w.partials,
+  hipLaunchKernelGGL(fm_reduce_kernel, dim3((pl.PF + 255) / 256), dim3(256), 0, st, pl, workspace + w.partials,
                      w.nchunk, grad_out);
   hipLaunchKernelGGL(fm_ln_reduce_kernel, dim3(pl.L * 2 * pl.HB), dim3(256), 0, st, pl, workspace + w.ln_part, nln,
                      grad_out);
