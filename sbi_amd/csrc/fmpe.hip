@@ -255,18 +255,31 @@ struct FmPipe {
     __syncthreads();
     prefetch_next();
   }
-  // called before a linear that opens a group; returns the LDS base of the resident group
-  __device__ __forceinline__ void enter(int opens_group) {
+  // Called before a linear that opens a group, in two halves so that a kernel can consume values it loaded
+  // into registers during the previous stage BETWEEN them: after enter_wait nothing is outstanding (the
+  // compiler's own conservative vmcnt(0) at the first use costs nothing); once enter_prefetch has issued the
+  // next group's global_load_lds, any ordinary load result would have to wait for those as well.
+  int pending;
+  __device__ __forceinline__ void enter_wait(int opens_group) {
+    pending = 0;
     if (opens_group) {
       if (started) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next group has landed ...
         __syncthreads();                                   // ... for every wave, and all are done with this one
         cur = cur + 1 == ngroups ? 0 : cur + 1;
         par ^= 1;
-        prefetch_next();
+        pending = 1;
       }
       started = 1;
     }
+  }
+  __device__ __forceinline__ void enter_prefetch() {
+    if (pending) prefetch_next();
+    pending = 0;
+  }
+  __device__ __forceinline__ void enter(int opens_group) {
+    enter_wait(opens_group);
+    enter_prefetch();
   }
   __device__ __forceinline__ const float* base() const { return lds + par * buf_floats; }
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -319,16 +332,45 @@ __device__ __forceinline__ void gemm_rr(const float* __restrict__ wl, int ld, co
   }
 }
 
+// same, with a callback after the MFMAs of each K block (b[kb] is dead from then on: the caller may refill it)
+template <int OB, int KB, class F>
+__device__ __forceinline__ void gemm_rr_cb(const float* __restrict__ wl, int ld, f4 (&b)[KB], f4 (&acc)[OB], F after_kb) {
+  f4 a[2][OB];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) a[0][ob] = *reinterpret_cast<const f4*>(wl + ob * 16 * ld);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+        a[(kb + 1) & 1][ob] = *reinterpret_cast<const f4*>(wl + ob * 16 * ld + 16 * (kb + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) acc[ob] = MFMA16(a[kb & 1][ob][r], b[kb][r], acc[ob]);
+    __builtin_amdgcn_sched_barrier(0);
+    after_kb(kb);
+  }
+}
+
 __device__ __forceinline__ float sum_over_g(float v) {   // lanes c, c+16, c+32, c+48
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
 }
-__device__ __forceinline__ float sum_over_c(float v) {   // the 16 lanes of one g
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
+// sum over the 16 lanes of one g (= one DPP row): four row rotations on the VALU (v_add_f32 ... row_ror:n)
+// instead of four ds_bpermute round trips through the LDS pipeline; every lane ends with the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum_over_c(float v) {
+  v += dpp_rot<0x128>(v);   // row_ror:8
+  v += dpp_rot<0x124>(v);   // row_ror:4
+  v += dpp_rot<0x122>(v);   // row_ror:2
+  v += dpp_rot<0x121>(v);   // row_ror:1
   return v;
 }
 
@@ -384,9 +426,45 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     wb = pipe.base();               \
   }
     f4 acc[HB], temb[HB], h[HB];
+    // Inputs of the first four 16-feature blocks (theta-dim / x-dim <= 64) are fetched one stage ahead of their
+    // use and turned into operand blocks between the two halves of the stage entry; further blocks take the
+    // inline path.
+    auto load_theta_noise = [&](f4 (&tv)[4], f4 (&nv)[4]) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 16 * kb + 4 * g + i;
+          tv[kb][i] = f < D ? th[f] : 0.f;
+          nv[kb][i] = (MODE != 0 && f < D) ? nz[f] : 0.f;
+        }
+      }
+    };
+    auto in_block = [&](int kb, const f4& tv, const f4& nv) {
+      f4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * kb + 4 * g + i;
+        float val = 0.f;
+        if (f < D) {
+          float tt = tv[i];
+          if (MODE != 0) tt = om * tt + (t + pl.noise_scale) * nv[i];
+          const float sd = om * z_std[f];
+          val = (tt - om * z_mean[f]) / sqrtf(sd * sd + t * t + 1e-6f);
+        }
+        v[i] = val;
+      }
+      return v;
+    };
+    f4 thv[4], nzv[4], blk4[4];
     // ---- input layer: theta_t -> time-dependent z-score -> Linear(D, H); then the first half of the merge
     FM_TS(0);
-    FM_ENTER(J_IN);
+    load_theta_noise(thv, nzv);
+    pipe.enter_wait(pl.lin[J_IN].fg_first);
+    wb = pipe.base();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) blk4[kb] = in_block(kb, thv[kb], nzv[kb]);
+    pipe.enter_prefetch();
     FM_TS(1);
     {
       const FmLin& q = pl.lin[J_IN];
@@ -394,20 +472,22 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) ie[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
       const float* wl = wb + q.lw + c * q.ldk + 4 * g;
-      for (int kb = 0; kb < pl.DB; ++kb) {
-        f4 v;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        if (kb < pl.DB) {
+          if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_in + kb, c, g, blk4[kb]);
+          gemm_blk<HB>(wl, q.ldk, kb, blk4[kb], ie);
+        }
+      }
+      for (int kb = 4; kb < pl.DB; ++kb) {
+        f4 tv, nv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int f = 16 * kb + 4 * g + i;
-          float val = 0.f;
-          if (f < D) {
-            float tt = th[f];
-            if (MODE != 0) tt = om * tt + (t + pl.noise_scale) * nz[f];
-            const float sd = om * z_std[f];
-            val = (tt - om * z_mean[f]) / sqrtf(sd * sd + t * t + 1e-6f);
-          }
-          v[i] = val;
+          tv[i] = f < D ? th[f] : 0.f;
+          nv[i] = (MODE != 0 && f < D) ? nz[f] : 0.f;
         }
+        const f4 v = in_block(kb, tv, nv);
         if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_in + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, ie);
       }
@@ -419,7 +499,25 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     }
     // merge: Linear(2H, H) on GELU([ie, ce]) as two K = H products
     FM_TS(2);
-    FM_ENTER(J_MA);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * kb + 4 * g + i;
+        thv[kb][i] = f < C ? xr[f] : 0.f;
+      }
+    }
+    pipe.enter_wait(pl.lin[J_MA].fg_first);
+    wb = pipe.base();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * kb + 4 * g + i;
+        blk4[kb][i] = f < C ? (thv[kb][i] - z_xm[f]) * z_xi[f] : 0.f;
+      }
+    }
+    pipe.enter_prefetch();
     FM_TS(3);
     {
       const FmLin& q = pl.lin[J_MA];
@@ -437,7 +535,14 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) ce[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
       const float* wl = wb + q.lw + c * q.ldk + 4 * g;
-      for (int kb = 0; kb < pl.CB; ++kb) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        if (kb < pl.CB) {
+          if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_c + kb, c, g, blk4[kb]);
+          gemm_blk<HB>(wl, q.ldk, kb, blk4[kb], ce);
+        }
+      }
+      for (int kb = 4; kb < pl.CB; ++kb) {
         f4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -531,7 +636,20 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     }
     // ---- output layer + loss / velocity
     FM_TS(10 + 2 * pl.L);
-    FM_ENTER(J_L0 + pl.L);
+    if (MODE != 0) load_theta_noise(thv, nzv);
+    pipe.enter_wait(pl.lin[J_L0 + pl.L].fg_first);
+    wb = pipe.base();
+    if (MODE != 0) {   // normalised velocity targets of the prefetched blocks
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 16 * kb + 4 * g + i;
+          blk4[kb][i] = f < D ? ((nzv[kb][i] - thv[kb][i]) + z_mean[f]) / z_vstd[f] : 0.f;
+        }
+      }
+    }
+    pipe.enter_prefetch();
     FM_TS(11 + 2 * pl.L);
     {
       const FmLin& q = pl.lin[J_L0 + pl.L];
@@ -559,7 +677,17 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
             if (f < D && valid) a.v_out[row * D + f] = o0[i] * z_vstd[f] - z_mean[f];
           } else {
             float d = 0.f;
-            if (f < D) d = o0[i] - ((nz[f] - th[f]) + z_mean[f]) / z_vstd[f];
+            if (f < D) {
+              float tgt;
+              switch (ob) {   // uniform: ob is a loop counter
+                case 0: tgt = blk4[0][i]; break;
+                case 1: tgt = blk4[1][i]; break;
+                case 2: tgt = blk4[2][i]; break;
+                case 3: tgt = blk4[3][i]; break;
+                default: tgt = ((nz[f] - th[f]) + z_mean[f]) / z_vstd[f];
+              }
+              d = o0[i] - tgt;
+            }
             diff[i] = d;
             lsum += d * d;
           }
@@ -604,14 +732,37 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
     wb = pipe.base();               \
   }
     f4 gh[HB], gte[HB], acc[HB];
+    // Stash reads are issued one stage ahead, in place, as soon as the registers they refill are dead, and
+    // always BEFORE the stage's global_load_lds (see FmPipe::enter_wait).
+    f4 sh[HB], u[HB], dv[4];
+    float rstd;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) dv[ob] = ld_nat(wtb, pl.s_diff + (ob < pl.DB ? ob : 0), c, g);
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) {
+      sh[ob] = ld_nat(wtb, pl.s_sh + (L - 1) * HB + ob, c, g);
+      u[ob] = ld_nat(wtb, pl.s_u + (L - 1) * HB + ob, c, g);
+    }
+    rstd = wtb[pl.s_rstd * 256 + (L - 1) * 16 + c];
     // ---- output layer: g_v = 2 w (out - target) / D ; g_h = W_o^T g_v
-    FM_BENTER(J_L0 + L);
+    pipe.enter_wait(pl.lin[J_L0 + L].bg_first);
+    wb = pipe.base();
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) dv[ob] = dv[ob] * wrow;
+    pipe.enter_prefetch();
     {
       const FmLin& q = pl.lin[J_L0 + L];
       const float* wl = wb + q.ltw + c * q.ldt + 4 * g;
 #pragma unroll
       for (int ib = 0; ib < HB; ++ib) { gh[ib] = f4{0.f, 0.f, 0.f, 0.f}; gte[ib] = f4{0.f, 0.f, 0.f, 0.f}; }
-      for (int ob = 0; ob < pl.DB; ++ob) {
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        if (ob < pl.DB) {
+          if (!(pl.ablate & 1)) st_tr(wtb, pl.g_v + ob, c, g, dv[ob]);
+          gemm_blk<HB>(wl, q.ldt, ob, dv[ob], gh);
+        }
+      }
+      for (int ob = 4; ob < pl.DB; ++ob) {
         const f4 gv = ld_nat(wtb, pl.s_diff + ob, c, g) * wrow;
         if (!(pl.ablate & 1)) st_tr(wtb, pl.g_v + ob, c, g, gv);
         gemm_blk<HB>(wl, q.ldt, ob, gv, gh);
@@ -619,14 +770,12 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
     }
     // ---- residual blocks in reverse
     for (int l = L - 1; l >= 0; --l) {
-      FM_BENTER(J_L0 + l);
+      pipe.enter_wait(pl.lin[J_L0 + l].bg_first);
+      wb = pipe.base();
       const FmLin& q = pl.lin[J_L0 + l];
-      const float rstd = wtb[pl.s_rstd * 256 + l * 16 + c];
-      f4 sh[HB];
       float m1 = 0.f, m2 = 0.f;
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        sh[ob] = ld_nat(wtb, pl.s_sh + l * HB + ob, c, g);
         const f4 gam = *reinterpret_cast<const f4*>(wb + q.ltg + 16 * ob + 4 * g);
         // LayerNorm parameter gradients: reduce over this wave's 16 rows, one add per feature into the
         // wave's private partial (single writer: deterministic)
@@ -646,7 +795,6 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
       }
       m1 = sum_over_g(m1) * invH;
       m2 = sum_over_g(m2) * invH;
-      f4 gu[HB];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
         f4 gs;
@@ -655,41 +803,55 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
           gs[i] = (16 * ob + 4 * g + i) < H ? rstd * (gh[ob][i] - m1 - sh[ob][i] * m2) : 0.f;
         gte[ob] += gs;
         acc[ob] = gs;                                   // skip connection
-        const f4 u = ld_nat(wtb, pl.s_u + l * HB + ob, c, g);
-        gu[ob] = (pl.ablate & 4) ? gs * u : gs * gelu_grad4(u);
-        if (!(pl.ablate & 1)) st_tr(wtb, pl.g_u + l * HB + ob, c, g, gu[ob]);
+        u[ob] = (pl.ablate & 4) ? gs * u[ob] : gs * gelu_grad4(u[ob]);     // g_u, in place
+        if (!(pl.ablate & 1)) st_tr(wtb, pl.g_u + l * HB + ob, c, g, u[ob]);
       }
-      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gu, acc);
+      // refill for the next stage: layer l-1's (s_hat, u, rstd), or (ie, h0) after the first block; the u
+      // blocks are refilled inside the GEMM as soon as it has consumed them
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob)
+        sh[ob] = ld_nat(wtb, (l > 0 ? pl.s_sh + (l - 1) * HB : pl.s_ie) + ob, c, g);
+      rstd = wtb[pl.s_rstd * 256 + (l > 0 ? l - 1 : 0) * 16 + c];
+      pipe.enter_prefetch();
+      const int u_next = l > 0 ? pl.s_u + (l - 1) * HB : pl.s_h0;
+      gemm_rr_cb<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, u, acc,
+                         [&](int kb) { u[kb] = ld_nat(wtb, u_next + kb, c, g); });
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) gh[ob] = acc[ob];
     }
-    // ---- h = GELU(h0); merge layer; input / condition layers
+    // ---- h = GELU(h0); merge layer; input / condition layers     (u = h0, sh = ie)
+    pipe.enter_wait(pl.lin[J_MA].bg_first);
+    wb = pipe.base();
     f4 gh0[HB];
 #pragma unroll
     for (int ob = 0; ob < HB; ++ob) {
-      gh0[ob] = gh[ob] * gelu_grad4(ld_nat(wtb, pl.s_h0 + ob, c, g));
+      gh0[ob] = gh[ob] * gelu_grad4(u[ob]);
       st_tr(wtb, pl.g_h0 + ob, c, g, gh0[ob]);
       st_tr(wtb, pl.g_te + ob, c, g, gte[ob]);
+      u[ob] = ld_nat(wtb, pl.s_ce + ob, c, g);
+      sh[ob] = gelu_grad4(sh[ob]);
     }
-    FM_BENTER(J_MA);
+    pipe.enter_prefetch();
     {
       const FmLin& q = pl.lin[J_MA];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
       gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob)
-        st_tr(wtb, pl.g_ie + ob, c, g, acc[ob] * gelu_grad4(ld_nat(wtb, pl.s_ie + ob, c, g)));
+      for (int ob = 0; ob < HB; ++ob) st_tr(wtb, pl.g_ie + ob, c, g, acc[ob] * sh[ob]);
     }
-    FM_BENTER(J_MB);
+    pipe.enter_wait(pl.lin[J_MB].bg_first);
+    wb = pipe.base();
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) u[ob] = gelu_grad4(u[ob]);
+    pipe.enter_prefetch();
     {
       const FmLin& q = pl.lin[J_MB];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
       gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob)
-        st_tr(wtb, pl.g_ce + ob, c, g, acc[ob] * gelu_grad4(ld_nat(wtb, pl.s_ce + ob, c, g)));
+      for (int ob = 0; ob < HB; ++ob) st_tr(wtb, pl.g_ce + ob, c, g, acc[ob] * u[ob]);
     }
   }
   pipe.drain();
