@@ -406,6 +406,32 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
   pipe.init(lds, a.packed, pl.fgrp_off, pl.fgrp_floats, pl.nfg, pl.lds_fwd_floats, wave, lane, pl.ablate & 2);
   const float* wb = lds;
   int titer = -1;
+  // theta / noise / t of the first four blocks travel one tile ahead (loaded during the previous tile's output
+  // stage); x one stage ahead
+  f4 thv[4], nzv[4], blk4[4];
+  float t_pref = 0.f;
+  auto row_of = [&](int tile_) {
+    const long long r = ((long long)tile_ * FM_WAVES + wave) * 16 + c;
+    return r < a.n ? r : a.n - 1;
+  };
+  auto load_theta_noise = [&](long long row_, f4 (&tv)[4], f4 (&nv)[4]) {
+    const float* th_ = a.theta + row_ * D;
+    const float* nz_ = MODE == 0 ? nullptr : a.noise + row_ * D;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * kb + 4 * g + i;
+        tv[kb][i] = f < D ? th_[f] : 0.f;
+        nv[kb][i] = (MODE != 0 && f < D) ? nz_[f] : 0.f;
+      }
+    }
+  };
+  if ((int)blockIdx.x < a.ntiles) {
+    const long long r0 = row_of(blockIdx.x);
+    load_theta_noise(r0, thv, nzv);
+    t_pref = a.times[a.t_rows == 1 ? 0 : r0];
+  }
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     ++titer;
     const long long wt = (long long)tile * FM_WAVES + wave;
@@ -413,7 +439,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     const bool valid = row_raw < a.n;
     const long long row = valid ? row_raw : a.n - 1;
     float* wtb = MODE == 2 ? a.stash + wt * (long long)pl.SB * 256 : nullptr;
-    const float t = a.times[a.t_rows == 1 ? 0 : row];
+    const float t = t_pref;
     const float om = 1.0f - t;
     const float* th = a.theta + row * D;
     const float* nz = MODE == 0 ? nullptr : a.noise + row * D;
@@ -426,20 +452,6 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     wb = pipe.base();               \
   }
     f4 acc[HB], temb[HB], h[HB];
-    // Inputs of the first four 16-feature blocks (theta-dim / x-dim <= 64) are fetched one stage ahead of their
-    // use and turned into operand blocks between the two halves of the stage entry; further blocks take the
-    // inline path.
-    auto load_theta_noise = [&](f4 (&tv)[4], f4 (&nv)[4]) {
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int f = 16 * kb + 4 * g + i;
-          tv[kb][i] = f < D ? th[f] : 0.f;
-          nv[kb][i] = (MODE != 0 && f < D) ? nz[f] : 0.f;
-        }
-      }
-    };
     auto in_block = [&](int kb, const f4& tv, const f4& nv) {
       f4 v;
 #pragma unroll
@@ -456,15 +468,21 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
       }
       return v;
     };
-    f4 thv[4], nzv[4], blk4[4];
     // ---- input layer: theta_t -> time-dependent z-score -> Linear(D, H); then the first half of the merge
     FM_TS(0);
-    load_theta_noise(thv, nzv);
     pipe.enter_wait(pl.lin[J_IN].fg_first);
     wb = pipe.base();
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) blk4[kb] = in_block(kb, thv[kb], nzv[kb]);
     pipe.enter_prefetch();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {   // x of this tile: consumed after the next stage entry
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * kb + 4 * g + i;
+        thv[kb][i] = f < C ? xr[f] : 0.f;
+      }
+    }
     FM_TS(1);
     {
       const FmLin& q = pl.lin[J_IN];
@@ -499,14 +517,6 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     }
     // merge: Linear(2H, H) on GELU([ie, ce]) as two K = H products
     FM_TS(2);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int f = 16 * kb + 4 * g + i;
-        thv[kb][i] = f < C ? xr[f] : 0.f;
-      }
-    }
     pipe.enter_wait(pl.lin[J_MA].fg_first);
     wb = pipe.base();
 #pragma unroll
@@ -636,7 +646,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     }
     // ---- output layer + loss / velocity
     FM_TS(10 + 2 * pl.L);
-    if (MODE != 0) load_theta_noise(thv, nzv);
+    if (MODE != 0) load_theta_noise(row, thv, nzv);   // L2 hits: the same rows were read for the input stage
     pipe.enter_wait(pl.lin[J_L0 + pl.L].fg_first);
     wb = pipe.base();
     if (MODE != 0) {   // normalised velocity targets of the prefetched blocks
@@ -650,6 +660,11 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
       }
     }
     pipe.enter_prefetch();
+    if (tile + (int)gridDim.x < a.ntiles) {   // next tile's theta / noise / t
+      const long long rn = row_of(tile + gridDim.x);
+      load_theta_noise(rn, thv, nzv);
+      t_pref = a.times[a.t_rows == 1 ? 0 : rn];
+    }
     FM_TS(11 + 2 * pl.L);
     {
       const FmLin& q = pl.lin[J_L0 + pl.L];
@@ -717,6 +732,25 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
   FmPipe pipe;
   pipe.init(lds, a.packed, pl.bgrp_off, pl.bgrp_floats, pl.nbg, pl.lds_bwd_floats, wave, lane, pl.ablate & 2);
   const float* wb = lds;
+  // Stash reads are issued one stage ahead, in place, as soon as the registers they refill are dead (see
+  // FmPipe::enter_wait for where their first use must sit); the head of the next tile is fetched during the
+  // last stage of the current one.
+  f4 sh[HB], u[HB], dv[4];
+  float rstd = 0.f;
+  auto tile_base = [&](int tile_) { return a.stash + ((long long)tile_ * FM_WAVES + wave) * (long long)pl.SB * 256; };
+  auto load_head = [&](const float* wtb_) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) dv[ob] = ld_nat(wtb_, pl.s_diff + (ob < pl.DB ? ob : 0), c, g);
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) sh[ob] = ld_nat(wtb_, pl.s_sh + (L - 1) * HB + ob, c, g);
+    rstd = wtb_[pl.s_rstd * 256 + (L - 1) * 16 + c];
+  };
+  if ((int)blockIdx.x < a.ntiles) {
+    const float* w0 = tile_base(blockIdx.x);
+    load_head(w0);
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) u[ob] = ld_nat(w0, pl.s_u + (L - 1) * HB + ob, c, g);
+  }
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const long long wt = (long long)tile * FM_WAVES + wave;
@@ -732,18 +766,6 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
     wb = pipe.base();               \
   }
     f4 gh[HB], gte[HB], acc[HB];
-    // Stash reads are issued one stage ahead, in place, as soon as the registers they refill are dead, and
-    // always BEFORE the stage's global_load_lds (see FmPipe::enter_wait).
-    f4 sh[HB], u[HB], dv[4];
-    float rstd;
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) dv[ob] = ld_nat(wtb, pl.s_diff + (ob < pl.DB ? ob : 0), c, g);
-#pragma unroll
-    for (int ob = 0; ob < HB; ++ob) {
-      sh[ob] = ld_nat(wtb, pl.s_sh + (L - 1) * HB + ob, c, g);
-      u[ob] = ld_nat(wtb, pl.s_u + (L - 1) * HB + ob, c, g);
-    }
-    rstd = wtb[pl.s_rstd * 256 + (L - 1) * 16 + c];
     // ---- output layer: g_v = 2 w (out - target) / D ; g_h = W_o^T g_v
     pipe.enter_wait(pl.lin[J_L0 + L].bg_first);
     wb = pipe.base();
@@ -845,13 +867,19 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
 #pragma unroll
     for (int ob = 0; ob < HB; ++ob) u[ob] = gelu_grad4(u[ob]);
     pipe.enter_prefetch();
+    const bool more = tile + (int)gridDim.x < a.ntiles;
+    const float* wnext = tile_base(more ? tile + (int)gridDim.x : tile);
+    if (more) load_head(wnext);
     {
       const FmLin& q = pl.lin[J_MB];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = f4{0.f, 0.f, 0.f, 0.f};
       gemm_rr<HB, HB>(wb + q.ltw + c * q.ldt + 4 * g, q.ldt, gh0, acc);
 #pragma unroll
-      for (int ob = 0; ob < HB; ++ob) st_tr(wtb, pl.g_ce + ob, c, g, acc[ob] * u[ob]);
+      for (int ob = 0; ob < HB; ++ob) {
+        st_tr(wtb, pl.g_ce + ob, c, g, acc[ob] * u[ob]);
+        if (more) u[ob] = ld_nat(wnext, pl.s_u + (L - 1) * HB + ob, c, g);
+      }
     }
   }
   pipe.drain();
