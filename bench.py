@@ -128,6 +128,38 @@ def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
             "sample": f"{k} x {n}-row oracle FMPE train steps ({dt:.1f} s), torch {torch.__version__} CPU fp32"}
 
 
+def fmpe_leg(args, B, rank, world, device, dist, distributed):
+    """SURVEY 8f-1 / BASELINE configs[4]: one FMPE training step (default vector-field MLP, theta-dim 50) on
+    `--batch` pairs per GPU: draws of t and theta_1, fused CFM loss fwd + bwd, [all-reduce], clip + Adam."""
+    from sbi_amd.inference.trainers.fused import FusedFMPEStep
+    from sbi_amd.neural_nets.estimators.flowmatching_estimator import build_flow_matching_estimator
+
+    DF = 50
+    g = torch.Generator().manual_seed(rank)
+    th_f = torch.randn(B, DF, generator=g) * (0.1**0.5)
+    x_f = (th_f + (0.1**0.5) * torch.randn(B, DF, generator=g)).to(device)
+    th_f = th_f.to(device)
+    torch.manual_seed(1)
+    fm = build_flow_matching_estimator(th_f[:4096].cpu(), x_f[:4096].cpu()).to(device)
+    if distributed:
+        dist.broadcast(fm.net.flat_params.data, src=0)
+    stepper = FusedFMPEStep(fm, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+    wall, dev_ms = timed(lambda: stepper.step(th_f, x_f), args.steps, args.warmup, device, dist)
+    h = fm.net.hyper
+    H, L, E = h.hidden_features, h.num_layers, h.time_embedding_dim
+    f_fwd = 2.0 * (DF * H + DF * H + 2 * H * H + E * H + L * H * H + H * DF)   # dense FLOP per row, forward
+    return {
+        "metric": "FMPE train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4] step: FMPE default vector-field MLP (hidden {H}, "
+                               f"{L} layers, {h.param_count()} parameters), theta-dim {DF}, x-dim {DF}, "
+                               f"batch {B} per GPU, synthetic linear-Gaussian", "parallelism": f"dp{world}"},
+        "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms),
+        "_cpu_baseline_fn": lambda: fmpe_cpu_baseline(fm, th_f, x_f)}
+
+
 def timed(step, steps, warmup, device, dist=None):
     """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
     for _ in range(warmup):
@@ -263,37 +295,11 @@ def main():
                                                      f"+50 width-tuning sweeps), theta-dim {D}, one x_o"}}))
         return
     if args.mode == "fmpe":
-        # SURVEY 8f-1 / BASELINE configs[4]: one FMPE training step (default vector-field MLP, theta-dim 50) on
-        # `--batch` pairs per GPU: draws of t and theta_1, fused CFM loss fwd + bwd, [all-reduce], clip + Adam
-        from sbi_amd.inference.trainers.fused import FusedFMPEStep
-        from sbi_amd.neural_nets.estimators.flowmatching_estimator import build_flow_matching_estimator
-
-        DF = 50
-        g = torch.Generator().manual_seed(rank)
-        th_f = torch.randn(B, DF, generator=g) * (0.1**0.5)
-        x_f = (th_f + (0.1**0.5) * torch.randn(B, DF, generator=g)).to(device)
-        th_f = th_f.to(device)
-        torch.manual_seed(1)
-        fm = build_flow_matching_estimator(th_f[:4096].cpu(), x_f[:4096].cpu()).to(device)
-        if distributed:
-            dist.broadcast(fm.net.flat_params.data, src=0)
-        stepper = FusedFMPEStep(fm, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
-        wall, dev_ms = timed(lambda: stepper.step(th_f, x_f), args.steps, args.warmup, device, dist)
-        h = fm.net.hyper
-        H, L, E = h.hidden_features, h.num_layers, h.time_embedding_dim
-        f_fwd = 2.0 * (DF * H + DF * H + 2 * H * H + E * H + L * H * H + H * DF)   # dense FLOP per row, forward
+        out = fmpe_leg(args, B, rank, world, device, dist, distributed)
         if rank == 0:
-            out = {
-                "metric": "FMPE train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
-                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"BASELINE configs[4] step: FMPE default vector-field MLP (hidden {H}, "
-                                       f"{L} layers, {h.param_count()} parameters), theta-dim {DF}, x-dim {DF}, "
-                                       f"batch {B} per GPU, synthetic linear-Gaussian", "parallelism": f"dp{world}"},
-                "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms)}
             if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = fmpe_cpu_baseline(fm, th_f, x_f)
+                out["cpu_baseline"] = out.pop("_cpu_baseline_fn")()
+            out.pop("_cpu_baseline_fn", None)
             print(json.dumps(out))
         if distributed:
             dist.destroy_process_group()
@@ -331,6 +337,7 @@ def main():
                             "ms_per_step": wall / args.steps * 1e3,
                             "roofline": roofline(F_TRAIN, B, args.steps, dev_ms, "train")}
 
+    fm_out = fmpe_leg(args, B, rank, world, device, dist, distributed) if args.mode == "both" else None
     if rank == 0:
         head = "train" if "train" in results else ("log_prob" if "log_prob" in results else "sample")
         r = results[head]
@@ -358,6 +365,11 @@ def main():
             out["posterior_sample"] = {"metric": "DirectPosterior.sample draws/sec", "value": sp["value"],
                                        "unit": sp["unit"], "draws_per_step": args.draws, "steps": sp["steps"],
                                        "ms_per_step": sp["ms_per_step"], "roofline": sp["roofline"]}
+        if fm_out is not None:
+            out["fmpe_train"] = {k: fm_out[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline")}
+            out["fmpe_train"]["workload"] = fm_out["config"]["workload"]
+            if world == 1 and not args.no_cpu_baseline:
+                out["fmpe_train"]["cpu_baseline"] = fm_out["_cpu_baseline_fn"]()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(head)
             if "posterior_sample" in out:
