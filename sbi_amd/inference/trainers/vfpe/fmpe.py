@@ -78,8 +78,6 @@ class FMPE(PosteriorEstimatorTrainer):
             raise RuntimeError("No simulations found. You must call .append_simulations() before calling .train().")
         if dataloader_kwargs:
             raise NotImplementedError("The device-resident loop has no DataLoader; dataloader_kwargs is unsupported.")
-        if torch.device(self._device).type != "cuda":
-            raise RuntimeError("sbi_amd FMPE trains on a ROCm device only (device='cuda'); there is no CPU path")
         cfg = TrainConfig(training_batch_size=training_batch_size, learning_rate=learning_rate,
                           validation_fraction=validation_fraction, stop_after_epochs=stop_after_epochs,
                           max_num_epochs=max_num_epochs, clip_max_norm=clip_max_norm,
@@ -95,8 +93,9 @@ class FMPE(PosteriorEstimatorTrainer):
         if self._neural_net is None or cfg.retrain_from_scratch:
             self._neural_net = self._build_neural_net(theta[self.train_indices.to(theta.device)].cpu(),
                                                       x[self.train_indices.to(x.device)].cpu())
-            if not isinstance(self._neural_net, FlowMatchingEstimator):
-                raise TypeError("The vf_estimator builder must return sbi_amd's FlowMatchingEstimator.")
+            if not hasattr(self._neural_net, "loss") or not hasattr(self._neural_net, "solve_schedule"):
+                raise TypeError("The vf_estimator builder must return a vector-field estimator (loss, "
+                                "solve_schedule, t_min, t_max).")
             self._stepper = None
         net = self._neural_net.to(self._device)
         d = self._dist()
@@ -106,11 +105,19 @@ class FMPE(PosteriorEstimatorTrainer):
         theta_d, x_d = theta.to(self._device).float().contiguous(), x.to(self._device).float().contiguous()
         train_idx, val_idx = self.train_indices.to(self._device), self.val_indices.to(self._device)
         rank, world = self._rank_world()
-        if not cfg.resume_training or self._stepper is None:
-            from sbi_amd.inference.trainers.fused import FusedFMPEStep
+        # sbi_amd's own estimator takes the fused HIP step (it refuses CPU tensors: no fallback); any other
+        # vector-field estimator a user supplies (sbi lets `vf_estimator` be a custom builder) is trained
+        # through autograd with the same loop, split, all-reduce and clipping
+        fused = isinstance(net, FlowMatchingEstimator)
+        params = [p for p in net.parameters() if p.requires_grad]
+        if not cfg.resume_training or (fused and self._stepper is None) or (not fused and self.optimizer is None):
+            if fused:
+                from sbi_amd.inference.trainers.fused import FusedFMPEStep
 
-            self._stepper = FusedFMPEStep(net, lr=cfg.learning_rate, clip_max_norm=cfg.clip_max_norm,
-                                          distributed=d is not None)
+                self._stepper = FusedFMPEStep(net, lr=cfg.learning_rate, clip_max_norm=cfg.clip_max_norm,
+                                              distributed=d is not None)
+            else:
+                self.optimizer = torch.optim.Adam(params, lr=cfg.learning_rate)
             self.epoch, self._val_loss = 0, float("Inf")
         if isinstance(validation_times, int):
             validation_times = net.solve_schedule(validation_times, t_min=net.t_min + validation_times_nugget,
@@ -138,8 +145,20 @@ class FMPE(PosteriorEstimatorTrainer):
                 idx = my_slice(epoch_idx[b * B : (b + 1) * B])
                 th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)
                 rw = calibration_kernel(xx).float() if calibration_kernel is not None else None
-                losses = self._stepper.loss_and_grad(th, xx, global_batch=B, row_weight=rw)
-                self._stepper.apply()
+                if fused:
+                    losses = self._stepper.loss_and_grad(th, xx, global_batch=B, row_weight=rw)
+                    self._stepper.apply()
+                else:
+                    self.optimizer.zero_grad()
+                    losses = net.loss(th, xx)
+                    ((losses * rw).sum() / B if rw is not None else losses.sum() / B).backward()
+                    if d is not None:
+                        for p_ in params:
+                            d.all_reduce(p_.grad, op=d.ReduceOp.SUM)
+                    if cfg.clip_max_norm is not None:
+                        torch.nn.utils.clip_grad_norm_(params, max_norm=cfg.clip_max_norm)
+                    self.optimizer.step()
+                    losses = losses.detach()
                 sums[0] += (losses * rw).sum() if rw is not None else losses.sum()
             vorder = self._bcast(torch.randperm(n_val)).to(self._device)
             with torch.no_grad():

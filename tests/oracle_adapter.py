@@ -36,3 +36,39 @@ def oracle_build_fn(**kw):
         return OracleEstimator(theta, x, **kw)
 
     return build
+
+
+class OracleVectorField(torch.nn.Module):
+    """The FMPE oracle behind the vector-field-estimator surface the FMPE trainer uses (loss, solve_schedule,
+    t_min, t_max).  Times and noise are deterministic functions of the row, so a data-parallel run sees the same
+    draws as a single process."""
+
+    def __init__(self, theta, x, **kw):
+        super().__init__()
+        from oracle.fmpe_oracle import FMPEOracle
+
+        self.o = FMPEOracle(theta.shape[1], x.shape[1], **kw)
+        with torch.no_grad():
+            self.o.mean_0.copy_(theta.mean(0))
+            self.o.std_0.copy_(theta.std(0))
+            self.o.x_mean.copy_(x.mean(0))
+            self.o.x_std.copy_(x.std(0))
+        self.input_shape, self.condition_shape = theta[0].shape, x[0].shape
+        self.t_min, self.t_max = 0.0, 1.0
+
+    def solve_schedule(self, steps, t_min=None, t_max=None):
+        return torch.linspace(self.t_max if t_max is None else t_max, self.t_min if t_min is None else t_min, steps)
+
+    def loss(self, input, condition, times=None, **kwargs):
+        key = input.sum(-1, keepdim=True)
+        if times is None:
+            times = torch.frac(key[:, 0].abs() * 7.31)
+        noise = torch.sin(key * torch.arange(1, input.shape[1] + 1) * 3.7) * 1.3
+        return self.o.loss(input, condition, times, noise)
+
+
+def oracle_vf_build_fn(**kw):
+    def build(theta, x):
+        return OracleVectorField(theta, x, **kw)
+
+    return build

@@ -62,3 +62,46 @@ def test_two_rank_data_parallel_matches_single_process():
     # same global batches, gradient = sum of the two half-batch gradients: equal up to fp32 re-association
     assert (f0 - ref_flat).abs().max() < 2e-4
     assert abs(v0[-1] - ref_summary["validation_loss"][-1]) < 1e-3
+
+
+# ---- the FMPE trainer's data-parallel plumbing (same contract: slices, summed gradients, identical replicas)
+def _train_fmpe(epochs=3):
+    from sbi_amd.inference import FMPE
+    from tests.oracle_adapter import oracle_vf_build_fn
+
+    theta, x = linear_gaussian_data(400, 3, 2)
+    torch.manual_seed(2)
+    inf = FMPE(vf_estimator=oracle_vf_build_fn(H=16, L=2, E=8), show_progress_bars=False)
+    inf.append_simulations(theta, x)
+    torch.manual_seed(5)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est = inf.train(training_batch_size=90, max_num_epochs=epochs, validation_times=3)
+    return torch.cat([p.detach().reshape(-1) for p in est.parameters()]), inf.summary
+
+
+def _worker_fmpe(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    flat, summary = _train_fmpe()
+    out[rank] = (flat, summary["validation_loss"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_fmpe_two_rank_data_parallel_matches_single_process():
+    torch.set_num_threads(1)
+    ref_flat, ref_summary = _train_fmpe()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_fmpe, args=(2, _free_port(), out), nprocs=2, join=True)
+    f0, v0 = out[0]
+    f1, v1 = out[1]
+    assert torch.equal(f0, f1), "replicas diverged"
+    assert (f0 - ref_flat).abs().max() <= 1e-5 * max(1.0, ref_flat.abs().max().item())
+    assert len(v0) == len(ref_summary["validation_loss"])
+    assert max(abs(a - b) for a, b in zip(v0, ref_summary["validation_loss"])) < 1e-5
