@@ -79,6 +79,8 @@ SHAPES = [
     dict(D=3, C=4, H=128, L=2),
     dict(D=17, C=33, H=100, L=1),
     dict(D=1, C=1, H=32, L=2),
+    dict(D=70, C=100, H=100, L=2),         # more than four 16-feature input blocks: the non-prefetched path
+    dict(D=128, C=65, H=48, L=1),
 ]
 
 
