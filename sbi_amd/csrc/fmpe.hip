@@ -72,6 +72,7 @@ struct FmPlan {
   int g_v, g_u, g_te, g_h0, g_ie, g_ce;
   int SB;                        // blocks per wave-tile
   int PF;                        // floats per weight-gradient partial (fragment layout)
+  int dw_order[FM_MAX_LIN];      // linears sorted by weight-gradient work (blocks), largest first
   int ablate;                    // timing experiments only (env SBI_AMD_FM_ABLATE): 1 no stash traffic,
                                  // 2 no weight staging, 4 no GELU, 8 no hidden-layer MFMAs; results invalid
 };
@@ -183,6 +184,15 @@ static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
       if (pl->bgrp_floats[k] > pl->lds_bwd_floats) pl->lds_bwd_floats = pl->bgrp_floats[k];
   }
   pl->packed_floats = p;
+  for (int j = 0; j < pl->NL; ++j) pl->dw_order[j] = j;
+  for (int a_ = 0; a_ < pl->NL; ++a_)
+    for (int b_ = a_ + 1; b_ < pl->NL; ++b_) {
+      const FmLin& la = pl->lin[pl->dw_order[a_]];
+      const FmLin& lb = pl->lin[pl->dw_order[b_]];
+      if (lb.OB * lb.KB > la.OB * la.KB) {
+        const int t_ = pl->dw_order[a_]; pl->dw_order[a_] = pl->dw_order[b_]; pl->dw_order[b_] = t_;
+      }
+    }
   for (int j = 0; j < pl->NL; ++j) {
     FmLin& l = pl->lin[j];
     l.pf_w = pl->PF; pl->PF += l.OB * l.KB * 256;
@@ -892,39 +902,37 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
 // read once: A fragments by one 16-byte load per lane from the transposed G blocks, B fragments from the natural
 // X blocks.  Operands of the next wave-tile are in flight under the MFMAs of the current one.  The four waves'
 // sums are combined through LDS in a fixed order and written as the chunk's partial.
-template <int NB>
-__global__ void __launch_bounds__(FM_DW_THREADS) fm_dw_kernel(const FmPlan pl, const float* __restrict__ stash,
-                                                           long long nwt, float* __restrict__ partials) {
-  extern __shared__ __align__(16) float lds[];
-  const int j = blockIdx.y;
-  const FmLin& q = pl.lin[j];
+template <int OBT, int KBT>
+__device__ __forceinline__ void fm_dw_body(const FmPlan& pl, const float* __restrict__ stash, long long nwt,
+                                           float* __restrict__ partials, const FmLin& q, float* lds) {
+  // OBT x KBT is the linear's block shape rounded up to an instantiated one: the MFMA loops are branch free
+  // (a guard per MFMA costs a basic block and an s_waitcnt each); slots past the real OB / KB re-read the last
+  // real block and accumulate values that are never stored.
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int OB = q.OB, KB = q.KB;
   const bool want_bias = q.g_b >= 0;
-  constexpr bool PF = NB <= 7;     // 8 x 8 accumulators leave no room for a second operand set
-  f4 acc[NB][NB];
-  float accb[NB];                  // bias gradient: per-lane row sums of the A fragments (feature c, rows 4g..4g+3)
+  constexpr bool PF = OBT * KBT <= 49;     // 8 x 8 accumulators leave no room for a second operand set
+  f4 acc[OBT][KBT];
+  float accb[OBT];                 // bias gradient: per-lane row sums of the A fragments (feature c, rows 4g..4g+3)
 #pragma unroll
-  for (int ob = 0; ob < NB; ++ob) {
+  for (int ob = 0; ob < OBT; ++ob) {
     accb[ob] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) acc[ob][kb] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < KBT; ++kb) acc[ob][kb] = f4{0.f, 0.f, 0.f, 0.f};
   }
   const long long wt0 = (long long)blockIdx.x * FM_DW_TILES + wave;
   const long long wt1 = (long long)(blockIdx.x + 1) * FM_DW_TILES < nwt ? (long long)(blockIdx.x + 1) * FM_DW_TILES : nwt;
   const long long wstride = (long long)pl.SB * 256;
   const float* gbase = stash + q.s_g * 256 + c * 16 + 4 * g;        // transposed G: [feature c][rows 4g..]
   const float* xbase = stash + q.s_x * 256 + (4 * g) * 16 + c;      // natural X: [rows 4g..][feature c]
-  f4 av[NB], bv[NB], avn[PF ? NB : 1], bvn[PF ? NB : 1];
-  auto load_ops = [&](long long wt, f4 (&a_)[NB], f4 (&b_)[NB]) {
+  f4 av[OBT], bv[KBT], avn[PF ? OBT : 1], bvn[PF ? KBT : 1];
+  auto load_ops = [&](long long wt, f4 (&a_)[OBT], f4 (&b_)[KBT]) {
     const float* ga = gbase + wt * wstride;
     const float* xb = xbase + wt * wstride;
-    // every block slot is loaded unconditionally (slots past OB / KB re-read the last real block): a static
-    // number of loads per iteration lets the compiler keep the prefetch in flight (s_waitcnt vmcnt(N), N > 0)
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) a_[ob] = *reinterpret_cast<const f4*>(ga + (ob < OB ? ob : OB - 1) * 256);
+    for (int ob = 0; ob < OBT; ++ob) a_[ob] = *reinterpret_cast<const f4*>(ga + (ob < OB ? ob : OB - 1) * 256);
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
+    for (int kb = 0; kb < KBT; ++kb) {
       const float* xk = xb + (kb < KB ? kb : KB - 1) * 256;
       b_[kb] = f4{xk[0], xk[16], xk[32], xk[48]};
     }
@@ -932,54 +940,48 @@ __global__ void __launch_bounds__(FM_DW_THREADS) fm_dw_kernel(const FmPlan pl, c
   if (PF && wt0 < wt1) load_ops(wt0, av, bv);
   for (long long wt = wt0; wt < wt1; wt += 4) {
     if constexpr (PF) {
-      if (wt + 4 < wt1) load_ops((pl.ablate & 32) ? wt0 : wt + 4, avn, bvn);
+      if (wt + 4 < wt1) load_ops(wt + 4, avn, bvn);
     } else {
       load_ops(wt, av, bv);
     }
     if (q.x_gelu) {
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb) bv[kb] = gelu4(bv[kb]);
+      for (int kb = 0; kb < KBT; ++kb) bv[kb] = gelu4(bv[kb]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
-        if (ob < OB && !((pl.ablate & 16) && ob > 0)) {
+      for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
-          for (int kb = 0; kb < NB; ++kb)
-            if (kb < KB) acc[ob][kb] = MFMA16(av[ob][r], bv[kb][r], acc[ob][kb]);
-        }
-      }
-    }
+        for (int kb = 0; kb < KBT; ++kb) acc[ob][kb] = MFMA16(av[ob][r], bv[kb][r], acc[ob][kb]);
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) accb[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
+    for (int ob = 0; ob < OBT; ++ob) accb[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
     if constexpr (PF) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) { av[b] = avn[b]; bv[b] = bvn[b]; }
+      for (int b = 0; b < OBT; ++b) av[b] = avn[b];
+#pragma unroll
+      for (int b = 0; b < KBT; ++b) bv[b] = bvn[b];
     }
   }
 #pragma unroll
-  for (int ob = 0; ob < NB; ++ob) accb[ob] = sum_over_g(accb[ob]);   // every lane: total of feature 16*ob + c
+  for (int ob = 0; ob < OBT; ++ob) accb[ob] = sum_over_g(accb[ob]);   // every lane: total of feature 16*ob + c
   // ---- combine the four waves: (2,3) -> LDS, (0,1) add; 1 -> LDS, 0 adds and stores
-  const int per_wave = NB * NB * 256 + NB * 64;        // floats: acc blocks [blk][lane][4] + bias [ob][lane]
+  const int per_wave = OBT * KBT * 256 + OBT * 64;     // floats: acc blocks [blk][lane][4] + bias [ob][lane]
   auto spill = [&](float* dst) {
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      if (ob >= OB) continue;
+    for (int ob = 0; ob < OBT; ++ob) {
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb)
-        if (kb < KB) *reinterpret_cast<f4*>(dst + ((ob * NB + kb) * 64 + lane) * 4) = acc[ob][kb];
-      dst[NB * NB * 256 + ob * 64 + lane] = accb[ob];
+      for (int kb = 0; kb < KBT; ++kb) *reinterpret_cast<f4*>(dst + ((ob * KBT + kb) * 64 + lane) * 4) = acc[ob][kb];
+      dst[OBT * KBT * 256 + ob * 64 + lane] = accb[ob];
     }
   };
   auto absorb = [&](const float* src) {
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      if (ob >= OB) continue;
+    for (int ob = 0; ob < OBT; ++ob) {
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb)
-        if (kb < KB) acc[ob][kb] += *reinterpret_cast<const f4*>(src + ((ob * NB + kb) * 64 + lane) * 4);
-      accb[ob] += src[NB * NB * 256 + ob * 64 + lane];
+      for (int kb = 0; kb < KBT; ++kb)
+        acc[ob][kb] += *reinterpret_cast<const f4*>(src + ((ob * KBT + kb) * 64 + lane) * 4);
+      accb[ob] += src[OBT * KBT * 256 + ob * 64 + lane];
     }
   };
   if (wave >= 2) spill(lds + (wave - 2) * per_wave);
@@ -993,13 +995,27 @@ __global__ void __launch_bounds__(FM_DW_THREADS) fm_dw_kernel(const FmPlan pl, c
   // partial in FRAGMENT layout (one 1 KB store per block); fm_reduce_kernel maps it to the flat gradient
   float* part = partials + (long long)blockIdx.x * pl.PF;
 #pragma unroll
-  for (int ob = 0; ob < NB; ++ob) {
+  for (int ob = 0; ob < OBT; ++ob) {
     if (ob >= OB) continue;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+    for (int kb = 0; kb < KBT; ++kb)
       if (kb < KB) *reinterpret_cast<f4*>(part + q.pf_w + ((ob * KB + kb) * 64 + lane) * 4) = acc[ob][kb];
     if (g == 0) part[q.pf_b + ob * 16 + c] = accb[ob];
   }
+}
+
+// One launch for all linears: blockIdx.y walks them largest first (pl.dw_order) and branches, uniformly, to the
+// body instantiated for the linear's rounded block shape.
+__global__ void __launch_bounds__(FM_DW_THREADS) fm_dw_kernel(const FmPlan pl, const float* __restrict__ stash,
+                                                           long long nwt, float* __restrict__ partials) {
+  extern __shared__ __align__(16) float lds[];
+  const FmLin& q = pl.lin[pl.dw_order[blockIdx.y]];
+  const int ot = q.OB <= 4 ? 4 : (q.OB <= 7 ? 7 : 8), kt = q.KB <= 4 ? 4 : (q.KB <= 7 ? 7 : 8);
+#define FM_DW_CASE(OT, KT) \
+  if (ot == OT && kt == KT) return fm_dw_body<OT, KT>(pl, stash, nwt, partials, q, lds);
+  FM_DW_CASE(7, 7) FM_DW_CASE(7, 4) FM_DW_CASE(4, 7) FM_DW_CASE(4, 4) FM_DW_CASE(8, 8)
+  FM_DW_CASE(8, 4) FM_DW_CASE(4, 8) FM_DW_CASE(7, 8) FM_DW_CASE(8, 7)
+#undef FM_DW_CASE
 }
 
 // Sums the chunks' fragment-layout partials (coalesced) and scatters each element to its place in the flat
@@ -1312,26 +1328,18 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
   rc = fm_launch_bwd(pl, a, bgrid, st);
   if (rc) return rc;
   {
-    int nb = pl.HB;
-    if (pl.DB > nb) nb = pl.DB;
-    if (pl.CB > nb) nb = pl.CB;
-    nb = nb <= 4 ? 4 : (nb <= 7 ? 7 : 8);
-    const size_t dlds = 4ull * 2 * (nb * nb * 256 + nb * 64);
-#define FM_DW_CASE(NBV)                                                                                         \
-  case NBV: {                                                                                                   \
-    hipError_t e2 = hipFuncSetAttribute((const void*)fm_dw_kernel<NBV>,                                         \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);                 \
-    if (e2 != hipSuccess) return (int)e2;                                                                       \
-    hipLaunchKernelGGL((fm_dw_kernel<NBV>), dim3(w.nchunk, pl.NL), dim3(FM_DW_THREADS), dlds, st, pl,              \
-                       workspace + w.stash, w.nwt, workspace + w.partials);                                     \
-    break;                                                                                                      \
-  }
-    switch (nb) {
-      FM_DW_CASE(4)
-      FM_DW_CASE(7)
-      FM_DW_CASE(8)
+    int mo = 4, mk = 4;
+    for (int j = 0; j < pl.NL; ++j) {
+      const int ot = pl.lin[j].OB <= 4 ? 4 : (pl.lin[j].OB <= 7 ? 7 : 8);
+      const int kt = pl.lin[j].KB <= 4 ? 4 : (pl.lin[j].KB <= 7 ? 7 : 8);
+      if (ot * kt * 256 + ot * 64 > mo * mk * 256 + mo * 64) { mo = ot; mk = kt; }
     }
-#undef FM_DW_CASE
+    const size_t dlds = 4ull * 2 * (mo * mk * 256 + mo * 64);
+    hipError_t e2 = hipFuncSetAttribute((const void*)fm_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)dlds);
+    if (e2 != hipSuccess) return (int)e2;
+    hipLaunchKernelGGL(fm_dw_kernel, dim3(w.nchunk, pl.NL), dim3(FM_DW_THREADS), dlds, st, pl, workspace + w.stash,
+                       w.nwt, workspace + w.partials);
   }
   hipLaunchKernelGGL(fm_reduce_kernel, dim3((pl.PF + 255) / 256), dim3(256), 0, st, pl, workspace + w.partials,
                      w.nchunk, grad_out);
