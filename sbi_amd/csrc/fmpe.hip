@@ -940,7 +940,7 @@ __device__ __forceinline__ void fm_dw_body(const FmPlan& pl, const float* __rest
   if (PF && wt0 < wt1) load_ops(wt0, av, bv);
   for (long long wt = wt0; wt < wt1; wt += 4) {
     if constexpr (PF) {
-      if (wt + 4 < wt1) load_ops(wt + 4, avn, bvn);
+      if (wt + 4 < wt1 && !(pl.ablate & 32)) load_ops(wt + 4, avn, bvn);
     } else {
       load_ops(wt, av, bv);
     }
@@ -948,12 +948,14 @@ __device__ __forceinline__ void fm_dw_body(const FmPlan& pl, const float* __rest
 #pragma unroll
       for (int kb = 0; kb < KBT; ++kb) bv[kb] = gelu4(bv[kb]);
     }
+    if (!(pl.ablate & 16)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int ob = 0; ob < OBT; ++ob)
+        for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
-        for (int kb = 0; kb < KBT; ++kb) acc[ob][kb] = MFMA16(av[ob][r], bv[kb][r], acc[ob][kb]);
+          for (int kb = 0; kb < KBT; ++kb) acc[ob][kb] = MFMA16(av[ob][r], bv[kb][r], acc[ob][kb]);
+    }
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob) accb[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
     if constexpr (PF) {
