@@ -148,7 +148,34 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed):
     h = fm.net.hyper
     H, L, E = h.hidden_features, h.num_layers, h.time_embedding_dim
     f_fwd = 2.0 * (DF * H + DF * H + 2 * H * H + E * H + L * H * H + H * DF)   # dense FLOP per row, forward
+    # ODE sampling of the (untrained, random-init) vector field: adaptive Dormand-Prince, every right-hand side one
+    # launch of the velocity kernel over all draws; reported as a nested object
+    from sbi_amd.inference.posteriors.vector_field_posterior import VectorFieldPosterior
+
+    sample_obj = None
+    if rank == 0:
+        with torch.no_grad():   # give the output layer non-zero weights so that the field is not constant
+            fm.net.flat_params.add_(0.02 * torch.randn_like(fm.net.flat_params))
+        post = VectorFieldPosterior(fm, prior=None, device=str(device))
+        n_draw = 65536
+        calls = [0]
+        real = fm.ode_fn
+        fm.ode_fn = lambda *a_, **k_: (calls.__setitem__(0, calls[0] + 1), real(*a_, **k_))[1]
+        post.sample((n_draw,), x=x_f[:1])
+        torch.cuda.synchronize()
+        calls[0] = 0
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            post.sample((n_draw,), x=x_f[:1])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        fm.ode_fn = real
+        sample_obj = {"metric": "FMPE posterior.sample draws/sec (ODE, atol 1e-6 rtol 1e-5)", "value": n_draw / dt,
+                      "unit": "draws/s", "draws_per_call": n_draw, "ms_per_call": dt * 1e3,
+                      "velocity_evals_per_call": calls[0] / reps}
     return {
+        "posterior_sample": sample_obj,
         "metric": "FMPE train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -366,7 +393,8 @@ def main():
                                        "unit": sp["unit"], "draws_per_step": args.draws, "steps": sp["steps"],
                                        "ms_per_step": sp["ms_per_step"], "roofline": sp["roofline"]}
         if fm_out is not None:
-            out["fmpe_train"] = {k: fm_out[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline")}
+            out["fmpe_train"] = {k: fm_out[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline",
+                                                        "posterior_sample")}
             out["fmpe_train"]["workload"] = fm_out["config"]["workload"]
             if world == 1 and not args.no_cpu_baseline:
                 out["fmpe_train"]["cpu_baseline"] = fm_out["_cpu_baseline_fn"]()
