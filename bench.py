@@ -153,7 +153,7 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed):
     from sbi_amd.inference.posteriors.vector_field_posterior import VectorFieldPosterior
 
     sample_obj = None
-    if rank == 0:
+    if rank == 0 and world == 1:   # single-GPU runs only: keeps the N > 1 scaling runs to the collective legs
         with torch.no_grad():   # give the output layer non-zero weights so that the field is not constant
             fm.net.flat_params.add_(0.02 * torch.randn_like(fm.net.flat_params))
         post = VectorFieldPosterior(fm, prior=None, device=str(device))
