@@ -770,11 +770,6 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
     float wrow = 0.f;
     if (valid) wrow = (a.row_weight ? a.row_weight[row_raw] : a.uniform_weight) * (2.0f / (float)D);
 
-#define FM_BENTER(J)                \
-  {                                 \
-    pipe.enter(pl.lin[J].bg_first); \
-    wb = pipe.base();               \
-  }
     f4 gh[HB], gte[HB], acc[HB];
     // ---- output layer: g_v = 2 w (out - target) / D ; g_h = W_o^T g_v
     pipe.enter_wait(pl.lin[J_L0 + L].bg_first);
@@ -893,7 +888,6 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
     }
   }
   pipe.drain();
-#undef FM_BENTER
 }
 
 // ---------------------------------------------------------------- weight gradients: dW_j = G_j^T X_j over a row chunk
