@@ -68,3 +68,39 @@ def test_unsupported_options_and_cpu_tensors_are_refused():
 
     with pytest.raises(RuntimeError, match="ROCm"):
         FMPE(prior=None, device="cpu").append_simulations(theta, x).train(max_num_epochs=1)
+
+
+def test_trainer_loop_bookkeeping_with_oracle_backed_estimator():
+    """Epoch loop of the FMPE trainer on a CPU stand-in estimator: EMA-smoothed summaries, validation at fixed
+    times (tensor or count), resume_training, calibration kernel, early-stopping rule."""
+    import warnings
+
+    from sbi_amd.inference import FMPE
+    from tests.helpers import linear_gaussian_data
+    from tests.oracle_adapter import oracle_vf_build_fn
+
+    theta, x = linear_gaussian_data(300, 3, 2)
+    torch.manual_seed(0)
+    inf = FMPE(vf_estimator=oracle_vf_build_fn(H=16, L=1, E=8), show_progress_bars=False)
+    inf.append_simulations(theta, x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inf.train(training_batch_size=64, max_num_epochs=3, validation_times=torch.tensor([0.2, 0.5, 0.8]),
+                  ema_loss_decay=0.25)
+        s = inf.summary
+        assert len(s["training_loss"]) == len(s["validation_loss"]) == 4 and s["epochs_trained"] == [4]
+        assert all(torch.isfinite(torch.tensor(s["validation_loss"])))
+        # resume: epochs continue, split is kept
+        split = inf.train_indices.clone()
+        inf.train(training_batch_size=64, max_num_epochs=5, resume_training=True, validation_times=3,
+                  calibration_kernel=lambda xx: torch.ones(xx.shape[0]) * 2.0)
+        assert torch.equal(split, inf.train_indices) and inf.epoch == 6
+    # the convergence rule: an epoch is only fruitless when more than two running stds above the best
+    inf._summary["validation_loss"] = [1.0, 0.9, 1.1, 1.0] * 3
+    inf._best_val_loss, inf._val_loss, inf._epochs_since_last_improvement = 0.5, 0.55, 0
+    assert inf._converged(epoch=7, stop_after_epochs=4) is False and inf._epochs_since_last_improvement == 0
+    inf._val_loss = 2.0
+    inf._converged(epoch=8, stop_after_epochs=4)
+    assert inf._epochs_since_last_improvement == 1
+    with pytest.raises(NotImplementedError):
+        inf.append_simulations(theta, x, proposal=object())
