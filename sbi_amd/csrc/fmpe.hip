@@ -1120,11 +1120,16 @@ __global__ void __launch_bounds__(256) fm_pack_kernel(const FmPlan pl, const flo
 
 // ---------------------------------------------------------------- host side
 static int fm_grid(int ntiles) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
+  static int cus_of[64] = {0};        // per device; filled on first use
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cus_of[dev] == 0) {
+    int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    cus_of[dev] = cus;
   }
+  const int cus = cus_of[dev];
   return ntiles < cus ? ntiles : cus;   // one 8-wave workgroup per CU
 }
 
