@@ -38,3 +38,32 @@ def test_velocity_matches_reference(name):
     with torch.no_grad():
         v = o.velocity(g["theta_q"], g["x"][:1], g["tq"])
     assert (v - g["vel"]).abs().max() <= 1e-5 * g["vel"].abs().max()
+
+
+def test_early_stopping_rule_matches_reference_trainer():
+    """FMPE._converged replayed on the sequences tools/make_golden_fmpe_trainer.py fed to sbi's real
+    VectorFieldTrainer._converged, in the reference loop order: identical decisions, counters and best losses."""
+    import types
+
+    from sbi_amd.inference.trainers.vfpe.fmpe import FMPE
+
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "fmpe_trainer_reference.pt"),
+                      weights_only=False)
+    assert len(gold) == 12
+    for (name, stop, decay), g in gold.items():
+        net = torch.nn.Linear(2, 2)
+        fake = types.SimpleNamespace(_neural_net=net, _val_loss=float("inf"), _best_val_loss=float("inf"),
+                                     _summary={"validation_loss": []}, _epochs_since_last_improvement=0,
+                                     _best_model_state_dict=None,
+                                     _load_state=lambda n, sd: n.load_state_dict(sd))
+        for ep, v in enumerate(g["seq"]):
+            c = FMPE._converged(fake, ep, stop)
+            ref_c, ref_cnt, ref_best = g["trace"][ep]
+            assert (bool(c), fake._epochs_since_last_improvement) == (ref_c, ref_cnt), (name, stop, decay, ep)
+            assert fake._best_val_loss == pytest.approx(ref_best, rel=1e-12) or fake._best_val_loss == ref_best
+            if c:
+                break
+            fake._val_loss = v
+            hist = fake._summary["validation_loss"]
+            hist.append(v if not hist else (1 - decay) * hist[-1] + decay * v)
+        assert ep + 1 == len(g["trace"])
