@@ -252,3 +252,36 @@ def test_build_posterior_requires_direct_and_trained_net():
     torch.manual_seed(0)
     b = post2.sample((3,), show_progress_bars=False)
     assert torch.equal(a, b)
+
+
+def test_npe_early_stopping_rule_matches_reference_trainer():
+    """PosteriorEstimatorTrainer._converged replayed on the sequences tools/make_golden_npe_trainer.py fed to
+    sbi's real NeuralInference._converged (base.py:1254-1284): decisions, counters, best loss, best weights held
+    and weights restored on convergence are identical."""
+    import os
+    import types
+
+    from sbi_amd.inference.trainers.npe.npe import PosteriorEstimatorTrainer
+
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "npe_trainer_reference.pt"),
+                      weights_only=False)
+    assert len(gold) == 9
+    for (name, stop), g in gold.items():
+        net = torch.nn.Linear(1, 1, bias=False)
+        with torch.no_grad():
+            net.weight.fill_(-1.0)
+        fake = types.SimpleNamespace(_neural_net=net, _val_loss=float("inf"), _best_val_loss=float("inf"),
+                                     _epochs_since_last_improvement=0, _best_model_state_dict=None,
+                                     _load_state=PosteriorEstimatorTrainer._load_state)
+        for ep, v in enumerate(g["seq"]):
+            c = PosteriorEstimatorTrainer._converged(fake, ep, stop)
+            ref = g["trace"][ep]
+            got = (bool(c), fake._epochs_since_last_improvement, fake._best_val_loss,
+                   fake._best_model_state_dict["weight"].item(), net.weight.item())
+            assert got == ref, (name, stop, ep, got, ref)
+            if c:
+                break
+            with torch.no_grad():
+                net.weight.fill_(float(ep + 1))
+            fake._val_loss = v
+        assert ep + 1 == len(g["trace"])
