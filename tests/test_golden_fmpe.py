@@ -67,3 +67,30 @@ def test_early_stopping_rule_matches_reference_trainer():
             hist = fake._summary["validation_loss"]
             hist.append(v if not hist else (1 - decay) * hist[-1] + decay * v)
         assert ep + 1 == len(g["trace"])
+
+
+@pytest.mark.parametrize("name", ["default_D5_C3", "H48_L2_D3_C4"])
+def test_builder_statistics_and_layout_match_reference_builder(name):
+    """sbi_amd's build_flow_matching_estimator on the data the reference builder saw (regenerated with the
+    fixture script's seed): the same z-scoring buffers and the same parameter shapes under the same names."""
+    from sbi_amd.neural_nets.estimators.flowmatching_estimator import build_flow_matching_estimator
+
+    g = torch.load(GOLD, weights_only=False)[name]
+    D, C = g["D"], g["C"]
+    torch.manual_seed(7)     # tools/make_golden_fmpe.py
+    theta = torch.randn(300, D) * torch.linspace(0.5, 3.0, D) + torch.linspace(-2.0, 2.0, D)
+    x = theta[:, :1] * torch.ones(1, C) + torch.randn(300, C) * 0.3 + 1.5
+    assert torch.equal(theta[:64], g["theta"]) and torch.equal(x[:64], g["x"])
+    kw = g["kw"]
+    est = build_flow_matching_estimator(theta, x, hidden_features=kw.get("hidden_features", 100),
+                                        num_layers=kw.get("num_layers", 5))
+    sd, ref = est.net.reference_state_dict(), g["state"]
+    for k in ("mean_0", "std_0", "_embedding_net.0._mean", "_embedding_net.0._std"):
+        assert torch.allclose(sd[k].reshape(-1), ref[k].reshape(-1), rtol=1e-6, atol=1e-7), k
+    for k, v in sd.items():
+        if k.startswith("net."):
+            assert tuple(v.shape) == tuple(ref[k].shape), k
+    owned = {k for k in ref if k.startswith("net.") and not k.endswith("div_term")}
+    assert owned == {k for k in sd if k.startswith("net.")}
+    sched = est.solve_schedule(10, t_min=0.05, t_max=0.95)
+    assert torch.allclose(sched, torch.tensor([0.95, 0.85, 0.75, 0.65, 0.55, 0.45, 0.35, 0.25, 0.15, 0.05]))
