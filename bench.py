@@ -183,7 +183,7 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed):
         "config": {"workload": f"BASELINE configs[4] step: FMPE default vector-field MLP (hidden {H}, "
                                f"{L} layers, {h.param_count()} parameters), theta-dim {DF}, x-dim {DF}, "
                                f"batch {B} per GPU, synthetic linear-Gaussian", "parallelism": f"dp{world}"},
-        "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms),
+        "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms, "fmpe"),
         "_cpu_baseline_fn": lambda: fmpe_cpu_baseline(fm, th_f, x_f)}
 
 
@@ -217,7 +217,8 @@ def timed(step, steps, warmup, device, dist=None):
 # (profiles/r1c_pmc_summary.txt: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch, summed over the step's
 # kernels).  bench.py cannot run the profiler on itself, so these are the committed measurements; they are
 # only attached when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"log_prob": 9.6e6, "train": 1.7e9, "sample": None}
+PROFILED_TRAFFIC = {"log_prob": 9.6e6, "train": 1.7e9, "sample": None, "fmpe": 1.83e9}
+TRAFFIC_SOURCE = {"fmpe": "profiles/r1e_fmpe_pmc_summary.txt (bytes per step)"}
 
 
 def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
@@ -226,7 +227,7 @@ def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
     out = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "device_ms_per_step": dev_ms / steps}
     if traffic is not None:
-        out["traffic_source"] = "profiles/r1c_pmc_summary.txt (bytes per step)"
+        out["traffic_source"] = TRAFFIC_SOURCE.get(kind, "profiles/r1c_pmc_summary.txt (bytes per step)")
     return out
 
 
