@@ -170,8 +170,8 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
     // pin the order: hipcc otherwise sinks every load next to its MFMA (load, wait, 2 MFMAs, load, ...)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      if (nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
+    for (int nt = 0; nt < NT; ++nt)   // NT == 1: no guard (a guard per MFMA costs a basic block and an s_waitcnt each)
+      if (NT == 1 || nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -201,8 +201,8 @@ __device__ __forceinline__ void dw_gemm_rs(const float* __restrict__ Ast, const 
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      if (nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
+    for (int nt = 0; nt < NT; ++nt)   // NT == 1: no guard (a guard per MFMA costs a basic block and an s_waitcnt each)
+      if (NT == 1 || nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
