@@ -15,7 +15,8 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libsbi_amd_nsf.so"
 SOURCES = ["nsf_plan.cpp", "nsf_flow.hip", "nsf_flow_inv.hip", "nsf_train.hip", "nsf_train_k4.hip", "nsf_train_k5.hip", "nsf_train_k8.hip", "nsf_train_k16.hip", "fmpe.hip",
            "adam.hip", "mcmc_slice.hip"]
-HEADERS = ["nsf_plan.h", "nsf_device.h", "nsf_flow_kernel.h", "nsf_train_kernel.h", "../../include/sbi_amd_nsf.h"]
+HEADERS = ["nsf_plan.h", "nsf_device.h", "nsf_flow_kernel.h", "nsf_train_kernel.h", "../../include/sbi_amd_nsf.h",
+           "../../include/sbi_amd_fmpe.h"]
 
 
 def hipcc_path() -> str:
