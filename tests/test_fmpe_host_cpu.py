@@ -104,3 +104,28 @@ def test_trainer_loop_bookkeeping_with_oracle_backed_estimator():
     assert inf._epochs_since_last_improvement == 1
     with pytest.raises(NotImplementedError):
         inf.append_simulations(theta, x, proposal=object())
+
+
+def test_estimator_and_posterior_pickle_round_trip():
+    """save_and_load_test.py of the reference pickles estimators / posteriors; joblib workers do the same."""
+    import pickle
+    from copy import deepcopy
+
+    from sbi_amd.inference.posteriors.vector_field_posterior import VectorFieldPosterior
+    from sbi_amd.neural_nets.estimators.flowmatching_estimator import build_flow_matching_estimator
+
+    theta, x = torch.randn(40, 3), torch.randn(40, 2)
+    est = build_flow_matching_estimator(theta, x, hidden_features=32, num_layers=2)
+    est2 = pickle.loads(pickle.dumps(est))
+    assert torch.equal(est2.net.flat_params, est.net.flat_params) and torch.equal(est2.net.zstats, est.net.zstats)
+    assert est2.net.hyper == est.net.hyper and est2.input_shape == est.input_shape
+    est3 = deepcopy(est)
+    assert torch.equal(est3.net.flat_params, est.net.flat_params)
+    prior = torch.distributions.Independent(torch.distributions.Normal(torch.zeros(3), torch.ones(3)), 1)
+    post = VectorFieldPosterior(est, prior, device="cpu")
+    post2 = pickle.loads(pickle.dumps(post))
+    assert torch.equal(post2.vector_field_estimator.net.flat_params, est.net.flat_params)
+    sd = est.state_dict()
+    est4 = build_flow_matching_estimator(theta + 1.0, x, hidden_features=32, num_layers=2)
+    est4.load_state_dict(sd)
+    assert torch.equal(est4.net.zstats, est.net.zstats)
