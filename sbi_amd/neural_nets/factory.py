@@ -51,3 +51,11 @@ def posterior_nn(
         return cfg.build(batch_theta, batch_x)
 
     return build_fn
+
+
+def posterior_flow_nn(*args, **kwargs):
+    """``sbi.neural_nets.posterior_flow_nn`` (factory.py:531-620) for the FMPE path; see
+    ``sbi_amd.inference.trainers.vfpe.fmpe.posterior_flow_nn`` (imported lazily: it needs the trainer package)."""
+    from sbi_amd.inference.trainers.vfpe.fmpe import posterior_flow_nn as _impl
+
+    return _impl(*args, **kwargs)
