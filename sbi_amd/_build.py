@@ -15,8 +15,10 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libsbi_amd_nsf.so"
 SOURCES = ["nsf_plan.cpp", "nsf_flow.hip", "nsf_flow_inv.hip", "nsf_train.hip", "nsf_train_k4.hip", "nsf_train_k5.hip", "nsf_train_k8.hip", "nsf_train_k16.hip", "fmpe.hip",
            "adam.hip", "mcmc_slice.hip"]
-HEADERS = ["nsf_plan.h", "nsf_device.h", "nsf_flow_kernel.h", "nsf_train_kernel.h", "../../include/sbi_amd_nsf.h",
-           "../../include/sbi_amd_fmpe.h"]
+HEADERS = ["nsf_plan.h", "nsf_device.h", "nsf_flow_kernel.h", "nsf_train_kernel.h", "debug_env.h",
+           "../../include/sbi_amd_nsf.h", "../../include/sbi_amd_fmpe.h"]
+HASH_PATH = LIB_PATH.with_suffix(".so.srchash")   # travels with the .so (git-ignored, not gpurun-ignored)
+LOCK_PATH = LIB_PATH.with_suffix(".so.lock")
 
 
 def hipcc_path() -> str:
@@ -26,18 +28,46 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: the sbi_amd HIP extension cannot be built")
 
 
+def source_hash() -> str:
+    """Content hash of every source / header the library is built from (mtimes do not survive a snapshot copy)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted([CSRC / s for s in SOURCES] + [CSRC / hd for hd in HEADERS]):
+        if f.exists():
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    h.update(os.environ.get("SBI_AMD_EXTRA_HIPCC_FLAGS", "").encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
+    """True when the library is missing or was built from different sources than the ones on disk."""
     if not LIB_PATH.exists():
         return True
-    t = LIB_PATH.stat().st_mtime
-    files = [CSRC / s for s in SOURCES] + [CSRC / h for h in HEADERS]
-    return any(f.exists() and f.stat().st_mtime > t for f in files)
+    if not HASH_PATH.exists():
+        return True
+    return HASH_PATH.read_text().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every translation unit for gfx950 (in parallel) and link the shared library."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
+
+    # one builder at a time (torchrun ranks, pytest-xdist workers): the others wait, then find it up to date
+    with open(LOCK_PATH, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> Path:
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = hipcc_path()
@@ -59,12 +89,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     srcs = [s for s in SOURCES if (CSRC / s).exists()]
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as pool:
         objs = list(pool.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
+    os.replace(tmp, LIB_PATH)          # atomic: a concurrent dlopen never sees a half-written file
+    HASH_PATH.write_text(source_hash() + "\n")
     return LIB_PATH
 
 

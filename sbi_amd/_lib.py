@@ -15,6 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
+ABI_VERSION = 102    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -127,15 +128,21 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if _LIB is not None:
         return _LIB
     path = _build.LIB_PATH
-    if not path.exists():
-        if not build_if_missing:
-            raise RuntimeError(f"{path} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
-        _build.build()
+    if not path.exists() and not build_if_missing:
+        raise RuntimeError(f"{path} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    if build_if_missing:
+        _build.build()      # no-op when the library matches the sources on disk (content hash, file-locked)
+    elif _build.needs_build():
+        raise RuntimeError(f"{path} is stale (built from different sources); rebuild it with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`")
     lib = ctypes.CDLL(str(path))
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export it
         fn.restype = restype
         fn.argtypes = argtypes
+    got = lib.sbi_amd_nsf_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {got}, this binding expects {ABI_VERSION} (stale library?)")
     _LIB = lib
     return lib
 

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include "../../include/sbi_amd_fmpe.h"
 #include "../../include/sbi_amd_nsf.h"
+#include "debug_env.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -198,7 +199,7 @@ static int fm_build_plan(const sbi_amd_fmpe_config* cfg, FmPlan* pl) {
     l.pf_w = pl->PF; pl->PF += l.OB * l.KB * 256;
     l.pf_b = pl->PF; pl->PF += l.OB * 16;
   }
-  if (const char* e = getenv("SBI_AMD_FM_ABLATE")) pl->ablate = atoi(e);
+  pl->ablate = sbi_amd_dbg_fm_ablate();
   return 0;
 }
 
@@ -1300,7 +1301,7 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
   a.row_weight = row_weight; a.uniform_weight = uniform_weight;
   a.loss_out = loss_out; a.stash = workspace + w.stash; a.ln_part = workspace + w.ln_part; a.ntiles = w.ntiles;
   static long long* tl_dev = nullptr;
-  if (getenv("SBI_AMD_FM_TIMELINE")) {
+  if (sbi_amd_dbg_fm_timeline()) {
     if (!tl_dev) { hipMalloc(&tl_dev, 8 * 32 * 8); }
     hipMemsetAsync(tl_dev, 0, 8 * 32 * 8, st);
     a.timeline = tl_dev;

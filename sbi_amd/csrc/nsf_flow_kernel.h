@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "nsf_device.h"
+#include "debug_env.h"
 
 template <int K, int KSH, bool INV>
 __global__ void __launch_bounds__(512)
@@ -219,7 +220,7 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
   const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, packed, zstats, in,
                      x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash, astash,
-                     getenv("SBI_AMD_TIMELINE") ? (long long*)out_aux : nullptr);
+                     sbi_amd_dbg_timeline() ? (long long*)out_aux : nullptr);
   return (int)hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // nsf_plan.cpp -- host-side plan builder (see nsf_plan.h).
 #include "nsf_plan.h"
+#include "debug_env.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -69,7 +70,7 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->one_minus_kh = (float)(1.0 - (double)cfg->min_bin_height * K);
   pl->d_const = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
   pl->log_z = (float)(0.5 * D * log(2.0 * M_PI));
-  { const char* a = getenv("SBI_AMD_ABLATE"); pl->ablate = a ? atoi(a) : 0; }
+  pl->ablate = sbi_amd_dbg_ablate();   // debug aid, read once per process and announced on stderr
 
   for (int par = 0; par < 2; ++par) {
     ShapeDesc* s = &pl->shape[par];
@@ -189,5 +190,5 @@ extern "C" int64_t sbi_amd_nsf_lu_offset(const sbi_amd_nsf_config* cfg, int32_t 
   if (t < 0 || t >= pl.T) return SBI_AMD_E_BADARG;
   return pl.g_layer[t] + pl.shape[t & 1].g_lu;
 }
-extern "C" int sbi_amd_nsf_abi_version(void) { return 101; }
+extern "C" int sbi_amd_nsf_abi_version(void) { return SBI_AMD_NSF_ABI_VERSION; }
 extern "C" const char* sbi_amd_nsf_arch(void) { return "gfx950"; }

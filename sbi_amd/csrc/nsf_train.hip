@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "nsf_train_kernel.h"
+#include "debug_env.h"
 
 // grad[p] = sum over workgroups of the partial slabs (fixed association => deterministic);
 // finishes LULinear's diagonal: d/d(unconstrained_upper_diag_i) =
@@ -164,7 +165,7 @@ extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const f
     switch (cfg->K) {
 #define CASE_K(KK) \
   case KK: rc = launch_bwd_k<KK>(pl, tp, t, packed, zstats, z_in, x, up, row_weight, uniform_weight, n, x_rows, dn, \
-                                 partial, grad_theta_out, astash, (t == 0 && getenv("SBI_AMD_TIMELINE")) ? dbg : nullptr, st); break;
+                                 partial, grad_theta_out, astash, (t == 0 && sbi_amd_dbg_timeline()) ? dbg : nullptr, st); break;
       CASE_K(4) CASE_K(5) CASE_K(8) CASE_K(10) CASE_K(16)
 #undef CASE_K
       default: rc = SBI_AMD_E_UNSUPPORTED;

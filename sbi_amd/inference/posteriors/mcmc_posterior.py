@@ -202,7 +202,13 @@ class MCMCPosterior:
             return None
         lib = _lib.load()
         net = pot.posterior_estimator.net
-        x_row = x_o.reshape(1, -1).to(torch.float32).contiguous()
+        # the kernels take the EMBEDDED condition (standardizing_net -> embedding_net in front of the flow,
+        # flow.py:1395-1416): embed x_o once, outside the chain loop -- never hand raw x to the kernel
+        est = pot.posterior_estimator
+        with torch.no_grad():
+            x_row = est._embed(x_o.to(dev)).reshape(1, -1).to(torch.float32).contiguous()
+        if x_row.shape[1] != net.hyper.C:
+            return None
 
         def potential_(u: Tensor):
             u = u.to(torch.float32).contiguous()

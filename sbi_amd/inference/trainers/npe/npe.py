@@ -157,7 +157,9 @@ class PosteriorEstimatorTrainer:
                            data_device: Optional[str] = None) -> "PosteriorEstimatorTrainer":
         # round bookkeeping (npe_base.py:222-240): data sampled from the prior is round 0 (MLE loss); any
         # other proposal opens a new round trained with the proposal-corrected atomic loss
-        if proposal is None or proposal is self._prior:
+        restricted_prior = (type(proposal).__name__ == "RestrictedPrior"
+                            and getattr(proposal, "_prior", None) is self._prior)   # npe_base.py:223-229
+        if proposal is None or proposal is self._prior or restricted_prior:
             current_round = 0
         elif not self._data_round_index:
             current_round = 1
@@ -222,7 +224,9 @@ class PosteriorEstimatorTrainer:
                 "`deepcopy(estimator)` when creating the proposal, or use `trainer.build_posterior()` which "
                 "handles this automatically."
             )
-        if not hasattr(proposal, "posterior_estimator"):
+        is_neural = hasattr(proposal, "posterior_estimator") or hasattr(
+            getattr(proposal, "potential_fn", None), "posterior_estimator")   # MCMC / rejection posteriors
+        if not is_neural:
             warnings.warn(
                 "The proposal you passed is neither the prior nor a neural posterior: the atomic multi-round loss "
                 "will be used. If the parameters were sampled from the prior, pass proposal=None.", stacklevel=3,
@@ -322,6 +326,7 @@ class PosteriorEstimatorTrainer:
 
         # the fused optimizer step owns ONE flat parameter buffer: an embedding net with trainable weights takes the
         # autograd path (bridge kernels incl. d loss / d embedded x + torch Adam over all parameters)
+        # (a frozen / parameter-free embedding still has to be APPLIED: FusedTrainStep embeds under no_grad)
         emb_trainable = any(p.requires_grad for p in net.embedding_net.parameters()) \
             if getattr(net, "embedding_net", None) is not None else False
         fused = (isinstance(net, NSFFlow) and torch.device(self._device).type == "cuda" and calibration_kernel is None
