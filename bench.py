@@ -1,22 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the NSF / NPE hot path on MI355X.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`
-prints ONE JSON line on rank 0.  A "step" is one pass of the hot path over one
-batch of 65 536 synthetic linear-Gaussian (theta, x) pairs per GPU (weak
-scaling): in `train` mode one NPE training step (fused loss fwd+bwd, gradient
-all-reduce over RCCL for N>1, fused clip+Adam), in `log_prob` mode one batched
-NSF log_prob evaluation.  Inputs are resident in HBM before the timed region.
+Contract (task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 
-Workload = BASELINE.json configs[1]: NPE + NSF, theta-dim 10, x-dim 10,
-batch 65 536, sbi's default NSF hyper-parameters (98 025 parameters).
+* N ranks, one per GPU, RCCL backend.  The driver launches N > 1 as `python -m torch.distributed.run
+  --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in the environment); a bare
+  `python bench.py --gpus N` with N > 1 re-launches ITSELF the same way (`launch_ranks`).  A world size that
+  differs from `--gpus`, or fewer visible devices than ranks, is an error -- never a silent 1-GPU run.
+* A "step" of the headline `train` leg is one pass of sbi's training inner loop (trainers/base.py:1150-1193) over
+  one batch: device-side gather of the batch from the resident simulations (fresh permutation, as
+  SubsetRandomSampler) -> weight re-pack -> fused loss forward + backward -> [ONE all-reduce of the flat
+  98 025-float gradient over RCCL] -> fused global-norm clip + Adam.  Inputs are resident in HBM.
+* `--scaling weak` (default): 65 536 pairs per GPU per step.  `--scaling strong`: 65 536 pairs per step split N
+  ways.  At N > 1 the weak line also carries the strong number as a nested object.
+
+Workload = BASELINE.json configs[1]: NPE + NSF, theta-dim 10, x-dim 10, 100 000 simulations, batch 65 536, sbi's
+default NSF hyper-parameters (98 025 parameters).  Nested objects: `log_prob` (M1, paired x) and
+`log_prob_broadcast_x` (M1, one x_o), `posterior_sample` (M3, 10^6 draws), `npe_train` (M2 exactly as SURVEY 8d
+defines it: `NPE.train()` on 100 000 simulations, batch 65 536, validation pass and early-stopping bookkeeping
+included), `fmpe_train` (configs[4] step).
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,17 +39,43 @@ sys.path.insert(0, ROOT)
 
 D = C = 10
 BATCH = 65536
+N_SIMS = 100_000
 F_EVAL = 191_000.0          # dense FLOP per log_prob eval
 F_TRAIN = 3 * F_EVAL        # fwd + 2x bwd per training pair (recompute not counted)
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
 
-def make_data(n, device, seed=0):
-    """10-D linear-Gaussian task of tests/mini_sbibm/gaussian_linear.py:30-32,101-123:
-    prior N(0, 0.1 I), x = theta + sqrt(0.1) eps."""
+# ----------------------------------------------------------------------------------------- rank launching
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, script: str, argv, require_gpus: bool = True, extra_env=None) -> int:
+    """Re-launch `script argv` as n ranks of ONE node through torch.distributed.run (127.0.0.1 rendezvous).
+    Returns the launcher's exit code.  Raises when the node has fewer GPUs than ranks."""
+    if require_gpus:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"bench.py: --gpus {n} requested but only {have} ROCm device(s) are visible; "
+                             "refusing to run fewer ranks than asked for")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------- data / model
+def make_data(n, device, seed=0, dim=D):
+    """Linear-Gaussian task of tests/mini_sbibm/gaussian_linear.py:30-32,101-123: prior N(0, 0.1 I),
+    x = theta + sqrt(0.1) eps."""
     g = torch.Generator().manual_seed(seed)
-    theta = torch.randn(n, D, generator=g) * (0.1**0.5)
-    x = theta + (0.1**0.5) * torch.randn(n, C, generator=g)
+    theta = torch.randn(n, dim, generator=g) * (0.1**0.5)
+    x = theta + (0.1**0.5) * torch.randn(n, dim, generator=g)
     return theta.to(device), x.to(device)
 
 
@@ -49,19 +87,27 @@ def build_estimator(theta, x, device):
     return est.to(device)
 
 
-def cpu_baseline(mode, budget_s=12.0):
-    """Oracle (= op-for-op restatement of what sbi+nflows execute) timed on host cores."""
-    from oracle.nsf_oracle import NSFOracle
-
-    # Intra-op threads: eager PyTorch on (N,145)-sized temporaries stops scaling (and
-    # collapses when oversubscribed) well before a 2-socket host's core count.
+# ----------------------------------------------------------------------------------------- CPU baselines
+def _cpu_cores():
+    # Intra-op threads: eager PyTorch on (N,145)-sized temporaries stops scaling (and collapses when
+    # oversubscribed) well before a 2-socket host's core count.
     cores = min(os.cpu_count() or 1, int(os.environ.get("SBI_AMD_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
+    return cores
+
+
+def cpu_baseline(mode, budget_s=12.0):
+    """Oracle (= op-for-op restatement of what sbi + nflows execute) timed on the host cores, at the SAME batch
+    of 65 536 rows as the GPU legs (bounded by wall time: at least 2 repetitions)."""
+    from oracle.nsf_oracle import NSFOracle
+
+    cores = _cpu_cores()
     theta, x = make_data(BATCH, "cpu")
     torch.manual_seed(1)
     oracle = NSFOracle(theta, x)
-    n = 16384
+    n = BATCH
     th, xx = theta[:n], x[:n]
+    tag = f"torch {torch.__version__} CPU fp32, {cores} intra-op threads"
     if mode == "sample":
         x_o = x[:1]
         with torch.no_grad():
@@ -72,18 +118,18 @@ def cpu_baseline(mode, budget_s=12.0):
                 reps += 1
             dt = time.perf_counter() - t0
         return {"value": n * reps / dt, "unit": "draws/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} x {n}-draw oracle sample calls, no support check ({dt:.1f} s), "
-                          f"torch {torch.__version__} CPU fp32"}
-    if mode == "log_prob":
+                "sample": f"{reps} x {n}-draw oracle sample calls, no support check ({dt:.1f} s), {tag}"}
+    if mode in ("log_prob", "log_prob_broadcast_x"):
+        xb = x[:1].expand(n, C) if mode == "log_prob_broadcast_x" else xx   # nflows materialises the repeat
         with torch.no_grad():
-            oracle.log_prob(th, xx)
+            oracle.log_prob(th, xb)
             reps, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < budget_s or reps < 2:
-                oracle.log_prob(th, xx)
+                oracle.log_prob(th, xb.contiguous() if mode == "log_prob_broadcast_x" else xb)
                 reps += 1
             dt = time.perf_counter() - t0
         return {"value": n * reps / dt, "unit": "log_prob evals/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} x {n}-row oracle log_prob calls ({dt:.1f} s), torch {torch.__version__} CPU fp32"}
+                "sample": f"{reps} x {n}-row oracle log_prob calls ({dt:.1f} s), {tag}"}
     opt = torch.optim.Adam(oracle.parameters(), lr=5e-4)
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s or reps < 2:
@@ -95,20 +141,19 @@ def cpu_baseline(mode, budget_s=12.0):
         reps += 1
     dt = time.perf_counter() - t0
     return {"value": n * reps / dt, "unit": "train pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {n}-row oracle train steps, pre-batched tensors ({dt:.1f} s), "
-                      f"torch {torch.__version__} CPU fp32"}
+            "sample": f"{reps} x {n}-row oracle train steps (loss, backward, clip, Adam; pre-batched tensors, no "
+                      f"DataLoader) ({dt:.1f} s), {tag}"}
 
 
 def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
     """Oracle FMPE training step (loss + backward + clip + Adam, eager PyTorch) on host cores."""
     from oracle.fmpe_oracle import FMPEOracle
 
-    cores = min(os.cpu_count() or 1, int(os.environ.get("SBI_AMD_CPU_THREADS", "32")))
-    torch.set_num_threads(cores)
+    cores = _cpu_cores()
     h = fm.net.hyper
     o = FMPEOracle(h.D, h.C, H=h.hidden_features, L=h.num_layers)
     o.load_reference_state_dict({k: v.cpu() for k, v in fm.net.reference_state_dict().items()})
-    n = 16384
+    n = min(BATCH, theta.shape[0])
     th, xx = theta[:n].cpu(), x[:n].cpu()
     opt = torch.optim.Adam(o.parameters(), lr=5e-4)
 
@@ -120,7 +165,7 @@ def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
 
     step()
     t0, k = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
+    while time.perf_counter() - t0 < budget_s or k < 2:
         step()
         k += 1
     dt = time.perf_counter() - t0
@@ -128,23 +173,141 @@ def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
             "sample": f"{k} x {n}-row oracle FMPE train steps ({dt:.1f} s), torch {torch.__version__} CPU fp32"}
 
 
-def fmpe_leg(args, B, rank, world, device, dist, distributed):
+# ----------------------------------------------------------------------------------------- timing / roofline
+def timed(step, steps, warmup, device, dist=None):
+    """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)     # HIP events on the stream the kernels are launched on
+    t = torch.tensor([wall], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), dev_ms
+
+
+def load_traffic():
+    """HBM bytes per step from the newest committed `profiles/*traffic.json`, which `tools/profile_round.sh` writes
+    from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (gfx950
+    correction of the guide applied: FETCH_SIZE x 2).  bench.py cannot profile itself, so the line carries the
+    committed measurement together with its source file and the commit it was measured at."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")), key=os.path.getmtime)
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            t = json.load(f)
+        t["_file"] = os.path.relpath(files[-1], ROOT)
+        return t
+    except (OSError, ValueError):
+        return None
+
+
+_TRAFFIC = None
+
+
+def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
+    global _TRAFFIC
+    achieved = flop_per_unit * units_per_step * steps / (dev_ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "device_ms_per_step": dev_ms / steps}
+    if kind is not None and units_per_step == BATCH:
+        if _TRAFFIC is None:
+            _TRAFFIC = load_traffic() or {}
+        per_step = (_TRAFFIC.get("bytes_per_step") or {}).get(kind)
+        if per_step is not None:
+            out["traffic"] = per_step
+            out["traffic_source"] = f"{_TRAFFIC['_file']} (rocprofv3 --pmc passes at commit " \
+                                    f"{_TRAFFIC.get('commit', '?')}; bytes per step at batch {BATCH})"
+    return out
+
+
+# ----------------------------------------------------------------------------------------- legs
+class TrainLeg:
+    """The NPE inner loop on resident simulations: per step a fresh device permutation, the batch gather and the
+    fused step (what `NPE.train` does per minibatch, npe.py)."""
+
+    def __init__(self, est, theta_all, x_all, batch, distributed, global_batch):
+        from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+        self.theta_all, self.x_all, self.batch = theta_all, x_all, batch
+        self.global_batch = global_batch
+        self.stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+
+    def __call__(self):
+        idx = torch.randperm(self.theta_all.shape[0], device=self.theta_all.device)[: self.batch]
+        self.stepper.step(self.theta_all.index_select(0, idx), self.x_all.index_select(0, idx),
+                          global_batch=self.global_batch)
+
+
+def npe_train_leg(device, rank, world, epochs):
+    """M2 as SURVEY 8d defines it: `NPE.train()` on 100 000 simulations with training_batch_size 65 536 (90 000 /
+    10 000 split => one 65 536-row training step + one 10 000-row validation step per epoch), fixed number of
+    epochs, early stopping disabled by a large `stop_after_epochs`; plus the dense variant (10 x 65 536 / 0.9
+    simulations => 10 training steps per epoch).  Wall time of the whole call: network construction, z-scoring,
+    per-epoch permutations, validation, best-weights bookkeeping and the per-epoch host read all included."""
+    import warnings
+
+    from torch.distributions import Independent, Normal
+
+    from sbi_amd.inference import NPE
+
+    out = {}
+    for name, n_sims, ep in (("sims_100k", N_SIMS, epochs), ("sims_728k_dense", 728_200, max(2, epochs // 10))):
+        prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
+        theta, x = make_data(n_sims, "cpu", seed=0)
+        torch.manual_seed(1)
+        inf = NPE(prior=prior, density_estimator="nsf", device=str(device), show_progress_bars=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            inf.append_simulations(theta, x)
+            inf.train(training_batch_size=BATCH, max_num_epochs=2, stop_after_epochs=10**9)   # warm-up (build, alloc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            inf.train(training_batch_size=BATCH, max_num_epochs=ep + 2, stop_after_epochs=10**9,
+                      resume_training=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        n_train = int(0.9 * n_sims)
+        steps = (n_train // BATCH) * ep
+        out[name] = {"value": BATCH * steps / dt, "unit": "pairs/s", "train_steps": steps, "epochs": ep,
+                     "ms_per_epoch": dt / ep * 1e3, "simulations": n_sims,
+                     "validation_rows_per_epoch": ((n_sims - n_train) // min(BATCH, n_sims - n_train))
+                     * min(BATCH, n_sims - n_train),
+                     "final_validation_loss": inf.summary["validation_loss"][-1]}
+    return {"metric": "NPE.train() (theta,x)-pairs/sec (M2, SURVEY 8d)", **out["sims_100k"],
+            "dense_epochs": out["sims_728k_dense"], "n_gpus": world}
+
+
+def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
     """SURVEY 8f-1 / BASELINE configs[4]: one FMPE training step (default vector-field MLP, theta-dim 50) on
-    `--batch` pairs per GPU: draws of t and theta_1, fused CFM loss fwd + bwd, [all-reduce], clip + Adam."""
+    B pairs per GPU: draws of t and theta_1, fused CFM loss fwd + bwd, [all-reduce], clip + Adam."""
     from sbi_amd.inference.trainers.fused import FusedFMPEStep
     from sbi_amd.neural_nets.estimators.flowmatching_estimator import build_flow_matching_estimator
 
     DF = 50
-    g = torch.Generator().manual_seed(rank)
-    th_f = torch.randn(B, DF, generator=g) * (0.1**0.5)
-    x_f = (th_f + (0.1**0.5) * torch.randn(B, DF, generator=g)).to(device)
-    th_f = th_f.to(device)
+    th_f, x_f = make_data(B, device, seed=rank, dim=DF)
     torch.manual_seed(1)
     fm = build_flow_matching_estimator(th_f[:4096].cpu(), x_f[:4096].cpu()).to(device)
     if distributed:
         dist.broadcast(fm.net.flat_params.data, src=0)
     stepper = FusedFMPEStep(fm, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
-    wall, dev_ms = timed(lambda: stepper.step(th_f, x_f), args.steps, args.warmup, device, dist)
+    wall, dev_ms = timed(lambda: stepper.step(th_f, x_f, global_batch=global_batch), args.steps, args.warmup, device,
+                         dist)
     h = fm.net.hyper
     H, L, E = h.hidden_features, h.num_layers, h.time_embedding_dim
     f_fwd = 2.0 * (DF * H + DF * H + 2 * H * H + E * H + L * H * H + H * DF)   # dense FLOP per row, forward
@@ -178,7 +341,7 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed):
         "posterior_sample": sample_obj,
         "metric": "FMPE train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[4] step: FMPE default vector-field MLP (hidden {H}, "
                                f"{L} layers, {h.param_count()} parameters), theta-dim {DF}, x-dim {DF}, "
@@ -187,80 +350,63 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed):
         "_cpu_baseline_fn": lambda: fmpe_cpu_baseline(fm, th_f, x_f)}
 
 
-def timed(step, steps, warmup, device, dist=None):
-    """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)     # HIP events on the stream the kernels are launched on
-    t = torch.tensor([wall], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item()), dev_ms
-
-
-# HBM bytes per step at batch 65 536 from the separate rocprofv3 --pmc passes of this same command
-# (profiles/r1c_pmc_summary.txt: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, per launch, summed over the step's
-# kernels).  bench.py cannot run the profiler on itself, so these are the committed measurements; they are
-# only attached when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"log_prob": 9.6e6, "train": 1.7e9, "sample": None, "fmpe": 1.83e9}
-TRAFFIC_SOURCE = {"fmpe": "profiles/r1e_fmpe_pmc_summary.txt (bytes per step)"}
-
-
-def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
-    achieved = flop_per_unit * units_per_step * steps / (dev_ms * 1e-3) / 1e12
-    traffic = PROFILED_TRAFFIC.get(kind) if units_per_step == BATCH else None
-    out = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "device_ms_per_step": dev_ms / steps}
-    if traffic is not None:
-        out["traffic_source"] = TRAFFIC_SOURCE.get(kind, "profiles/r1c_pmc_summary.txt (bytes per step)")
-    return out
-
-
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["both", "train", "log_prob", "sample", "atomic", "mcmc", "fmpe"],
+    ap.add_argument("--mode", choices=["both", "train", "log_prob", "log_prob_broadcast", "sample", "atomic", "mcmc", "fmpe",
+                                      "npe_train"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch pairs per GPU per step; strong: --batch pairs per step split over the GPUs")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--draws", type=int, default=1_000_000, help="posterior draws per step in the sample leg")
+    ap.add_argument("--npe-epochs", type=int, default=200, help="epochs of the NPE.train() (M2) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: become one (one process per GPU, RCCL)
+        raise SystemExit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # SBI_AMD_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, all-reduce, barrier) with one rank
     distributed = world > 1 or (os.environ.get("SBI_AMD_FORCE_DIST") == "1" and "RANK" in os.environ)
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (there is no CPU path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    rccl_world = 1
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        rccl_world = int(probe.item())          # the number of ranks RCCL actually reduced over
+        if rccl_world != world:
+            raise SystemExit(f"bench.py: RCCL all-reduce saw {rccl_world} ranks, expected {world}")
 
-    B = args.batch
-    theta, x = make_data(B, device, seed=rank)     # per-GPU batch, weak scaling
-    est = build_estimator(*make_data(B, "cpu", seed=0), device)
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("bench.py: --scaling strong needs --batch divisible by --gpus")
+        B = args.batch // world          # rows per GPU per step
+    else:
+        B = args.batch
+    GB = B * world                       # global batch of one step
+    theta, x = make_data(B, device, seed=rank)     # this rank's evaluation batch
+    est = build_estimator(*make_data(BATCH, "cpu", seed=0), device)
     if distributed:
         dist.broadcast(est.net.flat_params.data, src=0)
 
@@ -271,9 +417,22 @@ def main():
                 est.log_prob(theta, x)
 
         wall, dev_ms = timed(lp_step, args.steps, args.warmup, device, dist)
-        results["log_prob"] = {"value": B * world * args.steps / wall, "unit": "evals/s",
+        results["log_prob"] = {"value": GB * args.steps / wall, "unit": "evals/s",
                                "ms_per_step": wall / args.steps * 1e3,
                                "roofline": roofline(F_EVAL, B, args.steps, dev_ms, "log_prob")}
+    if args.mode in ("both", "log_prob_broadcast"):
+        # M1 (ii): the samplers' shape -- N thetas against ONE observation (x is never expanded: 44 B / eval)
+        x_o1 = x[:1].clone()
+        th_s = theta.unsqueeze(1)        # (N, 1, D) sample-batch-event, condition (1, C)
+
+        def lpb_step():
+            with torch.no_grad():
+                est.log_prob(th_s, x_o1)
+
+        wall, dev_ms = timed(lpb_step, args.steps, args.warmup, device, dist)
+        results["log_prob_broadcast_x"] = {"value": GB * args.steps / wall, "unit": "evals/s",
+                                           "ms_per_step": wall / args.steps * 1e3,
+                                           "roofline": roofline(F_EVAL, B, args.steps, dev_ms)}
     if args.mode in ("both", "sample"):
         # BASELINE configs[3] (M3): DirectPosterior.sample of 10^6 draws for one x_o, prior support check included
         from torch.distributions import Independent, Normal
@@ -323,11 +482,18 @@ def main():
                                                      f"+50 width-tuning sweeps), theta-dim {D}, one x_o"}}))
         return
     if args.mode == "fmpe":
-        out = fmpe_leg(args, B, rank, world, device, dist, distributed)
+        out = fmpe_leg(args, B, rank, world, device, dist, distributed, GB)
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = out.pop("_cpu_baseline_fn")()
             out.pop("_cpu_baseline_fn", None)
+            print(json.dumps(out))
+        if distributed:
+            dist.destroy_process_group()
+        return
+    if args.mode == "npe_train":
+        out = npe_train_leg(device, rank, world, args.npe_epochs)
+        if rank == 0:
             print(json.dumps(out))
         if distributed:
             dist.destroy_process_group()
@@ -346,9 +512,9 @@ def main():
                              dist)
         if rank == 0:
             print(json.dumps({
-                "metric": "NPE-C atomic-loss train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
+                "metric": "NPE-C atomic-loss train (theta,x)-pairs/sec", "value": GB * args.steps / wall,
                 "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"multi-round NPE-C step, {A} atoms, batch {B} per GPU = {A * B} log_prob "
                                        f"rows forward + backward, theta-dim {D}", "parallelism": f"dp{world}"},
@@ -356,43 +522,69 @@ def main():
         if distributed:
             dist.destroy_process_group()
         return
-    if args.mode in ("both", "train"):
-        from sbi_amd.inference.trainers.fused import FusedTrainStep
 
-        stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
-        wall, dev_ms = timed(lambda: stepper.step(theta, x), args.steps, args.warmup, device, dist)
-        results["train"] = {"value": B * world * args.steps / wall, "unit": "pairs/s",
+    strong_obj = None
+    if args.mode in ("both", "train"):
+        # this rank's resident simulations: the 90 000-row training split of 100 000 simulations (weak scaling:
+        # every rank its own 100 000; strong scaling: the ranks share ONE dataset and take 1/N of every batch)
+        n_train = int(0.9 * N_SIMS)
+        th_all, x_all = make_data(n_train, device, seed=1000 + (rank if args.scaling == "weak" else 0))
+        leg = TrainLeg(est, th_all, x_all, B, distributed, GB)
+        wall, dev_ms = timed(leg, args.steps, args.warmup, device, dist)
+        results["train"] = {"value": GB * args.steps / wall, "unit": "pairs/s",
                             "ms_per_step": wall / args.steps * 1e3,
                             "roofline": roofline(F_TRAIN, B, args.steps, dev_ms, "train")}
+        if world > 1 and args.scaling == "weak" and args.batch % world == 0:
+            # the same inner loop with the 65 536-pair global batch split over the ranks
+            Bs = args.batch // world
+            leg_s = TrainLeg(est, th_all, x_all, Bs, distributed, args.batch)
+            wall_s, dev_ms_s = timed(leg_s, args.steps, args.warmup, device, dist)
+            strong_obj = {"scaling": "strong", "global_batch": args.batch, "rows_per_gpu": Bs,
+                          "value": args.batch * args.steps / wall_s, "unit": "pairs/s",
+                          "ms_per_step": wall_s / args.steps * 1e3,
+                          "roofline": roofline(F_TRAIN, Bs, args.steps, dev_ms_s)}
 
-    fm_out = fmpe_leg(args, B, rank, world, device, dist, distributed) if args.mode == "both" else None
+    npe_obj = npe_train_leg(device, rank, world, args.npe_epochs) if args.mode == "both" else None
+    fm_out = fmpe_leg(args, B, rank, world, device, dist, distributed, GB) if args.mode == "both" else None
     if rank == 0:
-        head = "train" if "train" in results else ("log_prob" if "log_prob" in results else "sample")
+        head = next(k for k in ("train", "log_prob", "log_prob_broadcast_x", "sample") if k in results)
         r = results[head]
+        per = "per GPU" if args.scaling == "weak" else f"global, {B} per GPU"
         out = {
             "metric": {"train": "NPE train (theta,x)-pairs/sec", "log_prob": "NSF log_prob evals/sec",
+                       "log_prob_broadcast_x": "NSF log_prob evals/sec (one x_o for all rows)",
                        "sample": "DirectPosterior.sample draws/sec"}[head],
             "value": r["value"], "unit": r["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: NPE + NSF theta-dim {D}, x-dim {C}, batch {B} per GPU, "
-                                   f"synthetic linear-Gaussian; step = one fused NPE training step"
+            "config": {"workload": f"BASELINE configs[1]: NPE + NSF theta-dim {D}, x-dim {C}, {N_SIMS} simulations "
+                                   f"(90 000-row training split resident in HBM), batch {args.batch} {per}, synthetic "
+                                   f"linear-Gaussian; step = device permutation + batch gather + fused NPE training "
+                                   f"step (pack, loss fwd+bwd, grad all-reduce, clip+Adam)"
                        if head == "train" else
-                       f"NSF log_prob, theta-dim {D}, x-dim {C}, batch {B} per GPU", "parallelism": f"dp{world}"},
+                       f"NSF log_prob, theta-dim {D}, x-dim {C}, batch {args.batch} {per}",
+                       "parallelism": f"dp{world}", "rccl_ranks": rccl_world if distributed else 1},
             # whole step (forward + T backward launches + reduce + clip/Adam) against dense fp32 MFMA;
             # per-kernel durations: profiles/*kernel_stats.csv
             "roofline": r["roofline"],
         }
-        if "log_prob" in results and head == "train":
-            lp = results["log_prob"]
-            out["log_prob"] = {"metric": "NSF log_prob evals/sec", "value": lp["value"], "unit": lp["unit"],
-                               "ms_per_step": lp["ms_per_step"], "roofline": lp["roofline"]}
+        if strong_obj is not None:
+            out["strong_scaling"] = strong_obj
+        for key in ("log_prob", "log_prob_broadcast_x"):
+            if key in results and head == "train":
+                lp = results[key]
+                out[key] = {"metric": "NSF log_prob evals/sec" + (" (one x_o for all rows)" if "broadcast" in key
+                                                                  else " (paired x)"),
+                            "value": lp["value"], "unit": lp["unit"], "ms_per_step": lp["ms_per_step"],
+                            "roofline": lp["roofline"]}
         if "sample" in results and head != "sample":
             sp = results["sample"]
             out["posterior_sample"] = {"metric": "DirectPosterior.sample draws/sec", "value": sp["value"],
                                        "unit": sp["unit"], "draws_per_step": args.draws, "steps": sp["steps"],
                                        "ms_per_step": sp["ms_per_step"], "roofline": sp["roofline"]}
+        if npe_obj is not None:
+            out["npe_train"] = npe_obj
         if fm_out is not None:
             out["fmpe_train"] = {k: fm_out[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline",
                                                         "posterior_sample")}

@@ -258,6 +258,19 @@ class PosteriorEstimatorTrainer:
             t = buf.to(t.device)
         return t
 
+    def _epoch_permutations(self):
+        """Returns `perm(n) -> device LongTensor`: the per-epoch SubsetRandomSampler orders.  On a ROCm device the
+        permutation is drawn ON the device from a generator seeded once per train() call from torch's global
+        RNG on rank 0 (seed broadcast: every rank draws identical permutations with no per-epoch collective and no
+        host work -- a CPU `torch.randperm(90000)` alone costs more than a 65 536-row training step).  On the CPU
+        (gloo tests) it stays the global-RNG host permutation."""
+        if torch.device(self._device).type != "cuda":
+            return lambda n: self._bcast(torch.randperm(n)).to(self._device)
+        seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
+        gen = torch.Generator(device=self._device)
+        gen.manual_seed(seed)
+        return lambda n: torch.randperm(n, generator=gen, device=self._device)
+
     # ------------------------------------------------------------------ training
     def train(self, num_atoms: int = 10, training_batch_size: int = 200, learning_rate: float = 5e-4,
               validation_fraction: float = 0.1, stop_after_epochs: int = 20, max_num_epochs: int = 2**31 - 1,
@@ -393,19 +406,20 @@ class PosteriorEstimatorTrainer:
                 losses = net_losses(th, xx, mk)
                 return losses * calibration_kernel(xx) if calibration_kernel is not None else losses
 
+        perm_of = self._epoch_permutations()
         while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
             t0 = time.time()
             net.train()
-            order = self._bcast(torch.randperm(n_train)).to(self._device)   # SubsetRandomSampler
+            order = perm_of(n_train)   # SubsetRandomSampler
             epoch_idx = train_idx[order]
             sums = torch.zeros(2, device=self._device)
             for b in range(n_train_batches):
                 idx = my_slice(epoch_idx[b * B : (b + 1) * B])
                 sums[0] += batch_losses(idx, True, B).sum()
             net.eval()
-            vorder = self._bcast(torch.randperm(n_val)).to(self._device)
+            val_epoch_idx = val_idx[perm_of(n_val)]
             for b in range(n_val_batches):
-                idx = my_slice(val_idx[vorder][b * Bv : (b + 1) * Bv])
+                idx = my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv])
                 sums[1] += batch_losses(idx, False, Bv).sum()
             if d is not None:
                 d.all_reduce(sums, op=d.ReduceOp.SUM)

@@ -136,9 +136,10 @@ class FMPE(PosteriorEstimatorTrainer):
             per = (idx.numel() + world - 1) // world
             return idx[rank * per : min((rank + 1) * per, idx.numel())]
 
+        perm_of = self._epoch_permutations()
         while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
             t0 = time.time()
-            order = self._bcast(torch.randperm(n_train)).to(self._device)
+            order = perm_of(n_train)
             epoch_idx = train_idx[order]
             sums = torch.zeros(2, device=self._device)
             for b in range(n_train_batches):
@@ -160,10 +161,10 @@ class FMPE(PosteriorEstimatorTrainer):
                     self.optimizer.step()
                     losses = losses.detach()
                 sums[0] += (losses * rw).sum() if rw is not None else losses.sum()
-            vorder = self._bcast(torch.randperm(n_val)).to(self._device)
+            val_epoch_idx = val_idx[perm_of(n_val)]
             with torch.no_grad():
                 for b in range(n_val_batches):
-                    idx = my_slice(val_idx[vorder][b * Bv : (b + 1) * Bv])
+                    idx = my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv])
                     # every validation row at every validation time (base_vf_inference.py:512-527)
                     th = theta_d.index_select(0, idx).repeat(T, 1)
                     xx = x_d.index_select(0, idx).repeat(T, 1)

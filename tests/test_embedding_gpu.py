@@ -106,3 +106,74 @@ def test_npe_with_trainable_embedding_net_c2st():
     score = c2st(samples, target).item()
     print(f"embedding NPE c2st={score:.3f} epochs={inf.summary['epochs_trained'][-1]}")
     assert 0.4 <= score <= 0.62
+
+
+def _frozen_embedding_estimator(n=600, D=3, Cx=9, Ce=5):
+    """Estimator with a FROZEN embedding net whose raw-x width differs from the embedded width."""
+    from sbi_amd.neural_nets.net_builders.flow import build_nsf
+
+    torch.manual_seed(0)
+    theta = torch.randn(n, D) * 0.5
+    x = torch.randn(n, Cx) + theta.repeat(1, 3)
+    emb = nn.Sequential(nn.Linear(Cx, Ce), nn.Tanh())
+    for p in emb.parameters():
+        p.requires_grad_(False)
+    torch.manual_seed(1)
+    est = build_nsf(theta, x, embedding_net=emb)
+    return est, theta, x
+
+
+def test_fused_step_applies_a_frozen_embedding_net():
+    """the fused trainer is chosen when the embedding has no trainable parameters; it must
+    still APPLY standardize -> embedding before the kernels (it used to feed them raw x)."""
+    from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+    est, theta, x = _frozen_embedding_estimator()
+    est = est.cuda()
+    th, xx = theta[:256].cuda(), x[:256].cuda()
+    stepper = FusedTrainStep(est, distributed=False)
+    fused_losses = stepper.loss_and_grad(th, xx)
+    fused_grad = stepper.grad.clone()
+    est.zero_grad()
+    ref_losses = est.loss(th, xx)              # autograd bridge: embeds, then the same kernels
+    ref_losses.mean().backward()
+    assert (fused_losses - ref_losses.detach()).abs().max() <= 1e-6
+    assert (fused_grad - est.net.flat_params.grad).abs().max() <= 1e-6 * est.net.flat_params.grad.abs().max() + 1e-9
+    # NPE.train() picks the fused path for this estimator and its training / validation losses agree
+    prior = MultivariateNormal(torch.zeros(3, device="cuda"), torch.eye(3, device="cuda"))
+    emb = nn.Sequential(nn.Linear(9, 5), nn.Tanh())
+    for p in emb.parameters():
+        p.requires_grad_(False)
+    inf = NPE(prior=prior, density_estimator=NSFConfig(embedding_net=emb), device="cuda", show_progress_bars=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inf.append_simulations(theta, x).train(training_batch_size=100, max_num_epochs=3)
+    assert inf._stepper is not None, "frozen embedding should train on the fused path"
+    tr, va = inf.summary["training_loss"][-1], inf.summary["validation_loss"][-1]
+    assert abs(tr - va) < 1.0, f"training ({tr}) and validation ({va}) losses disagree: x was not embedded"
+
+
+def test_mcmc_fused_potential_embeds_the_observation():
+    """MCMCPosterior's fused potential must evaluate the flow on the EMBEDDED x_o."""
+    from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+    from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+    from sbi_amd.utils.potentialutils import transformed_potential
+    from sbi_amd.utils.sbiutils import mcmc_transform
+
+    est, theta, x = _frozen_embedding_estimator()
+    est = est.cuda()
+    prior = MultivariateNormal(torch.zeros(3, device="cuda"), torch.eye(3, device="cuda"))
+    potential_fn, _ = posterior_estimator_based_potential(est, prior, x_o=None)
+    tf = mcmc_transform(prior, device="cuda")
+    post = MCMCPosterior(potential_fn, prior, tf, num_chains=8, thin=1, warmup_steps=2, device="cuda")
+    x_o = x[:1].cuda()
+    post.set_default_x(x_o)
+    post.potential_fn.set_x(x_o, x_is_iid=True)
+    fused = post._fused_potential()
+    assert fused is not None
+    u = torch.randn(64, 3, device="cuda")
+    logp, lad = fused(u)
+    ref = transformed_potential(u, post.potential_fn, tf, "cuda", track_gradients=False)
+    assert (logp - lad - ref).abs().max() <= 1e-4
+    s = post.sample((40,), show_progress_bars=False)
+    assert s.shape == (40, 3) and torch.isfinite(s).all()

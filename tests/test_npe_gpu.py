@@ -69,9 +69,10 @@ def test_uniform_prior_rejection_and_leakage_normalisation():
 
 def test_cfg2_dim10_posterior_c2st():
     """10-D task of tests/mini_sbibm/gaussian_linear.py: prior N(0, 0.1 I), x = theta + sqrt(0.1) eps;
-    posterior N(x_o/2, 0.05 I).  Target of the north_star: C2ST <= 0.55 (checked loosely here,
-    reported exactly by tools/c2st_report.py)."""
-    dim, n = 10, 30000
+    posterior N(x_o/2, 0.05 I).  Gate of the north_star: C2ST <= 0.55 -- asserted here for the accuracy
+    configuration (100 000 simulations, batch 1 000, sbi's early stopping); tools/c2st_report.py reports the same
+    number over three observations with 10 000 samples, and for the batch-65 536 benchmark configuration."""
+    dim, n = 10, 100000
     torch.manual_seed(0)
     prior = MultivariateNormal(torch.zeros(dim, device="cuda"), 0.1 * torch.eye(dim, device="cuda"))
     theta = prior.sample((n,)).cpu()
@@ -82,15 +83,19 @@ def test_cfg2_dim10_posterior_c2st():
     inf = NPE(prior=prior, density_estimator=NSFConfig(), device="cuda", show_progress_bars=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        inf.append_simulations(theta, x).train(training_batch_size=1000, max_num_epochs=150)
+        inf.append_simulations(theta, x).train(training_batch_size=1000)
     post = inf.build_posterior().set_default_x(x_o)
-    samples = post.sample((2000,), show_progress_bars=False).cpu()
+    samples = post.sample((5000,), show_progress_bars=False).cpu()
     target = true_posterior_linear_gaussian_mvn_prior(x_o, torch.zeros(dim), 0.1 * torch.eye(dim), torch.zeros(dim),
-                                                      0.1 * torch.eye(dim)).sample((2000,))
+                                                      0.1 * torch.eye(dim)).sample((5000,))
     score = c2st(samples, target).item()
     print(f"cfg2 c2st={score:.3f} epochs={inf.summary['epochs_trained'][-1]} "
           f"val={inf.summary['best_validation_loss'][-1]:.3f}")
-    assert 0.4 <= score <= 0.6
+    from tests.parity_log import record
+
+    record("c2st", "cfg2 accuracy config (100k sims, batch 1000, 5000 samples)", c2st=score,
+           epochs=inf.summary["epochs_trained"][-1])
+    assert 0.45 <= score <= 0.55, "north_star gate: posterior C2ST <= 0.55 on linear-Gaussian"
 
 
 def test_sample_1m_draws_direct_posterior():

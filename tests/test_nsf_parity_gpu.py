@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from tests.helpers import matched_pair, make_inputs
+from tests.parity_log import record
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +35,7 @@ def _ids(c):
     return "-".join(f"{k}{v}" for k, v in c.items())
 
 
-def _assert_as_accurate_as_fp32_reference(got, ref32, ref64, what):
+def _assert_as_accurate_as_fp32_reference(got, ref32, ref64, what, log=None):
     """`got` (HIP fp32) must sit within the fp32 reference's own distance from the fp64
     truth (x2) + 1e-5: on ill-scaled rows (|log p| in the hundreds, one ulp = 3e-5) the
     reference's fp32 eager arithmetic itself is only that close to the exact value."""
@@ -42,6 +43,10 @@ def _assert_as_accurate_as_fp32_reference(got, ref32, ref64, what):
     e_ref = (ref32.double() - ref64).abs().max().item()
     print(f"{what}: max|hip-f64|={e_hip:.3e} max|oracle32-f64|={e_ref:.3e} "
           f"max|hip-oracle32|={(got - ref32).abs().max().item():.3e} max|ref|={ref32.abs().max().item():.1f}")
+    if log is not None:
+        record(log[0], log[1] + " | " + what, max_abs_hip_vs_oracle32=(got - ref32).abs().max().item(),
+               max_abs_hip_vs_f64=e_hip, max_abs_oracle32_vs_f64=e_ref, max_abs_ref=ref32.abs().max().item(),
+               rows=int(got.shape[0]))
     assert e_hip <= 2.0 * e_ref + ATOL, f"{what}: hip err {e_hip} vs reference fp32 err {e_ref}"
 
 
@@ -62,7 +67,7 @@ def test_log_prob_matches_oracle(cfg):
     err = (got - ref).abs()
     print(f"in-distribution: max|hip-oracle32|={err.max().item():.3e} max|ref|={ref.abs().max().item():.1f}")
     assert err.max() <= ATOL + RTOL * ref.abs().max(), f"max err {err.max()}"
-    _assert_as_accurate_as_fp32_reference(got, ref, ref64, "in-distribution log_prob")
+    _assert_as_accurate_as_fp32_reference(got, ref, ref64, "in-distribution log_prob", ("log_prob", _ids(cfg)))
     # (b) stress rows: deep tails, |log p| up to several hundred
     theta, x = make_inputs(4096, cfg["D"], cfg["C"])
     with torch.no_grad():
@@ -71,7 +76,7 @@ def test_log_prob_matches_oracle(cfg):
         oracle.float()
     got = est.log_prob(theta.cuda(), x.cuda())[0].cpu()
     assert torch.isfinite(got).all()
-    _assert_as_accurate_as_fp32_reference(got, ref, ref64, "stress log_prob")
+    _assert_as_accurate_as_fp32_reference(got, ref, ref64, "stress log_prob", ("log_prob", _ids(cfg)))
 
 
 @pytest.mark.parametrize("cfg", CONFIGS[:5] + CONFIGS[-2:], ids=_ids)
@@ -85,8 +90,8 @@ def test_sample_matches_oracle(cfg):
         ref, ref_ld = oracle.sample_from_noise(noise, x)
         ref64, ref_ld64 = oracle.double().sample_from_noise(noise.double(), x.double())
     got, got_ld = est.sample_from_noise(noise.cuda(), x.cuda(), with_logabsdet=True)
-    _assert_as_accurate_as_fp32_reference(got.cpu(), ref, ref64, "theta")
-    _assert_as_accurate_as_fp32_reference(got_ld.cpu(), ref_ld, ref_ld64, "logabsdet")
+    _assert_as_accurate_as_fp32_reference(got.cpu(), ref, ref64, "theta", ("sample", _ids(cfg)))
+    _assert_as_accurate_as_fp32_reference(got_ld.cpu(), ref_ld, ref_ld64, "logabsdet", ("sample", _ids(cfg)))
     # typical rows directly against the fp32 oracle
     err = (got.cpu() - ref).abs()
     frac_ok = (err <= ATOL + RTOL * ref.abs()).float().mean().item()
