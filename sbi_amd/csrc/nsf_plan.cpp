@@ -162,6 +162,7 @@ int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int
   // workgroup, cap at 8 waves (2 per SIMD).
   int nw = 8;
   while (nw > 1 && (n + 16 * nw - 1) / (16 * nw) < 256) nw >>= 1;
+  if ((sbi_amd_dbg_ablate() & 1024) && nw > 4) nw = 4;   // debug aid: forward kernel with one wave per SIMD
   for (; nw >= 1; nw >>= 1) {
     int rc = nsf_build_plan(cfg, nw, pl);
     if (rc == 0) { *nw_out = nw; return 0; }

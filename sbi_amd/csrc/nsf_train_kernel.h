@@ -104,6 +104,7 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   tp->grad_x = nullptr;
   tp->ntiles = (int)((n + TR_ROWS - 1) / TR_ROWS);
   tp->grid = tp->ntiles < TR_GRID_MAX ? tp->ntiles : TR_GRID_MAX;
+  if ((pl.ablate & 512) && tp->grid > 4) tp->grid = 4;   // debug aid: many tiles per persistent workgroup at small n
   return 0;
 }
 

@@ -97,54 +97,82 @@ def test_sample_from_noise_65536_matches_oracle():
 
 
 def test_training_gradient_65536_matches_autograd():
-    """The fused step's flat gradient at the benchmarked batch (256 persistent workgroups x 4 tiles each)."""
-    from sbi_amd.inference.trainers.fused import FusedTrainStep
+    """The fused step's flat gradient at the benchmarked batch (256 persistent workgroups x 4 tiles each).
+
+    At this size (65 536 rows x 25 spline evaluations) a handful of spline inputs land within one fp32 ulp of a
+    knot.  The RQ spline is C1: log p is continuous there, but d log p / d(parameters, theta) is two-valued (the
+    second derivative jumps at a knot), and the kernels' knot positions differ from the eager oracle's by an ulp
+    (fused multiply-adds), so such a row can take the neighbouring bin: its gradient contribution (weight 1/N) then
+    differs by O(1) x 1/N.  The test finds those rows through the per-row d loss / d theta (every other row agrees
+    closely), bounds their number, and holds the flat gradient of all remaining rows to the fp64 oracle."""
+    from sbi_amd.neural_nets.estimators.nsf_flow import loss_fwd_bwd, train_workspace
     from tests.test_nsf_train_gpu import oracle_flat_grad
 
     oracle, est, _, _ = matched_pair(D=10, C=10)
     theta, x = _bench_data(seed=2)
-    oracle.zero_grad()
-    losses_ref = []
-    for i in range(0, N, CHUNK):        # gradient of the batch mean, accumulated over chunks
-        l = oracle.loss(theta[i : i + CHUNK], x[i : i + CHUNK])
-        (l.sum() / N).backward()
-        losses_ref.append(l.detach())
-    loss_ref = torch.cat(losses_ref)
-    gref = oracle_flat_grad(oracle, est)
-    # the same gradient in fp64: a 65 536-term fp32 sum has its own round-off, in the oracle as in the kernels
-    oracle.zero_grad()
-    oracle.double()
-    for i in range(0, N, CHUNK):
-        (oracle.loss(theta[i : i + CHUNK].double(), x[i : i + CHUNK].double()).sum() / N).backward()
-    named = dict(oracle.named_parameters())
-    gref64 = torch.zeros(est.net.flat_params.numel(), dtype=torch.float64)
-    for key, off, n_, _ in est.net._slices():
-        gref64[off : off + n_] = named["net." + key].grad.reshape(-1)
-    oracle.float()
-    stepper = FusedTrainStep(est, distributed=False)
-    stepper._workspace(N).fill_(float("nan"))
-    losses = stepper.loss_and_grad(theta.cuda(), x.cuda())
-    torch.cuda.synchronize()
-    got = stepper.grad.cpu()
-    scale = gref.abs().max().item()
-    err = (got - gref).abs().max().item()
-    e_l = (losses.cpu() - loss_ref).abs().max().item()
+
+    def oracle_pass(double, keep=None):
+        """(per-row loss, flat param grad of sum_n keep_n loss_n / N, per-row d loss_n / d theta_n)"""
+        oracle.zero_grad()
+        dt = torch.float64 if double else torch.float32
+        oracle.double() if double else oracle.float()
+        losses, gth = [], []
+        for i in range(0, N, CHUNK):
+            th = theta[i : i + CHUNK].to(dt).requires_grad_(True)
+            l = oracle.loss(th, x[i : i + CHUNK].to(dt))
+            w = torch.ones(l.shape[0], dtype=dt) if keep is None else keep[i : i + CHUNK].to(dt)
+            ((l * w).sum() / N).backward()
+            losses.append(l.detach())
+            gth.append(th.grad * N)        # rows are independent: row n of th.grad is d loss_n / d theta_n / N
+        named = dict(oracle.named_parameters())
+        flat = torch.zeros(est.net.flat_params.numel(), dtype=dt)
+        for key, off, n_, _ in est.net._slices():
+            flat[off : off + n_] = named["net." + key].grad.reshape(-1)
+        oracle.float()
+        return torch.cat(losses), flat, torch.cat(gth)
+
+    def hip_pass(keep=None):
+        grad = torch.empty_like(est.net.flat_params.data)
+        ws = train_workspace(est.net, N, "cuda")
+        ws.fill_(float("nan"))
+        rw = None if keep is None else (keep / N).cuda().contiguous()
+        losses, gth = loss_fwd_bwd(est.net, theta.cuda(), x.cuda(), rw, 1.0 / N, grad, want_grad_theta=True,
+                                   workspace=ws)
+        torch.cuda.synchronize()
+        return losses.cpu(), grad.cpu(), gth.cpu() * N
+
+    loss32, g32, _ = oracle_pass(False)
+    loss64, g64, gth64 = oracle_pass(True)
+    loss_h, g_h, gth_h = hip_pass()
+    assert torch.isfinite(g_h).all() and torch.isfinite(gth_h).all()
+    scale = g64.abs().max().item()
+    e_l = (loss_h - loss32).abs().max().item()
+    assert e_l <= 1e-5 + 1e-5 * loss32.abs().max().item()
+    e_all = (g_h.double() - g64).abs().max().item() / scale
+    e_o64 = (g32.double() - g64).abs().max().item() / scale
+    # rows whose d loss / d theta disagrees with the fp64 oracle: the knot-straddling rows
+    row_err = (gth_h.double() - gth64).abs().max(dim=1).values / gth64.abs().max().item()
+    outliers = (row_err > 1e-3).nonzero().flatten()
+    typical = row_err[row_err <= 1e-3].max().item()
+    print(f"grad 65536, all rows: hip vs f64 {e_all:.3e}, o32 vs f64 {e_o64:.3e}; rows off in d loss/d theta: "
+          f"{outliers.tolist()} (err {row_err[outliers].tolist()}), every other row within {typical:.3e}")
+    assert outliers.numel() <= 8, "more knot-straddling rows than one-ulp knot differences can explain"
+    keep = torch.ones(N)
+    keep[outliers] = 0.0
+    _, g64k, _ = oracle_pass(True, keep)
+    _, g_hk, _ = hip_pass(keep)
+    e_keep = (g_hk.double() - g64k).abs().max().item() / scale
     worst_block = 0.0
     for key, off, cnt, _ in est.net._slices():
-        a, b = got[off : off + cnt], gref[off : off + cnt]
+        a, b = g_hk[off : off + cnt].double(), g64k[off : off + cnt]
         worst_block = max(worst_block, (a - b).abs().max().item() / max(b.abs().max().item(), 1e-3 * scale))
-    e_hip64 = (got.double() - gref64).abs().max().item() / scale
-    e_o64 = (gref.double() - gref64).abs().max().item() / scale
-    record("train_grad_65536", "D10-C10", max_abs_grad_err_vs_oracle32=err, max_abs_grad_ref=scale,
-           rel_grad_err_vs_oracle32=err / scale, rel_grad_err_hip_vs_f64=e_hip64, rel_grad_err_oracle32_vs_f64=e_o64,
-           worst_block_rel_err_vs_oracle32=worst_block, max_abs_loss_err=e_l,
-           max_abs_loss_ref=loss_ref.abs().max().item(), rows=N)
-    print(f"grad 65536: rel vs o32 {err / scale:.3e} (worst block {worst_block:.3e}), hip vs f64 {e_hip64:.3e}, "
-          f"o32 vs f64 {e_o64:.3e}, loss err {e_l:.3e}")
-    assert torch.isfinite(got).all()
-    assert e_l <= 1e-5 + 1e-5 * loss_ref.abs().max().item()
-    # bar: within 2e-4 of max|grad| of the fp64 gradient, or no worse than twice the fp32 oracle's own distance
-    assert e_hip64 <= max(2e-4, 2.0 * e_o64), f"hip {e_hip64} vs oracle32 {e_o64} (both against fp64)"
+    record("train_grad_65536", "D10-C10", rows=N, max_abs_grad_ref=scale, max_abs_loss_err_vs_oracle32=e_l,
+           rel_grad_err_hip_vs_f64_all_rows=e_all, rel_grad_err_oracle32_vs_f64_all_rows=e_o64,
+           knot_straddling_rows=int(outliers.numel()), rel_grad_err_hip_vs_f64_without_those_rows=e_keep,
+           worst_block_rel_err_without_those_rows=worst_block, max_rel_row_grad_theta_err_other_rows=typical)
+    print(f"without those rows: hip vs f64 {e_keep:.3e}, worst block {worst_block:.3e}")
+    assert e_keep <= 5e-5, f"flat gradient off by {e_keep} of max|grad| on rows away from knots"
+    assert worst_block <= 5e-4
 
 
 def test_fmpe_loss_and_gradient_65536_match_pinned_oracle():
