@@ -1,0 +1,147 @@
+"""``RejectionPosterior`` -- rejection sampling of a potential over a proposal.
+
+Mirror of sbi/inference/posteriors/rejection_posterior.py:17-345 (constructor, ``sample`` overrides,
+``log_prob`` = the unnormalised potential with the reference's deprecation warnings, ``map``, ``to``).  Here the
+potential is the NSF posterior estimator inside the prior support (``build_posterior(sample_with="rejection")``
+passes the prior as proposal, trainers/base.py:1029-1036): every iteration evaluates all candidates with one
+launch of the batched log_prob kernel against the single x_o (44 B per evaluation) and the gradient ascent for
+``log M`` uses the fused backward pass for d log_prob / d theta.
+"""
+
+from __future__ import annotations
+
+from functools import partial
+from typing import Any, Optional, Union
+from warnings import warn
+
+import torch
+from torch import Tensor
+
+from sbi_amd.samplers.rejection.rejection import rejection_sample
+from sbi_amd.utils.sbiutils import gradient_ascent, mcmc_transform
+from sbi_amd.utils.torchutils import ensure_theta_batched, process_device
+
+
+class RejectionPosterior:
+    def __init__(self, potential_fn, proposal: Any, theta_transform=None, max_sampling_batch_size: int = 10_000,
+                 num_samples_to_find_max: int = 10_000, num_iter_to_find_max: int = 100, m: float = 1.2,
+                 device: Optional[Union[str, torch.device]] = None, x_shape: Optional[torch.Size] = None):
+        if not callable(potential_fn):
+            raise TypeError("potential_fn must be a callable potential (BasePotential / CustomPotential role).")
+        self.potential_fn = potential_fn
+        if device is None:
+            device = getattr(potential_fn, "device", "cpu")
+        self._device = process_device(device)
+        self.theta_transform = (torch.distributions.transforms.identity_transform if theta_transform is None
+                                else theta_transform)
+        self.proposal = proposal
+        self.max_sampling_batch_size = max_sampling_batch_size
+        self.num_samples_to_find_max = num_samples_to_find_max
+        self.num_iter_to_find_max = num_iter_to_find_max
+        self.m = m
+        self.x_shape = x_shape
+        self._x: Optional[Tensor] = None
+        self._map: Optional[Tensor] = None
+        self._purpose = ("It provides rejection sampling to .sample() from the posterior and can evaluate the "
+                         "_unnormalized_ posterior density with .log_prob().")
+
+    # -- x_o handling (base_posterior.py:170-214) ------------------------------------------------------
+    @property
+    def default_x(self) -> Optional[Tensor]:
+        return self._x
+
+    def set_default_x(self, x: Tensor) -> "RejectionPosterior":
+        x = torch.as_tensor(x, dtype=torch.float32)
+        if not torch.isfinite(x).all():
+            raise ValueError("x_o contains NaN or Inf values.")
+        self._x = x.reshape(1, -1).to(self._device) if x.dim() <= 1 else x.to(self._device)
+        self._map = None
+        return self
+
+    def _x_else_default_x(self, x: Optional[Tensor]) -> Tensor:
+        if x is not None:
+            x = torch.as_tensor(x, dtype=torch.float32)
+            return (x.reshape(1, -1) if x.dim() <= 1 else x).to(self._device)
+        if self._x is None:
+            raise ValueError("Context `x` needed when a default has not been set. If you'd like to have a default, "
+                             "use the `.set_default_x()` method.")
+        return self._x
+
+    def to(self, device: Union[str, torch.device]) -> None:
+        device = process_device(device)
+        self._device = device
+        self.potential_fn.to(device)
+        if hasattr(self.proposal, "to"):
+            self.proposal = self.proposal.to(device) or self.proposal
+        self.theta_transform = mcmc_transform(self.proposal, device=device)
+        if self._x is not None:
+            self._x = self._x.to(device)
+
+    # -- evaluation ---------------------------------------------------------------------------------------
+    def potential(self, theta: Tensor, x: Optional[Tensor] = None, track_gradients: bool = False) -> Tensor:
+        self.potential_fn.set_x(self._x_else_default_x(x))
+        theta = ensure_theta_batched(torch.as_tensor(theta))
+        return self.potential_fn(theta.to(self._device), track_gradients=track_gradients)
+
+    def log_prob(self, theta: Tensor, x: Optional[Tensor] = None, track_gradients: bool = False) -> Tensor:
+        warn("`.log_prob()` is deprecated for methods that can only evaluate the log-probability up to a "
+             "normalizing constant. Use `.potential()` instead.", stacklevel=2)
+        warn("The log-probability is unnormalized!", stacklevel=2)
+        return self.potential(theta, x, track_gradients)
+
+    # -- sampling -----------------------------------------------------------------------------------------
+    def sample(self, sample_shape=torch.Size(), x: Optional[Tensor] = None,
+               max_sampling_batch_size: Optional[int] = None, num_samples_to_find_max: Optional[int] = None,
+               num_iter_to_find_max: Optional[int] = None, m: Optional[float] = None,
+               show_progress_bars: bool = True, reject_outside_prior: bool = True,
+               max_sampling_time: Optional[float] = None, return_partial_on_timeout: bool = False) -> Tensor:
+        sample_shape = torch.Size(sample_shape)
+        num_samples = sample_shape.numel()
+        self.potential_fn.set_x(self._x_else_default_x(x))
+        potential = partial(self.potential_fn, track_gradients=True)
+        if reject_outside_prior:
+            samples, _ = rejection_sample(
+                potential, proposal=self.proposal, theta_transform=self.theta_transform, num_samples=num_samples,
+                show_progress_bars=show_progress_bars, warn_acceptance=0.01,
+                max_sampling_batch_size=(self.max_sampling_batch_size if max_sampling_batch_size is None
+                                         else max_sampling_batch_size),
+                num_samples_to_find_max=(self.num_samples_to_find_max if num_samples_to_find_max is None
+                                         else num_samples_to_find_max),
+                num_iter_to_find_max=(self.num_iter_to_find_max if num_iter_to_find_max is None
+                                      else num_iter_to_find_max),
+                m=self.m if m is None else m, max_sampling_time=max_sampling_time,
+                return_partial_on_timeout=return_partial_on_timeout, device=self._device,
+            )
+        else:
+            samples = self.proposal.sample((num_samples,))
+            warn("Samples drawn with reject_outside_prior=False are taken directly from the proposal without "
+                 "rejection sampling. These samples may lie outside the prior support, which could lead to "
+                 "incorrect inference.", stacklevel=2)
+        return samples.reshape((*sample_shape, -1))
+
+    def sample_batched(self, sample_shape, x: Tensor, max_sampling_batch_size: int = 10000,
+                       show_progress_bars: bool = True) -> Tensor:
+        raise NotImplementedError("Batched sampling is not implemented for RejectionPosterior. Alternatively you can "
+                                  "use `sample` in a loop [posterior.sample(theta, x_o) for x_o in x].")
+
+    def map(self, x: Optional[Tensor] = None, num_iter: int = 1_000, num_to_optimize: int = 100,
+            learning_rate: float = 0.01, init_method: Union[str, Tensor] = "proposal", num_init_samples: int = 1_000,
+            save_best_every: int = 10, show_progress_bars: bool = False, force_update: bool = False) -> Tensor:
+        """base_posterior.py:216-323: gradient ascent on the potential from proposal (or posterior) draws."""
+        if self._map is not None and not force_update and x is None:
+            return self._map
+        self.potential_fn.set_x(self._x_else_default_x(x))
+        if isinstance(init_method, Tensor):
+            inits = init_method
+        elif init_method == "proposal":
+            inits = self.proposal.sample((num_init_samples,))
+        elif init_method == "posterior":
+            inits = self.sample((num_init_samples,), x=x, show_progress_bars=False)
+        else:
+            raise ValueError("init_method must be 'posterior', 'proposal' or a tensor of initial parameters.")
+        best, _ = gradient_ascent(partial(self.potential_fn, track_gradients=True), inits.to(self._device),
+                                  theta_transform=self.theta_transform, num_iter=num_iter,
+                                  num_to_optimize=num_to_optimize, learning_rate=learning_rate,
+                                  save_best_every=save_best_every, show_progress_bars=show_progress_bars)
+        self._map = best
+        return best

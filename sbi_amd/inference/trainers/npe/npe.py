@@ -492,10 +492,10 @@ class PosteriorEstimatorTrainer:
                         direct_sampling_parameters: Optional[Dict[str, Any]] = None, **kwargs):
         from sbi_amd.inference.posteriors.direct_posterior import DirectPosterior
 
-        if sample_with not in ("direct", "mcmc"):
+        if sample_with not in ("direct", "mcmc", "rejection"):
             raise NotImplementedError(
-                f"sample_with={sample_with!r}: VI / importance / rejection posteriors are outside this round's "
-                "scope (SURVEY.md section 8f-3); use 'direct' or 'mcmc'."
+                f"sample_with={sample_with!r}: VI / importance posteriors are outside the accelerated path "
+                "(SURVEY.md section 8f-3 covers the batched-log_prob callers: 'direct', 'mcmc', 'rejection')."
             )
         if prior is None:
             if self._prior is None:
@@ -526,6 +526,23 @@ class PosteriorEstimatorTrainer:
             self._posterior = MCMCPosterior(potential_fn=potential_fn, proposal=prior, theta_transform=theta_transform,
                                             method=kwargs.get("mcmc_method", "slice_np_vectorized"), device=device,
                                             **mcmc_parameters)
+            return deepcopy(self._posterior)
+        if sample_with == "rejection":
+            # trainers/base.py:794-796, 1029-1036: potential = estimator log-prob inside the prior support,
+            # proposal = prior, RejectionPosteriorParameters(max_sampling_batch_size, num_samples_to_find_max,
+            # num_iter_to_find_max, m)
+            from sbi_amd.inference.posteriors.rejection_posterior import RejectionPosterior
+            from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+            from sbi_amd.utils.sbiutils import mcmc_transform
+
+            params = dict(kwargs.get("rejection_sampling_parameters") or {})
+            unknown = set(params) - {"max_sampling_batch_size", "num_samples_to_find_max", "num_iter_to_find_max", "m"}
+            if unknown:
+                raise TypeError(f"unexpected rejection_sampling_parameters: {sorted(unknown)}")
+            potential_fn, _ = posterior_estimator_based_potential(estimator, prior, x_o=None)
+            self._posterior = RejectionPosterior(potential_fn=potential_fn, proposal=prior,
+                                                 theta_transform=mcmc_transform(prior, device=device), device=device,
+                                                 **params)
             return deepcopy(self._posterior)
         self._posterior = DirectPosterior(posterior_estimator=estimator, prior=prior, device=device,
                                           **(direct_sampling_parameters or {}))

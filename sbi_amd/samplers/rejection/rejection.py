@@ -138,3 +138,105 @@ def accept_reject_sample(
     assert out is not None
     samples = out.reshape(num_samples, *candidates.shape[1:])
     return samples, acceptance_rate.to(samples.device)
+
+
+def rejection_sample(
+    potential_fn: Callable,
+    proposal,
+    theta_transform=None,
+    num_samples: int = 1,
+    show_progress_bars: bool = False,
+    warn_acceptance: float = 0.01,
+    max_sampling_batch_size: int = 10_000,
+    num_samples_to_find_max: int = 10_000,
+    num_iter_to_find_max: int = 100,
+    m: float = 1.2,
+    max_sampling_time: Optional[float] = None,
+    return_partial_on_timeout: bool = False,
+    device: str = "cpu",
+) -> Tuple[Tensor, Tensor]:
+    r"""Rejection sampling of `exp(potential_fn)` with candidates from `proposal`
+    (sbi/samplers/rejection/rejection.py:18-227): the envelope is `proposal * M` with
+    `log M = max_theta [potential(theta) - proposal.log_prob(theta)] + log m`, the maximum found by gradient
+    ascent from the best tenth of `num_samples_to_find_max` proposal draws; a candidate is kept when
+    `exp(potential - proposal.log_prob - log M) > u`, `u ~ U[0, 1]`.  Same batch-size adaptation, low-acceptance
+    warning and `max_sampling_time` / `return_partial_on_timeout` behaviour; returns (samples, acceptance rate).
+
+    MI355X-first: the potential of all candidates of an iteration is ONE launch of the batched log_prob kernel (one
+    x_o broadcast), the ratio test and the compaction of the accepted candidates into a preallocated buffer are
+    device ops (stable prefix-sum scatter: same samples in the same order as the reference's boolean-mask gather +
+    list + cat), and the loop reads back one integer per iteration."""
+    import torch.distributions.transforms as torch_tf
+
+    from sbi_amd.utils.sbiutils import gradient_ascent
+
+    if theta_transform is None:
+        theta_transform = torch_tf.IndependentTransform(torch_tf.identity_transform, reinterpreted_batch_ndims=1)
+    samples_to_find_max = proposal.sample((num_samples_to_find_max,))
+
+    def potential_over_proposal(theta):
+        return potential_fn(theta) - proposal.log_prob(theta)
+
+    _, max_log_ratio = gradient_ascent(
+        potential_fn=potential_over_proposal, inits=samples_to_find_max, theta_transform=theta_transform,
+        num_iter=num_iter_to_find_max, learning_rate=0.01,
+        num_to_optimize=max(1, int(num_samples_to_find_max / 10)), show_progress_bars=False,
+    )
+    if m < 1.0:
+        warnings.warn("A value of m < 1.0 will lead to systematically wrong results.", stacklevel=2)
+    log_envelope = max_log_ratio.detach() + torch.log(torch.as_tensor(m))   # proposal.log_prob + this >= potential
+
+    with torch.no_grad():
+        out: Optional[Tensor] = None
+        num_sampled_total, num_remaining = 0, num_samples
+        acceptance_rate = float("nan")
+        leakage_warning_raised = False
+        sampling_batch_size = min(num_samples, max_sampling_batch_size)
+        start_time = time.time()
+        filled = 0
+        while num_remaining > 0:
+            if max_sampling_time is not None and (time.time() - start_time) > max_sampling_time:
+                if return_partial_on_timeout and filled > 0:
+                    warnings.warn(f"Timeout exceeded after collecting {filled}/{num_samples} samples. Returning "
+                                  "partial results.", stacklevel=2)
+                    return out[:filled], torch.as_tensor(acceptance_rate)
+                raise RuntimeError(
+                    "Sampling aborted early because rejection sampling exceeded max_sampling_time. This is likely "
+                    "due to extremely low acceptance. You can disable rejection sampling using "
+                    "`reject_outside_prior=False` to draw samples directly from the trained estimator. Consider "
+                    "switching to MCMC or VI, or checking for model misspecification."
+                )
+            candidates = proposal.sample((sampling_batch_size,)).reshape(sampling_batch_size, -1)
+            log_ratio = potential_fn(candidates) - (proposal.log_prob(candidates) + log_envelope.to(candidates.device))
+            target_proposal_ratio = torch.exp(log_ratio).reshape(-1)
+            if target_proposal_ratio.is_cuda:
+                uniform_rand = torch.rand(target_proposal_ratio.shape, device=target_proposal_ratio.device)
+            else:
+                uniform_rand = torch.rand(target_proposal_ratio.shape).to(device)
+            accept = target_proposal_ratio > uniform_rand
+            if out is None:   # one extra row: the dump slot of rejected / surplus candidates
+                buf = torch.empty((num_samples + 1, candidates.shape[1]), dtype=candidates.dtype,
+                                  device=candidates.device)
+                out = buf[:num_samples]
+            acc_i = accept.to(torch.long)
+            dest = torch.cumsum(acc_i, dim=0) - 1 + filled
+            dest = torch.where(accept & (dest < num_samples), dest, torch.full_like(dest, num_samples))
+            buf.index_copy_(0, dest, candidates)
+            n_acc = int(acc_i.sum().item())                    # the one host read-back of the iteration
+            filled = min(filled + n_acc, num_samples)
+            num_sampled_total += sampling_batch_size
+            num_remaining -= n_acc
+            acceptance_rate = (num_samples - num_remaining) / num_sampled_total
+            sampling_batch_size = min(max_sampling_batch_size,
+                                      max(int(1.5 * num_remaining / max(acceptance_rate, 1e-12)), 100))
+            if num_sampled_total > 1000 and acceptance_rate < warn_acceptance and not leakage_warning_raised:
+                logging.warning(
+                    f"Only {acceptance_rate:.3%} proposal samples were accepted. It may take a long time to collect "
+                    f"the remaining {num_remaining} samples. You can prevent long runtimes by setting "
+                    "`max_sampling_time` to limit runtime, or disabling rejection sampling (e.g. via "
+                    "`reject_outside_prior=False` in `posterior.sample()` when available). Alternatively, consider "
+                    "switching to a different sampling method with `build_posterior(..., sample_with='mcmc')`."
+                )
+                leakage_warning_raised = True
+        assert out is not None and filled == num_samples, "Number of accepted samples must match required samples."
+    return out, torch.as_tensor(acceptance_rate)

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import logging
 import warnings
-from typing import Optional, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -183,3 +183,59 @@ def check_transform(prior, transform, atol: float = 1e-3) -> None:
         "MultipleIndependent prior with a Dirichlet prior.")
     assert torch.allclose(theta, transform(theta_unconstrained), atol=atol), \
         "Original and re-transformed parameters must be close to each other."
+
+
+def gradient_ascent(potential_fn: Callable, inits: Tensor, theta_transform=None, num_iter: int = 1_000,
+                    num_to_optimize: int = 100, learning_rate: float = 0.01, save_best_every: int = 10,
+                    show_progress_bars: bool = False, interruption_note: str = "") -> Tuple[Tensor, Tensor]:
+    """`argmax` and `max` of `potential_fn` by Adam ascent in the unconstrained space of `theta_transform`, started
+    from the `num_to_optimize` best of `inits` (sbi/utils/sbiutils.py:1160-1286: same selection, optimizer, the
+    best-so-far bookkeeping every `save_best_every` iterations, Ctrl-C returns the current best).  With an NSF
+    estimator on a ROCm device every evaluation is one launch of the batched log_prob kernel and every gradient the
+    fused backward pass (d log_prob / d theta)."""
+    import torch.distributions.transforms as torch_tf
+
+    if theta_transform is None:
+        theta_transform = torch_tf.IndependentTransform(torch_tf.identity_transform, reinterpreted_batch_ndims=1)
+    init_probs = potential_fn(inits).detach()
+    inits = inits.to(init_probs.device)
+    sort_indices = torch.argsort(init_probs, dim=0)
+    sorted_inits = inits[sort_indices]
+    optimize_inits = sorted_inits[-num_to_optimize:]
+    best_log_prob_iter = torch.max(init_probs)
+    best_theta_iter = sorted_inits[-1]
+    best_theta_overall = best_theta_iter.detach().clone()
+    best_log_prob_overall = best_log_prob_iter.detach().clone()
+    argmax_, max_val = best_theta_overall, best_log_prob_overall
+    # NOTE (as in the reference): `best_theta_overall` starts in constrained space and is replaced by
+    # unconstrained-space points once an iteration improves on it; the return maps it back with `.inv`
+    optimize_inits = theta_transform(optimize_inits).detach().clone()
+    optimize_inits.requires_grad_(True)
+    optimizer = torch.optim.Adam([optimize_inits], lr=learning_rate)
+    iter_ = 0
+    try:
+        while iter_ < num_iter:
+            optimizer.zero_grad()
+            probs = potential_fn(theta_transform.inv(optimize_inits)).squeeze()
+            (-probs.sum()).backward()
+            optimizer.step()
+            with torch.no_grad():
+                if iter_ % save_best_every == 0 or iter_ == num_iter - 1:
+                    log_probs_of_optimized = potential_fn(theta_transform.inv(optimize_inits))
+                    best_theta_iter = optimize_inits[torch.argmax(log_probs_of_optimized)].unsqueeze(0)
+                    best_log_prob_iter = potential_fn(theta_transform.inv(best_theta_iter))
+                    if best_log_prob_iter > best_log_prob_overall:
+                        best_theta_overall = best_theta_iter.detach().clone()
+                        best_log_prob_overall = best_log_prob_iter.detach().clone()
+                if show_progress_bars:
+                    print("\r", f"Optimizing MAP estimate. Iterations: {iter_ + 1} / {num_iter}. Performance in "
+                          f"iteration {divmod(iter_ + 1, save_best_every)[0] * save_best_every}: "
+                          f"{best_log_prob_iter.item():.2f} (= unnormalized log-prob). Press Ctrl-C to interrupt.",
+                          end="")
+                argmax_ = theta_transform.inv(best_theta_overall)
+                max_val = best_log_prob_overall
+            iter_ += 1
+    except KeyboardInterrupt:
+        print(f"Optimization was interrupted after {iter_} iterations. " + interruption_note)
+        return argmax_, max_val
+    return theta_transform.inv(best_theta_overall), max_val

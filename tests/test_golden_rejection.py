@@ -1,0 +1,63 @@
+"""`rejection_sample` / `gradient_ascent` replayed against outputs of the reference's REAL functions
+(tests/golden/rejection_reference.pt, made by tools/make_golden_rejection.py): same seeds, same RNG call order =>
+the same candidates, the same envelope constant, the same accepted samples in the same order."""
+import os
+import warnings
+
+import pytest
+import torch
+from torch.distributions import Independent, MultivariateNormal, Uniform
+
+from sbi_amd.samplers.rejection.rejection import rejection_sample
+from sbi_amd.utils.sbiutils import gradient_ascent
+
+G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "rejection_reference.pt"), weights_only=False)
+
+
+def _case(name):
+    if name == "gauss_in_gauss":
+        target = MultivariateNormal(torch.tensor([0.3, -0.2, 0.1]), 0.05 * torch.eye(3))
+        return (lambda th: target.log_prob(th) + 1.7), MultivariateNormal(torch.zeros(3), 0.3 * torch.eye(3))
+    t2 = MultivariateNormal(torch.tensor([0.5, -0.4]), torch.tensor([[0.08, 0.03], [0.03, 0.05]]))
+    return (lambda th: t2.log_prob(th)), Independent(Uniform(-1.5 * torch.ones(2), 1.5 * torch.ones(2)), 1)
+
+
+@pytest.mark.parametrize("name", ["gauss_in_gauss", "gauss_in_box"])
+def test_rejection_sample_reproduces_the_reference_run(name):
+    pot, prop = _case(name)
+    torch.manual_seed(7)
+    samples, acc = rejection_sample(pot, prop, **G[name]["kw"])
+    ref = G[name]["samples"]
+    assert samples.shape == ref.shape
+    same_rows = (samples == ref).all(dim=1).float().mean().item()
+    assert same_rows == 1.0, f"only {same_rows:.3%} of the accepted samples coincide with the reference run"
+    assert torch.allclose(torch.as_tensor(acc, dtype=torch.float64), G[name]["acceptance"].double())
+
+
+def test_gradient_ascent_reproduces_the_reference_run():
+    t = MultivariateNormal(torch.tensor([1.0, -2.0]), torch.tensor([[0.5, 0.1], [0.1, 0.3]]))
+    g = G["gradient_ascent"]
+    arg, val = gradient_ascent(lambda th: t.log_prob(th), g["inits"].clone(), num_iter=60, num_to_optimize=20,
+                               learning_rate=0.05)
+    assert torch.allclose(arg, g["argmax"], atol=1e-6) and torch.allclose(val, g["max"], atol=1e-6)
+
+
+def test_rejection_sample_timeout_and_m_warning():
+    """tests/rejection_sampling_test.py:15-60 of the reference: a hopeless acceptance must hit the timeout."""
+
+    class DummyProposal:
+        def sample(self, shape, **kwargs):
+            return torch.randn(shape[0], 1)
+
+        def log_prob(self, x, **kwargs):
+            return -0.5 * x.pow(2).sum(dim=-1)
+
+    with pytest.raises(RuntimeError, match="rejection sampling exceeded"):
+        rejection_sample(potential_fn=lambda x: torch.full((x.shape[0],), -1e6), proposal=DummyProposal(),
+                         num_samples=5, max_sampling_time=0.01, m=1e12)
+    prop = MultivariateNormal(torch.zeros(2), torch.eye(2))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rejection_sample(lambda th: prop.log_prob(th), prop, num_samples=10, num_samples_to_find_max=50,
+                         num_iter_to_find_max=2, m=0.9)
+    assert any("m < 1.0" in str(x.message) for x in w)
