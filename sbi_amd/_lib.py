@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 102    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 103    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -35,6 +35,16 @@ class NSFConfigC(Structure):
         ("D", c_int32), ("C", c_int32), ("H", c_int32), ("K", c_int32), ("T", c_int32), ("NB", c_int32),
         ("tail_bound", c_float), ("min_bin_width", c_float), ("min_bin_height", c_float),
         ("min_derivative", c_float), ("lu_eps", c_float),
+    ]
+
+
+class MAFConfigC(Structure):
+    """Mirror of ``struct sbi_amd_maf_config`` (include/sbi_amd_maf.h)."""
+
+    _fields_ = [
+        ("D", c_int32), ("C", c_int32), ("H", c_int32), ("K", c_int32), ("T", c_int32), ("NB", c_int32),
+        ("tail_bound", c_float), ("min_bin_width", c_float), ("min_bin_height", c_float),
+        ("min_derivative", c_float), ("scale_by_sqrt_hidden", c_int32),
     ]
 
 
@@ -112,6 +122,24 @@ _SIGNATURES = {
         c_int,
         [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
          c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_maf_param_count": (c_int64, [POINTER(MAFConfigC)]),
+    "sbi_amd_maf_packed_floats": (c_int64, [POINTER(MAFConfigC)]),
+    "sbi_amd_maf_param_offset": (c_int64, [POINTER(MAFConfigC), c_int32, c_int32, c_int32]),
+    "sbi_amd_maf_pack": (c_int, [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sbi_amd_maf_log_prob": (
+        c_int,
+        [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_maf_sample": (
+        c_int,
+        [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_maf_train_workspace_floats": (c_int64, [POINTER(MAFConfigC), c_int64]),
+    "sbi_amd_maf_loss_fwd_bwd": (
+        c_int,
+        [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_nsf_abi_version": (c_int, []),
     "sbi_amd_nsf_arch": (c_char_p, []),

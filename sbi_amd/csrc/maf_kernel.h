@@ -1,0 +1,605 @@
+#pragma once
+// maf_kernel.h -- `maf_rqs` on gfx950: masked autoregressive flow whose transforms are rational-quadratic splines
+// (sbi build_maf_rqs, /root/reference/sbi/neural_nets/net_builders/flow.py:212-330; arithmetic = nflows 0.14
+// transforms/made.py + transforms/autoregressive.py + transforms/permutations.py).
+//
+// Execution model = the NSF kernels' (nsf_device.h): one wavefront owns 16 rows, lane = (row j, k-slot g); every
+// linear of the MADE conditioner runs on v_mfma_f32_16x16x4_f32 with M = output feature, N = row, K = input
+// feature, activations chained through registers (D fragment of a layer = B fragment of the next), weights read
+// from the LDS image a workgroup stages once per transform.  The degree masks of MaskedLinear are static: the
+// pack kernel multiplies them into the image ("MADE masked linear" = a dense GEMM on pre-masked weights), the
+// weight-gradient kernel multiplies them into the gradients.
+//   maf_flow_kernel<K,KSH,false>: theta, x -> log p [+ noise]          one conditioner pass per transform
+//   maf_flow_kernel<K,KSH,true >: noise, x -> theta [+ logabsdet]      D passes per transform (pass i fixes dim i)
+//   maf_bwd_kernel<K,KSH>       : per transform, row-parallel backward; leaves the per-row layer gradients and
+//                                 activations in HBM for
+//   maf_dw_kernel               : dW = G^T A as split-K (K = rows) MFMA GEMMs, masks applied, per-chunk partials
+//   maf_reduce_kernel           : fixed-order sum of the partials (deterministic)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "nsf_train_kernel.h"   // nsf_device.h + rq_spline_pair_bwd, gemm_T_breg
+#include "../../include/sbi_amd_maf.h"
+
+#define MAF_MAX_NB 4
+#define MAF_AW 64          // activation / gradient rows in HBM are 64 floats per layer
+#define MAF_CW 32          // standardized-context rows in HBM
+
+struct MafPlan {
+  NsfPlan n;               // dims, spline constants, shape[0] = the MADE's linears:
+                           //   lin[0] initial (H x D, masked) | lin[1] context (H x C) | lin[2+b] block b (H x H, masked)
+                           //   | lin[fin = 2+NB] final (D*P x H, masked)
+  int l_perm, l_iperm;     // image offsets of the transform's permutation / inverse permutation (int32 bits)
+  int n_layer;             // parameters per transform
+  int sc_zs, sc_us, sc_gy, sc_cin, sc_pst, sc_total;   // per-wave scratch (floats)
+  int PTW, DP;             // 16*PT; D*PTW: width of a padded spline-parameter-gradient row
+};
+
+// hidden / output degrees of nflows' MADE (made.py, random_mask=False)
+__host__ __device__ __forceinline__ int maf_hidden_degree(int o, int D) {
+  const int mx = D - 1 > 1 ? D - 1 : 1, mn = D - 1 < 1 ? D - 1 : 1;
+  return o % mx + mn;
+}
+// kind: 0 initial (inputs -> hidden), 1 context (dense), 2 block (hidden -> hidden), 3 final (hidden -> outputs)
+__host__ __device__ __forceinline__ bool maf_mask(int kind, int o, int c, int D, int P) {
+  switch (kind) {
+    case 0: return maf_hidden_degree(o, D) >= c + 1;
+    case 2: return maf_hidden_degree(o, D) >= maf_hidden_degree(c, D);
+    case 3: return o / P + 1 > maf_hidden_degree(c, D);
+    default: return true;
+  }
+}
+
+__device__ __forceinline__ float tanh_f(float x) {
+  // 1 - 2 / (e^{2|x|} + 1) on the hardware exp / rcp: absolute error ~1e-7 (the activations feed dense sums)
+  const float t = exp_f(-2.f * fabsf(x));
+  const float r = (1.f - t) * rcp_f(1.f + t);
+  return copysignf(r, x);
+}
+
+__device__ __forceinline__ void maf_pack_linear(float* __restrict__ img, const float* __restrict__ gl, const LinDesc& L,
+                                                int kind, int D, int P, int bias_pad, int bias_group,
+                                                int bias_group_pad, int tid, int nthreads) {
+  const int total = L.rows * L.ldk;
+  for (int idx = tid; idx < total; idx += nthreads) {
+    const int r = idx / L.ldk, c = idx - r * L.ldk;
+    float v = 0.f;
+    if (r < L.out && c < L.in && maf_mask(kind, r, c, D, P)) v = gl[L.g_w + r * L.in + c];
+    img[L.l_w + idx] = v;
+  }
+  for (int idx = tid; idx < bias_pad; idx += nthreads) {
+    const int grp = idx / bias_group_pad, p = idx - grp * bias_group_pad;
+    const int src = grp * bias_group + p;
+    img[L.l_b + idx] = (p < bias_group && src < L.out) ? gl[L.g_b + src] : 0.f;
+  }
+}
+
+#ifdef MAF_MAIN_TU   // non-template kernels: defined by maf.hip only
+__global__ void __launch_bounds__(256)
+maf_pack_kernel(const MafPlan mp, const float* __restrict__ params, const int* __restrict__ perms,
+                float* __restrict__ packed) {
+  const NsfPlan& pl = mp.n;
+  const ShapeDesc& S = pl.shape[0];
+  const int t = blockIdx.x;
+  float* img = packed + (long long)t * pl.img_floats;
+  const float* gl = params + (long long)t * mp.n_layer;
+  const int tid = blockIdx.y * blockDim.x + threadIdx.x, nthreads = gridDim.y * blockDim.x;
+  const int hb = 16 * NSF_HT;
+  maf_pack_linear(img, gl, S.lin[0], 0, pl.D, pl.P, hb, hb, hb, tid, nthreads);
+  maf_pack_linear(img, gl, S.lin[1], 1, pl.D, pl.P, hb, hb, hb, tid, nthreads);
+  for (int b = 0; b < pl.NB; ++b) maf_pack_linear(img, gl, S.lin[2 + b], 2, pl.D, pl.P, hb, hb, hb, tid, nthreads);
+  maf_pack_linear(img, gl, S.lin[S.fin], 3, pl.D, pl.P, pl.D * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
+  for (int d = tid; d < pl.D; d += nthreads) {
+    const int p = perms[t * pl.D + d];
+    img[mp.l_perm + d] = __int_as_float(p);
+    img[mp.l_iperm + p] = __int_as_float(d);
+  }
+  for (int idx = mp.l_iperm + 16 + tid; idx < pl.img_floats; idx += nthreads) img[idx] = 0.f;
+}
+
+#endif
+
+// MADE hidden stack: h = tanh(W0m z + b0 + gate), then NB x h = tanh(Wb h + bb); gate = tanh(Wc c + bc) is
+// computed once per transform by the caller.  `hs` (optional) receives the activation after every layer.
+template <int KSH>
+__device__ __forceinline__ void made_hidden(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S,
+                                            const LaneId& id, const float* __restrict__ cin_row,
+                                            const f4 (&gate)[NSF_HT], f4 (&h)[NSF_HT],
+                                            f4 (*hs)[NSF_HT] = nullptr) {
+  acc_init_bias(lds, S.lin[0], id, h);
+  gemm_blds(lds, S.lin[0], id, cin_row, h);
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[mt][r] = tanh_f(h[mt][r] + gate[mt][r]);
+  if (hs) {
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt) hs[0][mt] = h[mt];
+  }
+  // compile-time block index (the activation array must stay in registers): guarded unroll over the maximum
+#pragma unroll
+  for (int b = 0; b < MAF_MAX_NB; ++b) {
+    if (b < pl.NB) {
+      f4 u[NSF_HT];
+      acc_init_bias(lds, S.lin[2 + b], id, u);
+      gemm_breg<KSH>(lds, S.lin[2 + b], id, h, u);
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[mt][r] = tanh_f(u[mt][r]);
+      if (hs) {
+#pragma unroll
+        for (int mt = 0; mt < NSF_HT; ++mt) hs[b + 1][mt] = h[mt];
+      }
+    }
+  }
+}
+
+template <int KSH>
+__device__ __forceinline__ void made_gate(const float* __restrict__ lds, const ShapeDesc& S, const LaneId& id,
+                                          const float* __restrict__ ctx_row, f4 (&gate)[NSF_HT]) {
+  acc_init_bias(lds, S.lin[1], id, gate);
+  gemm_blds(lds, S.lin[1], id, ctx_row, gate);
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gate[mt][r] = tanh_f(gate[mt][r]);
+}
+
+// RandomPermutation on the wave's state rows: zs[j][d] <- zs[j][idx[d]]
+__device__ __forceinline__ void permute_rows(float* __restrict__ zs, int ZW, int D, const float* __restrict__ idx_f,
+                                             const LaneId& id) {
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int d = id.g + 4 * u;
+    v[u] = d < D ? zs[id.j * ZW + __float_as_int(idx_f[d])] : 0.f;
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int d = id.g + 4 * u;
+    if (d < D) zs[id.j * ZW + d] = v[u];
+  }
+  wave_lds_fence();
+}
+
+template <int K, int KSH, bool INV>
+__global__ void __launch_bounds__(512)
+maf_flow_kernel(const MafPlan mp, const float* __restrict__ packed, const float* __restrict__ zstats,
+                const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
+                float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash) {
+  constexpr int PT = (3 * K - 1 + 15) / 16;
+  const NsfPlan& pl = mp.n;
+  const ShapeDesc& S = pl.shape[0];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int wave = tid >> 6, nw = nthreads >> 6;
+  const LaneId id = make_lane();
+  float* sc = lds + pl.lds_w_floats + wave * mp.sc_total;
+  float* zs = sc + mp.sc_zs;
+  float* us = sc + mp.sc_us;
+  float* cin = sc + mp.sc_cin;
+  float* pst = sc + mp.sc_pst;
+  const long long row = (long long)blockIdx.x * (16 * nw) + 16 * wave + id.j;
+  const bool valid = row < n;
+  const int D = pl.D, C = pl.C;
+  const float* th_shift = zstats;
+  const float* th_scale = zstats + D;
+  const float* x_mean = zstats + 2 * D;
+  const float* x_std = x_mean + C;
+  float ld_acc = 0.f;
+  for (int i = id.lane; i < mp.sc_total; i += 64) sc[i] = 0.f;
+  {
+    const long long xr = (x_rows == n) ? row : (x_rows == 1 ? 0 : row % x_rows);
+    for (int d = id.g; d < D; d += 4) {
+      float v = valid ? in[row * D + d] : 0.f;
+      if (!INV) {
+        v = v * th_scale[d] + th_shift[d];
+        ld_acc += logf(fabsf(th_scale[d]));
+      }
+      zs[id.j * pl.ZW + d] = v;
+    }
+    // standardized context: constant over the transforms, lives at columns [D, D + C) of the conditioner input
+    for (int c = id.g; c < C; c += 4)
+      cin[id.j * pl.CINW + D + c] = ((valid ? x[xr * C + c] : 0.f) - x_mean[c]) / x_std[c];
+  }
+  wave_lds_fence();
+  const float* cin_row = cin + id.j * pl.CINW + id.g;
+
+  for (int li = 0; li < pl.T; ++li) {
+    const int t = INV ? (pl.T - 1 - li) : li;
+    __syncthreads();
+    stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
+    __syncthreads();
+    if (!INV && z_stash) {
+      for (int d = id.g; d < D; d += 4)
+        if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
+    }
+    f4 gate[NSF_HT], h[NSF_HT];
+    made_gate<KSH>(lds, S, id, cin_row + D, gate);
+    if (!INV) {
+      for (int k = id.g; k < D; k += 4) cin[id.j * pl.CINW + k] = zs[id.j * pl.ZW + k];
+      wave_lds_fence();
+      made_hidden<KSH>(lds, pl, S, id, cin_row, gate, h);
+      // all D dims are transformed, parameters from the ORIGINAL inputs (already folded into h)
+      const int nchunks = (D + 1) / 2;
+      for (int c = 0; c < nchunks; ++c) {
+        if (D - 2 * c >= 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 2 * c);
+        else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, 2 * c);
+        wave_lds_fence();
+        const int slot = id.g & 1, part = id.g >> 1;
+        const bool live = 2 * c + slot < D;
+        const int sl = live ? slot : 0;
+        const int dd = 2 * c + sl;
+        const int zi = id.j * pl.ZW + dd;
+        float y, ld;
+        rq_spline_pair<K, false>(pst + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part, y, ld);
+        zs[zi] = y;   // idle lanes recompute slot 0's task and store the same value
+        ld_acc += (live && part == 0) ? ld : 0.f;
+        wave_lds_fence();
+      }
+      permute_rows(zs, pl.ZW, D, lds + mp.l_perm, id);
+    } else {
+      permute_rows(zs, pl.ZW, D, lds + mp.l_iperm, id);   // inverse of the permutation that FOLLOWS the transform
+      for (int k = id.g; k < D; k += 4) cin[id.j * pl.CINW + k] = 0.f;
+      wave_lds_fence();
+      // autoregressive inverse (autoregressive.py: D passes from zeros): pass i sees the exact outputs of the
+      // dims < i, which is all dim i depends on, so only dim i's parameters and spline are evaluated
+      for (int i = 0; i < D; ++i) {
+        made_hidden<KSH>(lds, pl, S, id, cin_row, gate, h);
+        final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, i);
+        wave_lds_fence();
+        const int part = id.g >> 1;
+        float y, ld;
+        rq_spline_pair<K, true>(pst + id.j * pl.PSW, zs[id.j * pl.ZW + i], pl, part, y, ld);
+        cin[id.j * pl.CINW + i] = y;
+        us[id.j * pl.ZW + i] = y;
+        ld_acc += (id.g == 0) ? ld : 0.f;
+        wave_lds_fence();
+      }
+      for (int k = id.g; k < D; k += 4) zs[id.j * pl.ZW + k] = us[id.j * pl.ZW + k];
+      wave_lds_fence();
+    }
+  }
+
+  if (!INV) {
+    float part = 0.f;
+    for (int d = id.g; d < D; d += 4) {
+      const float z = zs[id.j * pl.ZW + d];
+      part += z * z;
+      if (out_aux && valid) out_aux[row * D + d] = z;
+    }
+    float v = -0.5f * part + ld_acc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (id.g == 0 && valid) out_main[row] = v - pl.log_z;
+  } else {
+    for (int d = id.g; d < D; d += 4) {
+      const float z = zs[id.j * pl.ZW + d];
+      ld_acc -= logf(fabsf(th_scale[d]));
+      if (valid) out_main[row * D + d] = (z - th_shift[d]) / th_scale[d];
+    }
+    float v = ld_acc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (out_aux && id.g == 0 && valid) out_aux[row] = v;
+  }
+}
+
+// ------------------------------------------------------------------ training: row-parallel backward
+struct MafBwdArgs {
+  const float* packed;
+  const float* zstats;
+  const float* z_in;       // (n, D) input state of this transform (forward stash)
+  const float* x;
+  const float* gz_up;      // (n, D) gradient wrt this transform's output (after the permutation); the LAST
+                           // transform receives the flow output z_T instead (d/dz of w 0.5|z|^2 = w z)
+  const float* row_w;
+  float uni_w;
+  long long n, x_rows;
+  float* gz_dn;            // (n, D) gradient wrt this transform's input (t > 0)
+  float* grad_theta;       // optional (n, D), written by t == 0
+  float* GP;               // (n, DP)  gradient wrt the raw spline parameters, rows padded to 16*PT per dim
+  float* ACT;              // (n, (NB+1)*64) h_0 .. h_NB
+  float* G;                // (n, (NB+2)*64) slot 0: d/d(a1), slot 1: d/d(context pre-activation), 2+b: block b
+  float* CTX;              // (n, 32) standardized context
+  int t, is_last;
+};
+
+// g_h += Wf[rows of dims d0 .. d0+1]^T g_p, g_p read from the wave's spline-parameter staging buffer
+template <int PT>
+__device__ __forceinline__ void maf_wft_chunk(const float* __restrict__ lds, const LinDesc& LF, const NsfPlan& pl,
+                                              const LaneId& id, const float* __restrict__ pst, int d0, int nact,
+                                              f4 (&gh)[NSF_HT]) {
+  constexpr int KS = 4 * PT;
+  int col[NSF_HT];
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt) {
+    const int f = 16 * mt + id.iperm;
+    col[mt] = f < LF.in ? f : 0;
+  }
+  const int kstride = 4 * LF.ldk;
+  for (int sl = 0; sl < nact; ++sl) {
+    const float* wrow = lds + LF.l_w + ((d0 + sl) * pl.P + id.g) * LF.ldk;
+    const float* brow = pst + sl * pl.DS + id.j * pl.PSW + id.g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float bv = brow[4 * s];
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = MFMA16(wrow[col[mt] + s * kstride], bv, gh[mt]);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gh[mt][r] = (16 * mt + 4 * r + id.g < LF.in) ? gh[mt][r] : 0.f;
+}
+
+// D fragments -> one 64-float row segment per batch row in HBM
+__device__ __forceinline__ void store_frag_rows(float* __restrict__ dst, int ld, long long row, bool valid,
+                                                const LaneId& id, const f4 (&v)[NSF_HT]) {
+  if (!valid) return;
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[row * ld + 16 * mt + 4 * r + id.g] = v[mt][r];
+}
+
+template <int K, int KSH>
+__global__ void __launch_bounds__(256)
+maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
+  constexpr int PT = (3 * K - 1 + 15) / 16;
+  const NsfPlan& pl = mp.n;
+  const ShapeDesc& S = pl.shape[0];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int wave = tid >> 6, nw = nthreads >> 6;
+  const LaneId id = make_lane();
+  float* sc = lds + pl.lds_w_floats + wave * mp.sc_total;
+  float* zs = sc + mp.sc_zs;
+  float* gxs = sc + mp.sc_us;      // direct-path gradient wrt the transform input (through the spline argument)
+  float* gys = sc + mp.sc_gy;      // gradient wrt the spline outputs
+  float* cin = sc + mp.sc_cin;
+  float* pst = sc + mp.sc_pst;
+  const int D = pl.D, C = pl.C, NB = pl.NB;
+  const long long n = a.n;
+  const long long row = (long long)blockIdx.x * (16 * nw) + 16 * wave + id.j;
+  const bool valid = row < n;
+  const long long rs = valid ? row : 0;
+  const float* x_mean = a.zstats + 2 * D;
+  const float* x_std = x_mean + C;
+  const float wn = valid ? (a.row_w ? a.row_w[rs] : a.uni_w) : 0.f;
+  const float gld = -wn;   // d(sum w loss) / d(any log|det| term)
+  stage_layer(lds, a.packed + (long long)a.t * pl.img_floats, pl.img_floats, tid, nthreads);
+  for (int i = id.lane; i < mp.sc_total; i += 64) sc[i] = 0.f;
+  __syncthreads();
+  {
+    const long long xr = (a.x_rows == n) ? rs : (a.x_rows == 1 ? 0 : rs % a.x_rows);
+    for (int d = id.g; d < D; d += 4) {
+      const float z = valid ? a.z_in[rs * D + d] : 0.f;
+      zs[id.j * pl.ZW + d] = z;
+      cin[id.j * pl.CINW + d] = z;
+      // undo the permutation on the way back: out[d] = in[perm[d]]  =>  g_in[k] = g_out[iperm[k]]
+      const int src = __float_as_int(lds[mp.l_iperm + d]);
+      const float g = valid ? a.gz_up[rs * D + src] : 0.f;
+      gys[id.j * pl.ZW + d] = a.is_last ? wn * g : g;
+    }
+    for (int c = id.g; c < C; c += 4) {
+      const float v = ((valid ? a.x[xr * C + c] : 0.f) - x_mean[c]) / x_std[c];
+      cin[id.j * pl.CINW + D + c] = v;
+      if (valid) a.CTX[row * MAF_CW + c] = v;
+    }
+  }
+  wave_lds_fence();
+  const float* cin_row = cin + id.j * pl.CINW + id.g;
+  // ---- recompute the conditioner (activations stay in registers)
+  f4 gate[NSF_HT], h[NSF_HT], hs[MAF_MAX_NB + 1][NSF_HT];
+  made_gate<KSH>(lds, S, id, cin_row + D, gate);
+  made_hidden<KSH>(lds, pl, S, id, cin_row, gate, h, hs);
+#pragma unroll
+  for (int b = 0; b <= MAF_MAX_NB; ++b)
+    if (b <= NB) store_frag_rows(a.ACT + 64 * b, (MAF_MAX_NB + 1) * MAF_AW, row, valid, id, hs[b]);
+  // ---- spline forward + reverse mode per chunk of two dims; g_h = Wf^T g_p accumulated on the fly
+  f4 gh[NSF_HT];
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = {0.f, 0.f, 0.f, 0.f};
+  const LinDesc& LF = S.lin[S.fin];
+  const int nchunks = (D + 1) / 2;
+  for (int c = 0; c < nchunks; ++c) {
+    const int nact = D - 2 * c >= 2 ? 2 : 1;
+    if (nact == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 2 * c);
+    else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, 2 * c);
+    wave_lds_fence();
+    const int slot = id.g & 1, part = id.g >> 1;
+    const int dd = 2 * c + slot;
+    if (dd < D) {     // both lanes of a pair (lane, lane ^ 32) share the slot: the exchange inside stays convergent
+      float* pp = pst + slot * pl.DS + id.j * pl.PSW;
+      const int zi = id.j * pl.ZW + dd;
+      float yv, gxv;
+      rq_spline_pair_bwd<K>(pp, mp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);
+      if (part == 0) gxs[zi] = gxv;
+    }
+    wave_lds_fence();
+    // g_p rows -> HBM (operand of d Wf), 16*PT floats per (row, dim)
+    for (int sl = 0; sl < nact; ++sl)
+      for (int k = id.g; k < mp.PTW; k += 4)
+        if (valid) a.GP[row * mp.DP + (2 * c + sl) * mp.PTW + k] = pst[sl * pl.DS + id.j * pl.PSW + k];
+    maf_wft_chunk<PT>(lds, LF, pl, id, pst, 2 * c, nact, gh);
+    wave_lds_fence();
+  }
+  // ---- back through the feed-forward blocks: G_b = g (1 - h_{b+1}^2), g <- W_b^T G_b
+  const int GW = (MAF_MAX_NB + 2) * MAF_AW;
+#pragma unroll
+  for (int b = MAF_MAX_NB - 1; b >= 0; --b) {
+    if (b < NB) {
+      f4 gb[NSF_HT];
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = hs[b + 1][mt][r];
+          gb[mt][r] = gh[mt][r] * (1.f - hv * hv);
+          gh[mt][r] = 0.f;
+        }
+      store_frag_rows(a.G + 64 * (2 + b), GW, row, valid, id, gb);
+      gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + b], id, gb, gh);
+    }
+  }
+  {
+    f4 g0[NSF_HT], gc[NSF_HT], gin[1];
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = hs[0][mt][r], gt = gate[mt][r];
+        g0[mt][r] = gh[mt][r] * (1.f - hv * hv);          // d / d(W0 z + b0 + gate)
+        gc[mt][r] = g0[mt][r] * (1.f - gt * gt);          // d / d(Wc c + bc)
+      }
+    store_frag_rows(a.G, GW, row, valid, id, g0);
+    store_frag_rows(a.G + 64, GW, row, valid, id, gc);
+    gin[0] = {0.f, 0.f, 0.f, 0.f};
+    gemm_T_breg<KSH, 1>(lds, S.lin[0], id, g0, gin);     // through the (masked) initial layer: dims < their own
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * r + id.g;
+      if (k < D && valid) {
+        const float g = gxs[id.j * pl.ZW + k] + gin[0][r];
+        if (a.t > 0) a.gz_dn[row * D + k] = g;
+        else if (a.grad_theta) a.grad_theta[row * D + k] = g * a.zstats[D + k];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ training: weight gradients
+struct MafLin {
+  const float* G;   // (n, ldg): per-row gradient wrt the layer's outputs (padded column layout, see group_pad)
+  const float* A;   // (n, lda): per-row inputs of the layer
+  int ldg, lda;
+  int out, in;      // natural dims
+  int group, group_pad;   // output o lives at column (o / group) * group_pad + o % group  (final layer: P -> 16*PT)
+  int g_w, g_b;     // offsets inside the transform's parameter block
+  int kind;         // mask kind (maf_mask)
+};
+struct MafDwArgs {
+  MafLin lin[3 + MAF_MAX_NB];
+  long long n;
+  int rows_per_chunk, nchunks, n_layer, D, P;
+  float* partial;   // (nchunks, n_layer) for this transform
+};
+
+#ifdef MAF_MAIN_TU
+__global__ void __launch_bounds__(256)
+maf_dw_kernel(const MafDwArgs a) {
+  const MafLin& L = a.lin[blockIdx.y];
+  const int chunk = blockIdx.x;
+  const long long r0 = (long long)chunk * a.rows_per_chunk;
+  long long r1 = r0 + a.rows_per_chunk;
+  if (r1 > a.n) r1 = a.n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int mcols = (L.out + L.group - 1) / L.group * L.group_pad;   // padded output columns
+  const int mtiles = (mcols + 15) / 16;
+  const int ntiles = (L.in + 15) / 16;
+  float* part = a.partial + (long long)chunk * a.n_layer;
+  const float one = (j == 0) ? 1.f : 0.f;
+  for (int mt = wave; mt < mtiles; mt += 4) {
+    f4 acc[4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = {0.f, 0.f, 0.f, 0.f};
+    const int mcol = 16 * mt + j;
+    const bool mok = mcol < mcols;
+#pragma unroll 4
+    for (long long k0 = r0; k0 < r1; k0 += 4) {
+      const long long row = k0 + g;
+      const bool ok = row < r1;
+      const float av = (ok && mok) ? L.G[row * L.ldg + mcol] : 0.f;
+      float bv[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = 16 * nt + j;
+        bv[nt] = (ok && nt < ntiles && col < L.in) ? L.A[row * L.lda + col] : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        if (nt < ntiles) acc[nt] = MFMA16(av, bv[nt], acc[nt]);
+      accb = MFMA16(av, ok ? one : 0.f, accb);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mt + 4 * g + r;           // padded output column of this accumulator row
+      const int grp = m / L.group_pad, p = m - grp * L.group_pad;
+      const int o = grp * L.group + p;
+      if (p < L.group && o < L.out) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int i = 16 * nt + j;
+          if (nt < ntiles && i < L.in)
+            part[L.g_w + o * L.in + i] = maf_mask(L.kind, o, i, a.D, a.P) ? acc[nt][r] : 0.f;
+        }
+        if (j == 0) part[L.g_b + o] = accb[r];
+      }
+    }
+  }
+}
+
+// grad[t][idx] = sum over chunks (fixed order, 4-way ILP)
+__global__ void __launch_bounds__(256)
+maf_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad, int n_layer, int nchunks, int T) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)T * n_layer) return;
+  const int t = (int)(idx / n_layer);
+  const int li = (int)(idx - (long long)t * n_layer);
+  const float* base = partial + (long long)t * nchunks * n_layer + li;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 3 < nchunks; c += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += base[(long long)(c + u) * n_layer];
+  }
+  for (; c < nchunks; ++c) s[0] += base[(long long)c * n_layer];
+  grad[idx] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+#endif
+
+// ------------------------------------------------------------------ per-K launchers (instantiated per TU)
+template <int K, int KSH, bool INV>
+static int maf_launch_flow(const MafPlan& mp, int nw, const float* packed, const float* zstats, const float* in,
+                           const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                           float* z_stash, hipStream_t st) {
+  const int lds_bytes = 4 * (mp.n.lds_w_floats + nw * mp.sc_total);
+  auto kern = maf_flow_kernel<K, KSH, INV>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  const int64_t grid = (n + 16 * nw - 1) / (16 * nw);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, st, mp, packed, zstats, in, x,
+                     (long long)n, (long long)x_rows, out_main, out_aux, z_stash);
+  return (int)hipGetLastError();
+}
+
+template <int K, int KSH>
+static int maf_launch_bwd(const MafPlan& mp, int nw, const MafBwdArgs& a, hipStream_t st) {
+  const int lds_bytes = 4 * (mp.n.lds_w_floats + nw * mp.sc_total);
+  auto kern = maf_bwd_kernel<K, KSH>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  const int64_t grid = (a.n + 16 * nw - 1) / (16 * nw);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, st, mp, a);
+  return (int)hipGetLastError();
+}
+
+// mode 0: log_prob (+ stash), 1: inverse, 2: backward of one transform
+template <int K>
+int maf_dispatch_k(const MafPlan& mp, int nw, int mode, const float* packed, const float* zstats, const float* in,
+                   const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux, float* z_stash,
+                   const MafBwdArgs* bwd, hipStream_t st) {
+  const bool k13 = mp.n.KSH == 13;
+  if (mode == 0)
+    return k13 ? maf_launch_flow<K, 13, false>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st)
+               : maf_launch_flow<K, 16, false>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+  if (mode == 1)
+    return k13 ? maf_launch_flow<K, 13, true>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st)
+               : maf_launch_flow<K, 16, true>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+  return k13 ? maf_launch_bwd<K, 13>(mp, nw, *bwd, st) : maf_launch_bwd<K, 16>(mp, nw, *bwd, st);
+}

@@ -162,7 +162,7 @@ class MCMCPosterior:
 
         from sbi_amd import _lib
         from sbi_amd.inference.potentials.posterior_based_potential import PosteriorBasedPotential
-        from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, _log_prob_call
+        from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow
 
         pot = self.potential_fn
         if not isinstance(pot, PosteriorBasedPotential) or not isinstance(pot.posterior_estimator, NSFFlow):
@@ -219,7 +219,7 @@ class MCMCPosterior:
                 rc = lib.sbi_amd_mcmc_to_constrained(kind, C, D, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(u),
                                                      _lib.ptr(theta), _lib.ptr(lad), _lib.current_stream(u.device))
             _lib.check(rc, "mcmc_to_constrained")
-            logp, _ = _log_prob_call(net, theta, x_row, want_noise=False)
+            logp, _ = est._kernel_log_prob(theta, x_row, False)
             return logp, lad
 
         return potential_

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 from sbi_amd import _lib
-from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, loss_fwd_bwd, train_backward, train_forward
+from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, train_backward, train_forward
 
 
 class FusedTrainStep:
@@ -59,10 +59,7 @@ class FusedTrainStep:
         self.step_count = int(sd["step"])
 
     def _workspace(self, n: int) -> Tensor:
-        lib = _lib.load()
-        need = lib.sbi_amd_nsf_train_workspace_floats(self.net.hyper.c_config(), n)
-        if need < 0:
-            _lib.check(int(need), "nsf_train_workspace_floats")
+        need = self.net.train_workspace_floats(n)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(int(need), dtype=torch.float32, device=self.net.flat_params.device)
         return self.workspace
@@ -87,7 +84,7 @@ class FusedTrainStep:
         n = theta.shape[0]
         gb = global_batch if global_batch is not None else n * self.world
         x = self._embedded(x)
-        losses, _ = loss_fwd_bwd(self.net, theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
+        losses, _ = self.net.train_pass(theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
         if self.distributed:
             self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
         return losses
@@ -102,6 +99,9 @@ class FusedTrainStep:
         weights d loss / d log q on the device, one backward pass on the stash of that forward."""
         from sbi_amd.inference.trainers.npe.atomic import build_atoms, clamp_num_atoms, sample_contrasting_indices
 
+        if not getattr(self.net, "supports_atomic", False):
+            raise NotImplementedError(f"{type(self.net).__name__} has no split forward / backward training pass; "
+                                      "multi-round training of this estimator takes NPE.train()'s autograd path")
         B = theta.shape[0]
         x = self._embedded(x)
         A = clamp_num_atoms(num_atoms, B)

@@ -343,7 +343,7 @@ class PosteriorEstimatorTrainer:
         emb_trainable = any(p.requires_grad for p in net.embedding_net.parameters()) \
             if getattr(net, "embedding_net", None) is not None else False
         fused = (isinstance(net, NSFFlow) and torch.device(self._device).type == "cuda" and calibration_kernel is None
-                 and not emb_trainable)
+                 and not emb_trainable and (not atomic or getattr(net.net, "supports_atomic", False)))
         if not cfg.resume_training or (fused and self._stepper is None) or (not fused and self.optimizer is None):
             if fused:
                 from sbi_amd.inference.trainers.fused import FusedTrainStep

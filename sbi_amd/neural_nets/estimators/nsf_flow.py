@@ -159,6 +159,21 @@ class NSFNet(nn.Module):
         assert flat.numel() == self.flat_params.numel()
         self.flat_params.copy_(flat)
 
+    # -- fused training pass (what FusedTrainStep drives) --------------------------------
+    supports_atomic = True     # train_forward / train_backward on one stash (multi-round NPE-C)
+
+    def train_workspace_floats(self, n: int) -> int:
+        need = _lib.load().sbi_amd_nsf_train_workspace_floats(self.hyper.c_config(), n)
+        if need < 0:
+            _lib.check(int(need), "nsf_train_workspace_floats")
+        return int(need)
+
+    def train_pass(self, theta: Tensor, x: Tensor, row_weight: Optional[Tensor], uniform_weight: float,
+                   grad_out: Tensor, workspace: Optional[Tensor] = None, want_grad_theta: bool = False,
+                   grad_x_out: Optional[Tensor] = None):
+        return loss_fwd_bwd(self, theta, x, row_weight, uniform_weight, grad_out, want_grad_theta, workspace,
+                            grad_x_out)
+
     # -- nflows state_dict exchange -------------------------------------------------
     def _slices(self):
         h = self.hyper
@@ -425,6 +440,16 @@ class NSFFlow(ConditionalDensityEstimator):
         e = self._embedding_net(condition.reshape(-1, *self.condition_shape).float())
         return e.reshape(*lead, self._cdim)
 
+    # -- kernel hooks (overridden by the maf_rqs estimator, which binds its own C entry points) -----
+    def _kernel_log_prob(self, theta: Tensor, x: Tensor, want_noise: bool):
+        return _log_prob_call(self.net, theta, x, want_noise)
+
+    def _kernel_sample(self, noise: Tensor, x: Tensor, want_ld: bool):
+        return _sample_call(self.net, noise, x, want_ld)
+
+    def _autograd_log_prob(self, theta: Tensor, x: Tensor) -> Tensor:
+        return _NSFLogProbFn.apply(theta, x, self.net.flat_params, self.net)
+
     # -- helpers ---------------------------------------------------------------------
     def _flatten_pair(self, input: Tensor, condition: Tensor) -> Tuple[Tensor, Tensor, int, int]:
         """(S,B,D)/(B,D) input + condition -> theta (S*B, D), x (x_rows, C), S, B without
@@ -451,9 +476,9 @@ class NSFFlow(ConditionalDensityEstimator):
         needs_grad = torch.is_grad_enabled() and (theta.requires_grad or x.requires_grad
                                                   or self.net.flat_params.requires_grad)
         if needs_grad:
-            lp = _NSFLogProbFn.apply(theta, x, self.net.flat_params, self.net)
+            lp = self._autograd_log_prob(theta, x)
         else:
-            lp, _ = _log_prob_call(self.net, theta, x, want_noise=False)
+            lp, _ = self._kernel_log_prob(theta, x, False)
         return lp.reshape(S, B)
 
     def loss(self, input: Tensor, condition: Tensor, **kwargs) -> Tensor:
@@ -466,15 +491,15 @@ class NSFFlow(ConditionalDensityEstimator):
         with torch.no_grad():
             emb = self._embed(condition)
             x = emb.expand(bshape + (self._cdim,)).reshape(-1, self._cdim).contiguous().float()
-            _, noise = _log_prob_call(self.net, theta, x, want_noise=True)
+            _, noise = self._kernel_log_prob(theta, x, True)
         return noise.reshape(bshape + (noise.shape[-1],))
 
     def sample_from_noise(self, noise: Tensor, condition: Tensor, with_logabsdet: bool = False):
         """theta = transform^{-1}(noise | condition); noise (N,D), condition (1|N, C)."""
         with torch.no_grad():
             emb = self._embed(condition)
-            theta, ld = _sample_call(self.net, noise.contiguous().float(),
-                                     emb.reshape(emb.shape[0], self._cdim).contiguous().float(), with_logabsdet)
+            theta, ld = self._kernel_sample(noise.contiguous().float(),
+                                            emb.reshape(emb.shape[0], self._cdim).contiguous().float(), with_logabsdet)
         return (theta, ld) if with_logabsdet else theta
 
     def sample(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tensor:

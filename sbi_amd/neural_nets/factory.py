@@ -14,10 +14,13 @@ from typing import Any, Callable, Optional
 
 from torch import Tensor, nn
 
-from sbi_amd.neural_nets.net_builders.estimator_configs import NSFConfig
+from sbi_amd.neural_nets.net_builders.estimator_configs import MAFRQSConfig, NSFConfig
 
 _NSF_FIELDS = {"hidden_features", "num_transforms", "num_bins", "num_blocks", "dropout_probability",
                "use_batch_norm", "tail_bound", "hidden_layers_spline_context", "dtype"}
+_MAF_RQS_FIELDS = (_NSF_FIELDS - {"hidden_layers_spline_context"}) | {"tails", "min_bin_width", "min_bin_height",
+                                                                        "min_derivative"}
+_MODELS = {"nsf": (NSFConfig, _NSF_FIELDS), "maf_rqs": (MAFRQSConfig, _MAF_RQS_FIELDS)}
 
 
 def posterior_nn(
@@ -31,18 +34,19 @@ def posterior_nn(
     **kwargs: Any,
 ) -> Callable[[Tensor, Tensor], nn.Module]:
     """Return a function that builds the posterior density estimator from (theta, x) batches."""
-    known = {k: v for k, v in kwargs.items() if k in _NSF_FIELDS}
-    unknown = {k: v for k, v in kwargs.items() if k not in _NSF_FIELDS}
+    model_fields = _MODELS.get(model, _MODELS["nsf"])[1]
+    known = {k: v for k, v in kwargs.items() if k in model_fields}
+    unknown = {k: v for k, v in kwargs.items() if k not in model_fields}
     if unknown:
         warnings.warn(f"Unknown kwargs {sorted(unknown)} are forwarded to the builder.", UserWarning, stacklevel=2)
 
     def build_fn(batch_theta: Tensor, batch_x: Tensor):
-        if model != "nsf":
+        if model not in _MODELS:
             raise NotImplementedError(
-                f"sbi_amd implements the 'nsf' posterior estimator only (got model={model!r}); other model "
-                "families are outside the accelerated path."
+                f"sbi_amd implements the 'nsf' and 'maf_rqs' posterior estimators (got model={model!r}); other "
+                "model families are outside the accelerated path."
             )
-        cfg = NSFConfig(
+        cfg = _MODELS[model][0](
             z_score_input=z_score_theta, z_score_condition=z_score_x,
             embedding_net=None if isinstance(embedding_net, nn.Identity) else embedding_net,
             hidden_features=hidden_features, num_transforms=num_transforms, num_bins=num_bins,

@@ -69,4 +69,24 @@ class NSFConfig:
                     parts.append(f"extra_kwargs={v!r}")
             elif v != default:
                 parts.append(f"{f.name}={v!r}")
-        return f"NSFConfig({', '.join(parts)})"
+        return f"{type(self).__name__}({', '.join(parts)})"
+
+
+@dataclass(frozen=True, repr=False)
+class MAFRQSConfig(NSFConfig):
+    """Mirror of sbi's ``MAFRQSConfig`` (estimator_configs.py:1200-1219): the flow-base fields plus the spline's."""
+
+    tails: Optional[str] = "linear"
+    min_bin_width: float = 1e-3
+    min_bin_height: float = 1e-3
+    min_derivative: float = 1e-3
+
+    def _build_kwargs(self) -> Dict[str, Any]:
+        kw = super()._build_kwargs()
+        kw.pop("hidden_layers_spline_context", None)   # an NSF-only field
+        return kw
+
+    def build(self, batch_input: Tensor, batch_condition: Tensor):
+        from sbi_amd.neural_nets.net_builders.flow import build_maf_rqs
+
+        return build_maf_rqs(batch_x=batch_input, batch_y=batch_condition, **self._build_kwargs())

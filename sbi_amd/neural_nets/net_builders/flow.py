@@ -33,40 +33,15 @@ def check_data_device(datum_1: Tensor, datum_2: Tensor) -> None:
         )
 
 
-def build_nsf(
-    batch_x: Tensor,
-    batch_y: Tensor,
-    z_score_x: Optional[str] = "independent",
-    z_score_y: Optional[str] = "independent",
-    hidden_features: int = 50,
-    num_transforms: int = 5,
-    num_bins: int = 10,
-    embedding_net: nn.Module = nn.Identity(),
-    tail_bound: float = 3.0,
-    hidden_layers_spline_context: int = 1,
-    num_blocks: int = 2,
-    dropout_probability: float = 0.0,
-    use_batch_norm: bool = False,
-    **kwargs,
-) -> NSFFlow:
-    """Same signature and meaning as the reference ``build_nsf`` (flow.py:333-352)."""
-    check_data_device(batch_x, batch_y)
-    assert_transform_to_unconstrained_supported(
-        z_score_x, "build_nsf",
-        "Use one of 'none', 'independent', 'structured'.",
-    )
-    if dropout_probability != 0.0 or use_batch_norm:
-        raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
+def _flow_inputs(batch_x: Tensor, batch_y: Tensor, z_score_x, z_score_y, embedding_net: nn.Module, builder: str):
+    """Shared front end of the flow builders (flow.py:393-394, 441-452, 1395-1416): event sizes, the optional
+    `standardizing_net -> embedding_net` module in front of the kernels, and the z-scoring buffers
+    `zstats = [theta shift, theta scale, x mean, x std]`.  Returns (D, C, zstats, zx, zy, embedding | None)."""
     x_numel = batch_x[0].numel()
     y_numel = batch_y[0].numel()
-    if x_numel == 1 and hidden_layers_spline_context != 1:
-        raise NotImplementedError(
-            "sbi_amd.build_nsf: the 1-D theta conditioner (ContextSplineMap, flow.py:1419-1478) is implemented "
-            "for hidden_layers_spline_context=1 (the reference default)."
-        )
     has_embedding = not isinstance(embedding_net, nn.Identity)
     if batch_x[0].dim() != 1 or (batch_y[0].dim() != 1 and not has_embedding):
-        raise NotImplementedError("sbi_amd.build_nsf: theta events must be 1-D (and x events too unless an "
+        raise NotImplementedError(f"sbi_amd.{builder}: theta events must be 1-D (and x events too unless an "
                                   "embedding net maps them to feature vectors)")
     embedding = None
     if has_embedding:
@@ -101,6 +76,41 @@ def build_nsf(
         zstats[2 * D : 2 * D + C] = mean.expand(C)
         zstats[2 * D + C :] = std.expand(C)
 
+    return D, C, zstats, zx, zy, embedding
+
+
+def build_nsf(
+    batch_x: Tensor,
+    batch_y: Tensor,
+    z_score_x: Optional[str] = "independent",
+    z_score_y: Optional[str] = "independent",
+    hidden_features: int = 50,
+    num_transforms: int = 5,
+    num_bins: int = 10,
+    embedding_net: nn.Module = nn.Identity(),
+    tail_bound: float = 3.0,
+    hidden_layers_spline_context: int = 1,
+    num_blocks: int = 2,
+    dropout_probability: float = 0.0,
+    use_batch_norm: bool = False,
+    **kwargs,
+) -> NSFFlow:
+    """Same signature and meaning as the reference ``build_nsf`` (flow.py:333-352)."""
+    check_data_device(batch_x, batch_y)
+    assert_transform_to_unconstrained_supported(
+        z_score_x, "build_nsf",
+        "Use one of 'none', 'independent', 'structured'.",
+    )
+    if dropout_probability != 0.0 or use_batch_norm:
+        raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
+    x_numel = batch_x[0].numel()
+    if x_numel == 1 and hidden_layers_spline_context != 1:
+        raise NotImplementedError(
+            "sbi_amd.build_nsf: the 1-D theta conditioner (ContextSplineMap, flow.py:1419-1478) is implemented "
+            "for hidden_layers_spline_context=1 (the reference default)."
+        )
+    D, C, zstats, zx, zy, embedding = _flow_inputs(batch_x, batch_y, z_score_x, z_score_y, embedding_net, "build_nsf")
+
     hyper = NSFHyper(D=D, C=C, hidden_features=hidden_features, num_transforms=num_transforms,
                      num_bins=num_bins, num_blocks=num_blocks, tail_bound=float(tail_bound))
     net = NSFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy, dtype=kwargs.get("dtype", torch.float32))
@@ -117,3 +127,50 @@ class Standardize(nn.Module):
 
     def forward(self, tensor: Tensor) -> Tensor:
         return (tensor - self._mean) / self._std
+
+
+def build_maf_rqs(
+    batch_x: Tensor,
+    batch_y: Tensor,
+    z_score_x: Optional[str] = "independent",
+    z_score_y: Optional[str] = "independent",
+    hidden_features: int = 50,
+    num_transforms: int = 5,
+    embedding_net: nn.Module = nn.Identity(),
+    num_blocks: int = 2,
+    num_bins: int = 10,
+    tails: Optional[str] = "linear",
+    tail_bound: float = 3.0,
+    dropout_probability: float = 0.0,
+    use_batch_norm: bool = False,
+    min_bin_width: float = 1e-3,
+    min_bin_height: float = 1e-3,
+    min_derivative: float = 1e-3,
+    **kwargs,
+):
+    """Same signature and meaning as the reference ``build_maf_rqs`` (flow.py:212-330): num_transforms x
+    [MaskedPiecewiseRationalQuadraticAutoregressiveTransform(hidden_features, num_blocks feed-forward blocks, tanh,
+    linear tails), RandomPermutation], z-scoring of both sides.  Runs on the maf_rqs HIP kernels
+    (include/sbi_amd_maf.h); unsupported options raise instead of degrading."""
+    from sbi_amd.neural_nets.estimators.maf_flow import MAFHyper, MAFNet, MAFRQSFlow
+
+    check_data_device(batch_x, batch_y)
+    assert_transform_to_unconstrained_supported(
+        z_score_x, "build_maf_rqs",
+        "Use one of 'none', 'independent', 'structured'.",
+    )
+    if dropout_probability != 0.0 or use_batch_norm:
+        raise NotImplementedError("sbi_amd.build_maf_rqs: dropout / batch norm are not implemented in the HIP path")
+    if tails != "linear":
+        raise NotImplementedError("sbi_amd.build_maf_rqs: only tails='linear' (sbi's default) is implemented")
+    if batch_x[0].numel() == 1:
+        import warnings
+
+        warnings.warn("In one-dimensional output space, this flow is limited to Gaussians", stacklevel=2)
+    D, C, zstats, zx, zy, embedding = _flow_inputs(batch_x, batch_y, z_score_x, z_score_y, embedding_net,
+                                                  "build_maf_rqs")
+    hyper = MAFHyper(D=D, C=C, hidden_features=hidden_features, num_transforms=num_transforms, num_bins=num_bins,
+                     num_blocks=num_blocks, tail_bound=float(tail_bound), min_bin_width=float(min_bin_width),
+                     min_bin_height=float(min_bin_height), min_derivative=float(min_derivative))
+    net = MAFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy, dtype=kwargs.get("dtype", torch.float32))
+    return MAFRQSFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape, embedding_net=embedding)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     syms = set()
-    for header in ("sbi_amd_nsf.h", "sbi_amd_fmpe.h"):
+    for header in ("sbi_amd_nsf.h", "sbi_amd_fmpe.h", "sbi_amd_maf.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         syms |= set(re.findall(r"\b(sbi_amd_\w+)\s*\(", text))
