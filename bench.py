@@ -356,7 +356,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["both", "train", "log_prob", "log_prob_broadcast", "sample", "atomic", "mcmc", "fmpe",
-                                      "npe_train"],
+                                      "npe_train", "maf"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch pairs per GPU per step; strong: --batch pairs per step split over the GPUs")
@@ -488,6 +488,48 @@ def main(argv=None):
                 out["cpu_baseline"] = out.pop("_cpu_baseline_fn")()
             out.pop("_cpu_baseline_fn", None)
             print(json.dumps(out))
+        if distributed:
+            dist.destroy_process_group()
+        return
+    if args.mode == "maf":
+        # the maf_rqs sibling flow (MADE masked-linear conditioner, autoregressive RQ
+        # splines) at the configs[1] shape: log_prob, sample for given noise (D conditioner passes per transform) and
+        # the fused training step
+        from sbi_amd.inference.trainers.fused import FusedTrainStep
+        from sbi_amd.neural_nets.net_builders.flow import build_maf_rqs
+
+        torch.manual_seed(1)
+        th0, x0 = make_data(BATCH, "cpu", seed=0)
+        mest = build_maf_rqs(th0, x0).to(device)
+        h = mest.net.hyper
+        H, P_, NBm = h.hidden_features, 3 * h.num_bins - 1, h.num_blocks
+        f_eval = h.num_transforms * 2.0 * (D * H + C * H + NBm * H * H + H * D * P_)   # dense FLOP per eval
+        noise = torch.randn(B, D, device=device)
+
+        def m_lp():
+            with torch.no_grad():
+                mest.log_prob(theta, x)
+
+        wall_lp, dev_lp = timed(m_lp, args.steps, args.warmup, device, dist)
+        wall_s, dev_s = timed(lambda: mest.sample_from_noise(noise, x), max(1, args.steps // 5), 2, device, dist)
+        stepper = FusedTrainStep(mest, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+        wall_t, dev_t = timed(lambda: stepper.step(theta, x, global_batch=GB), args.steps, args.warmup, device, dist)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "maf_rqs train (theta,x)-pairs/sec", "value": GB * args.steps / wall_t, "unit": "pairs/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_t / args.steps * 1e3,
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": f"maf_rqs (sbi defaults: hidden {H}, {h.num_transforms} transforms, {NBm} "
+                                       f"blocks, {h.num_bins} bins, {h.param_count()} parameters), theta-dim {D}, "
+                                       f"x-dim {C}, batch {B} per GPU", "parallelism": f"dp{world}"},
+                "roofline": roofline(3 * f_eval, B, args.steps, dev_t),
+                "log_prob": {"value": GB * args.steps / wall_lp, "unit": "evals/s",
+                             "ms_per_step": wall_lp / args.steps * 1e3,
+                             "roofline": roofline(f_eval, B, args.steps, dev_lp)},
+                "sample_from_noise": {"value": GB * max(1, args.steps // 5) / wall_s, "unit": "draws/s",
+                                      "ms_per_step": wall_s / max(1, args.steps // 5) * 1e3,
+                                      "roofline": roofline(D * f_eval, B, max(1, args.steps // 5), dev_s)}}))
         if distributed:
             dist.destroy_process_group()
         return
