@@ -316,7 +316,7 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
     from sbi_amd.inference.posteriors.vector_field_posterior import VectorFieldPosterior
 
     sample_obj = None
-    if rank == 0 and world == 1:   # single-GPU runs only: keeps the N > 1 scaling runs to the collective legs
+    if rank == 0 and world == 1 and not args.skip_sampling:   # single-GPU runs only
         with torch.no_grad():   # give the output layer non-zero weights so that the field is not constant
             fm.net.flat_params.add_(0.02 * torch.randn_like(fm.net.flat_params))
         post = VectorFieldPosterior(fm, prior=None, device=str(device))
@@ -364,6 +364,7 @@ def main(argv=None):
     ap.add_argument("--draws", type=int, default=1_000_000, help="posterior draws per step in the sample leg")
     ap.add_argument("--npe-epochs", type=int, default=200, help="epochs of the NPE.train() (M2) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-sampling", action="store_true", help="fmpe mode: no ODE-sampling leg (profiling passes)")
     args = ap.parse_args(argv)
 
     if args.gpus < 1:
@@ -504,6 +505,8 @@ def main(argv=None):
         h = mest.net.hyper
         H, P_, NBm = h.hidden_features, 3 * h.num_bins - 1, h.num_blocks
         f_eval = h.num_transforms * 2.0 * (D * H + C * H + NBm * H * H + H * D * P_)   # dense FLOP per eval
+        # inverse: the context layer once, then D passes of [initial + blocks + ONE dim's final-layer rows]
+        f_draw = h.num_transforms * 2.0 * (C * H + D * (D * H + NBm * H * H + H * P_))
         noise = torch.randn(B, D, device=device)
 
         def m_lp():
@@ -529,7 +532,7 @@ def main(argv=None):
                              "roofline": roofline(f_eval, B, args.steps, dev_lp)},
                 "sample_from_noise": {"value": GB * max(1, args.steps // 5) / wall_s, "unit": "draws/s",
                                       "ms_per_step": wall_s / max(1, args.steps // 5) * 1e3,
-                                      "roofline": roofline(D * f_eval, B, max(1, args.steps // 5), dev_s)}}))
+                                      "roofline": roofline(f_draw, B, max(1, args.steps // 5), dev_s)}}))
         if distributed:
             dist.destroy_process_group()
         return

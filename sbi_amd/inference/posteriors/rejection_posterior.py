@@ -32,8 +32,10 @@ class RejectionPosterior:
         if device is None:
             device = getattr(potential_fn, "device", "cpu")
         self._device = process_device(device)
-        self.theta_transform = (torch.distributions.transforms.identity_transform if theta_transform is None
-                                else theta_transform)
+        # keep the constrained <- unconstrained direction and build its inverse on demand: `mcmc_transform` hands out
+        # an `_InverseTransform`, which is tied to its parent by a weak reference that deepcopy / pickling breaks
+        tt = torch.distributions.transforms.identity_transform if theta_transform is None else theta_transform
+        self._to_constrained = tt.inv
         self.proposal = proposal
         self.max_sampling_batch_size = max_sampling_batch_size
         self.num_samples_to_find_max = num_samples_to_find_max
@@ -44,6 +46,11 @@ class RejectionPosterior:
         self._map: Optional[Tensor] = None
         self._purpose = ("It provides rejection sampling to .sample() from the posterior and can evaluate the "
                          "_unnormalized_ posterior density with .log_prob().")
+
+    @property
+    def theta_transform(self):
+        """constrained -> unconstrained (what `mcmc_transform(prior)` returns)"""
+        return torch.distributions.transforms._InverseTransform(self._to_constrained)
 
     # -- x_o handling (base_posterior.py:170-214) ------------------------------------------------------
     @property
@@ -73,7 +80,7 @@ class RejectionPosterior:
         self.potential_fn.to(device)
         if hasattr(self.proposal, "to"):
             self.proposal = self.proposal.to(device) or self.proposal
-        self.theta_transform = mcmc_transform(self.proposal, device=device)
+        self._to_constrained = mcmc_transform(self.proposal, device=device).inv
         if self._x is not None:
             self._x = self._x.to(device)
 

@@ -19,7 +19,7 @@ done
 specs=""
 for mode in log_prob train fmpe; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $out/hbm_${mode}_$c -- python $R/bench.py --mode $mode --steps 3 --warmup 1 --no-cpu-baseline > $out/hbm_${mode}_$c.log 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $out/hbm_${mode}_$c -- python $R/bench.py --mode $mode --steps 3 --warmup 1 --no-cpu-baseline --skip-sampling > $out/hbm_${mode}_$c.log 2>&1
   done
   specs="$specs $mode=$out/hbm_${mode}_FETCH_SIZE,$out/hbm_${mode}_WRITE_SIZE"
 done
