@@ -41,6 +41,13 @@ typedef struct sbi_amd_maf_config {
   float min_bin_width, min_bin_height, min_derivative;   /* flow.py:231-233 */
   int32_t scale_by_sqrt_hidden;   /* 0: nflows' MADE has no `hidden_features` attribute, the spline logits are used
                                      as produced (default); 1: divide width / height logits by sqrt(H) */
+  int32_t variant;    /* 0: nflows maf_rqs (above).  1: zuko NSF (sbi build_zuko_nsf, flow.py:578-640 ->
+                         zuko.flows.NSF): per transform a masked MLP hyper-net on [z ; context]
+                         (Linear(D+C, H), NB x Linear(H, H), Linear(H, D*(3K-1)); ReLU; adjacency masks given by the
+                         caller in `masks`), no context layer, no permutation (`perms` holds each transform's
+                         autoregressive ORDER: arange / reversed), zuko's MonotonicRQSTransform parametrisation
+                         (soft-clipped logits, exp slopes, tail_bound 5); min_* and scale_by_sqrt_hidden unused.
+                         Flat layout: hyper.0 (H, D+C), hyper.2 .. (H, H), last (D*(3K-1), H), each weight then bias */
 } sbi_amd_maf_config;
 
 /* Floats in the flat parameter buffer / in the packed weight image; <0 = SBI_AMD_E_*. */
@@ -51,8 +58,10 @@ int64_t sbi_amd_maf_packed_floats(const sbi_amd_maf_config* cfg);
 int64_t sbi_amd_maf_param_offset(const sbi_amd_maf_config* cfg, int32_t t, int32_t which, int32_t bias);
 
 /* flat params (+ the permutations) -> packed image (masked weights in the MFMA operand layout). */
-int sbi_amd_maf_pack(const sbi_amd_maf_config* cfg, const float* params, const int32_t* perms, float* packed,
-                     void* stream);
+/* `masks`: optional 0/1 floats in the layout of `params` (bias slots ignored); NULL = the MADE degree formulas of
+ * variant 0; required for variant 1. */
+int sbi_amd_maf_pack(const sbi_amd_maf_config* cfg, const float* params, const int32_t* perms, const float* masks,
+                     float* packed, void* stream);
 
 /* Flow.log_prob: logp_out[n] = log p(theta_n | x_{n % x_rows}); noise_out (n, D) optional (transform output).
  * One launch: z-scoring, T x [MADE on MFMA -> RQ spline on all D dims -> permutation], base density. */
@@ -73,7 +82,7 @@ int sbi_amd_maf_sample(const sbi_amd_maf_config* cfg, const float* packed, const
  * split-K MFMA GEMM for the weight gradients, then a fixed-order reduction (deterministic, no atomics). */
 int64_t sbi_amd_maf_train_workspace_floats(const sbi_amd_maf_config* cfg, int64_t n);
 int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const float* packed, const float* zstats,
-                             const float* theta, const float* x, int64_t n, int64_t x_rows,
+                             const float* masks, const float* theta, const float* x, int64_t n, int64_t x_rows,
                              const float* row_weight, float uniform_weight, float* loss_out, float* grad_out,
                              float* grad_theta_out, float* workspace, void* stream);
 

@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 103    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 104    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -44,7 +44,7 @@ class MAFConfigC(Structure):
     _fields_ = [
         ("D", c_int32), ("C", c_int32), ("H", c_int32), ("K", c_int32), ("T", c_int32), ("NB", c_int32),
         ("tail_bound", c_float), ("min_bin_width", c_float), ("min_bin_height", c_float),
-        ("min_derivative", c_float), ("scale_by_sqrt_hidden", c_int32),
+        ("min_derivative", c_float), ("scale_by_sqrt_hidden", c_int32), ("variant", c_int32),
     ]
 
 
@@ -126,7 +126,7 @@ _SIGNATURES = {
     "sbi_amd_maf_param_count": (c_int64, [POINTER(MAFConfigC)]),
     "sbi_amd_maf_packed_floats": (c_int64, [POINTER(MAFConfigC)]),
     "sbi_amd_maf_param_offset": (c_int64, [POINTER(MAFConfigC), c_int32, c_int32, c_int32]),
-    "sbi_amd_maf_pack": (c_int, [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sbi_amd_maf_pack": (c_int, [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sbi_amd_maf_log_prob": (
         c_int,
         [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
@@ -138,8 +138,8 @@ _SIGNATURES = {
     "sbi_amd_maf_train_workspace_floats": (c_int64, [POINTER(MAFConfigC), c_int64]),
     "sbi_amd_maf_loss_fwd_bwd": (
         c_int,
-        [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p],
+        [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_nsf_abi_version": (c_int, []),
     "sbi_amd_nsf_arch": (c_char_p, []),

@@ -36,10 +36,12 @@ static int maf_build_plan(const sbi_amd_maf_config* c, int nw, MafPlan* mp) {
   if (c->D < 1 || c->C < 1 || c->H < 1 || c->T < 1 || c->NB < 0) return SBI_AMD_E_BADARG;
   const int K = c->K;
   if (!(K == 4 || K == 5 || K == 8 || K == 10 || K == 16)) return SBI_AMD_E_UNSUPPORTED;
-  if (c->D > 16 || c->C > MAF_CW || c->H > 16 * NSF_HT || c->T > NSF_MAX_T || c->NB > MAF_MAX_NB)
+  if (c->D > 16 || c->C > 32 || c->H > 16 * NSF_HT || c->T > NSF_MAX_T || c->NB > MAF_MAX_NB)
     return SBI_AMD_E_UNSUPPORTED;
+  if (c->variant != 0 && c->variant != 1) return SBI_AMD_E_UNSUPPORTED;
   if (c->min_bin_width * K > 1.0f || c->min_bin_height * K > 1.0f) return SBI_AMD_E_BADARG;
   memset(mp, 0, sizeof(*mp));
+  mp->variant = c->variant;
   NsfPlan* pl = &mp->n;
   const int D = c->D, C = c->C, H = c->H, NB = c->NB;
   pl->D = D; pl->C = C; pl->H = H; pl->K = K; pl->T = c->T; pl->NB = NB;
@@ -54,13 +56,19 @@ static int maf_build_plan(const sbi_amd_maf_config* c, int nw, MafPlan* mp) {
   pl->one_minus_kw = (float)(1.0 - (double)c->min_bin_width * K);
   pl->one_minus_kh = (float)(1.0 - (double)c->min_bin_height * K);
   pl->d_const = (float)log(exp(1.0 - (double)c->min_derivative) - 1.0);
+  if (c->variant == 1) {   // zuko's MonotonicRQSTransform: plain softmax bins, no logit rescaling
+    pl->min_w = pl->min_h = pl->min_d = 0.f;
+    pl->one_minus_kw = pl->one_minus_kh = 1.f;
+    pl->sqrt_h = pl->inv_sqrt_h = 1.f;
+  }
   pl->log_z = (float)(0.5 * D * log(2.0 * M_PI));
   ShapeDesc* s = &pl->shape[0];
   s->d_id = D; s->d_tr = D; s->in0 = D;
   int g = 0, l = 0;
   const int hb = 16 * NSF_HT, tr_rows = 4 * pl->KSH + 1;
-  m_set_lin(&s->lin[0], &g, &l, H, D, hb, 0, tr_rows);
-  m_set_lin(&s->lin[1], &g, &l, H, C, hb, 0, 0);
+  const int in0 = c->variant == 1 ? D + C : D;   // zuko: the hyper-net's first layer reads [z ; context]
+  m_set_lin(&s->lin[0], &g, &l, H, in0, hb, 0, tr_rows);
+  if (c->variant == 0) m_set_lin(&s->lin[1], &g, &l, H, C, hb, 0, 0);
   for (int b = 0; b < NB; ++b) m_set_lin(&s->lin[2 + b], &g, &l, H, H, hb, pl->KSH, tr_rows);
   s->fin = 2 + NB;
   l = m_round_up(l, 4);
@@ -77,7 +85,7 @@ static int maf_build_plan(const sbi_amd_maf_config* c, int nw, MafPlan* mp) {
   for (int t = 0; t < c->T; ++t) pl->g_layer[t] = t * g;
   // per-wave scratch
   pl->ZW = m_two_odd(D);
-  const int ks0 = m_round_up((D + 3) / 4, 4), ksc = m_round_up((C + 3) / 4, 4);
+  const int ks0 = m_round_up((in0 + 3) / 4, 4), ksc = m_round_up((C + 3) / 4, 4);
   const int need = 4 * ks0 > D + 4 * ksc ? 4 * ks0 : D + 4 * ksc;
   pl->CINW = m_two_odd(need);
   pl->PSW = 16 * pl->PT + 1;
@@ -145,18 +153,20 @@ extern "C" int64_t sbi_amd_maf_param_offset(const sbi_amd_maf_config* cfg, int32
   MafPlan mp;
   const int rc = maf_build_plan(cfg, 1, &mp);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
-  if (t < 0 || t >= mp.n.T || which < 0 || which > mp.n.shape[0].fin) return SBI_AMD_E_BADARG;
+  if (t < 0 || t >= mp.n.T || which < 0 || which > mp.n.shape[0].fin || (mp.variant == 1 && which == 1))
+    return SBI_AMD_E_BADARG;
   const LinDesc& L = mp.n.shape[0].lin[which];
   return (int64_t)t * mp.n_layer + (bias ? L.g_b : L.g_w);
 }
 
 extern "C" int sbi_amd_maf_pack(const sbi_amd_maf_config* cfg, const float* params, const int32_t* perms,
-                                float* packed, void* stream) {
+                                const float* masks, float* packed, void* stream) {
   if (!cfg || !params || !perms || !packed) return SBI_AMD_E_BADARG;
+  if (cfg->variant == 1 && !masks) return SBI_AMD_E_BADARG;   // zuko's adjacency masks come from the host
   MafPlan mp;
   const int rc = maf_build_plan(cfg, 1, &mp);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
-  hipLaunchKernelGGL(maf_pack_kernel, dim3(mp.n.T, 16), dim3(256), 0, (hipStream_t)stream, mp, params, perms, packed);
+  hipLaunchKernelGGL(maf_pack_kernel, dim3(mp.n.T, 16), dim3(256), 0, (hipStream_t)stream, mp, params, perms, masks, packed);
   return (int)hipGetLastError();
 }
 
@@ -229,11 +239,13 @@ __global__ void maf_neg_copy_kernel(const float* __restrict__ in, float* __restr
 }
 
 extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const float* packed, const float* zstats,
-                                        const float* theta, const float* x, int64_t n, int64_t x_rows,
-                                        const float* row_weight, float uniform_weight, float* loss_out,
-                                        float* grad_out, float* grad_theta_out, float* workspace, void* stream) {
+                                        const float* masks, const float* theta, const float* x, int64_t n,
+                                        int64_t x_rows, const float* row_weight, float uniform_weight,
+                                        float* loss_out, float* grad_out, float* grad_theta_out, float* workspace,
+                                        void* stream) {
   if (!cfg || !packed || !zstats || !theta || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
     return SBI_AMD_E_BADARG;
+  if (cfg->variant == 1 && !masks) return SBI_AMD_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   MafPlan mp;
   int nw = 0;
@@ -280,12 +292,14 @@ extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const flo
     // largest first (the final layer has D*(3K-1) outputs)
     set(0, a.GP, mp.DP, a.ACT + 64 * NB, AWS, S.lin[S.fin], mp.n.P, mp.PTW, 3);
     for (int b = 0; b < NB; ++b) set(1 + b, a.G + 64 * (2 + b), GW, a.ACT + 64 * b, AWS, S.lin[2 + b], mp.n.H, 64, 2);
-    set(1 + NB, a.G, GW, a.z_in, D, S.lin[0], mp.n.H, 64, 0);
-    set(2 + NB, a.G + 64, GW, a.CTX, MAF_CW, S.lin[1], mp.n.H, 64, 1);
+    set(1 + NB, a.G, GW, a.CTX, MAF_CW, S.lin[0], mp.n.H, 64, 0);     // inputs: CTX rows = [z ; context]
+    int nlin = 2 + NB;
+    if (mp.variant == 0) { set(2 + NB, a.G + 64, GW, a.CTX + D, MAF_CW, S.lin[1], mp.n.H, 64, 1); nlin = 3 + NB; }
+    d.mask = masks ? masks + (int64_t)t * mp.n_layer : nullptr;
     d.n = n; d.rows_per_chunk = w.rows_per_chunk; d.nchunks = w.nchunks; d.n_layer = mp.n_layer;
     d.D = D; d.P = mp.n.P;
     d.partial = workspace + w.part + (int64_t)t * w.nchunks * mp.n_layer;
-    hipLaunchKernelGGL(maf_dw_kernel, dim3(w.nchunks, 3 + NB), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(maf_dw_kernel, dim3(w.nchunks, nlin), dim3(256), 0, st, d);
     rc = (int)hipGetLastError();
     if (rc) return rc;
   }

@@ -22,7 +22,7 @@
 
 #define MAF_MAX_NB 4
 #define MAF_AW 64          // activation / gradient rows in HBM are 64 floats per layer
-#define MAF_CW 32          // standardized-context rows in HBM
+#define MAF_CW 48          // conditioner-input rows [z ; standardized context] in HBM (D <= 16, C <= 32)
 
 struct MafPlan {
   NsfPlan n;               // dims, spline constants, shape[0] = the MADE's linears:
@@ -32,6 +32,9 @@ struct MafPlan {
   int n_layer;             // parameters per transform
   int sc_zs, sc_us, sc_gy, sc_cin, sc_pst, sc_total;   // per-wave scratch (floats)
   int PTW, DP;             // 16*PT; D*PTW: width of a padded spline-parameter-gradient row
+  int variant;             // 0: nflows maf_rqs (MADE: separate context layer, tanh, degree masks, RandomPermutation)
+                           // 1: zuko NSF (hyper-net on [z ; context], ReLU, adjacency masks from a buffer, fixed
+                           //    autoregressive order instead of a permutation, MonotonicRQSTransform parametrisation)
 };
 
 // hidden / output degrees of nflows' MADE (made.py, random_mask=False)
@@ -56,14 +59,18 @@ __device__ __forceinline__ float tanh_f(float x) {
   return copysignf(r, x);
 }
 
-__device__ __forceinline__ void maf_pack_linear(float* __restrict__ img, const float* __restrict__ gl, const LinDesc& L,
+__device__ __forceinline__ void maf_pack_linear(float* __restrict__ img, const float* __restrict__ gl,
+                                                const float* __restrict__ ml, const LinDesc& L,
                                                 int kind, int D, int P, int bias_pad, int bias_group,
                                                 int bias_group_pad, int tid, int nthreads) {
   const int total = L.rows * L.ldk;
   for (int idx = tid; idx < total; idx += nthreads) {
     const int r = idx / L.ldk, c = idx - r * L.ldk;
     float v = 0.f;
-    if (r < L.out && c < L.in && maf_mask(kind, r, c, D, P)) v = gl[L.g_w + r * L.in + c];
+    if (r < L.out && c < L.in) {
+      const bool keep = ml ? (ml[L.g_w + r * L.in + c] != 0.f) : maf_mask(kind, r, c, D, P);
+      if (keep) v = gl[L.g_w + r * L.in + c];
+    }
     img[L.l_w + idx] = v;
   }
   for (int idx = tid; idx < bias_pad; idx += nthreads) {
@@ -76,18 +83,19 @@ __device__ __forceinline__ void maf_pack_linear(float* __restrict__ img, const f
 #ifdef MAF_MAIN_TU   // non-template kernels: defined by maf.hip only
 __global__ void __launch_bounds__(256)
 maf_pack_kernel(const MafPlan mp, const float* __restrict__ params, const int* __restrict__ perms,
-                float* __restrict__ packed) {
+                const float* __restrict__ masks, float* __restrict__ packed) {
   const NsfPlan& pl = mp.n;
   const ShapeDesc& S = pl.shape[0];
   const int t = blockIdx.x;
   float* img = packed + (long long)t * pl.img_floats;
   const float* gl = params + (long long)t * mp.n_layer;
+  const float* ml = masks ? masks + (long long)t * mp.n_layer : nullptr;
   const int tid = blockIdx.y * blockDim.x + threadIdx.x, nthreads = gridDim.y * blockDim.x;
   const int hb = 16 * NSF_HT;
-  maf_pack_linear(img, gl, S.lin[0], 0, pl.D, pl.P, hb, hb, hb, tid, nthreads);
-  maf_pack_linear(img, gl, S.lin[1], 1, pl.D, pl.P, hb, hb, hb, tid, nthreads);
-  for (int b = 0; b < pl.NB; ++b) maf_pack_linear(img, gl, S.lin[2 + b], 2, pl.D, pl.P, hb, hb, hb, tid, nthreads);
-  maf_pack_linear(img, gl, S.lin[S.fin], 3, pl.D, pl.P, pl.D * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
+  maf_pack_linear(img, gl, ml, S.lin[0], 0, pl.D, pl.P, hb, hb, hb, tid, nthreads);
+  if (mp.variant == 0) maf_pack_linear(img, gl, ml, S.lin[1], 1, pl.D, pl.P, hb, hb, hb, tid, nthreads);
+  for (int b = 0; b < pl.NB; ++b) maf_pack_linear(img, gl, ml, S.lin[2 + b], 2, pl.D, pl.P, hb, hb, hb, tid, nthreads);
+  maf_pack_linear(img, gl, ml, S.lin[S.fin], 3, pl.D, pl.P, pl.D * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
   for (int d = tid; d < pl.D; d += nthreads) {
     const int p = perms[t * pl.D + d];
     img[mp.l_perm + d] = __int_as_float(p);
@@ -100,17 +108,23 @@ maf_pack_kernel(const MafPlan mp, const float* __restrict__ params, const int* _
 
 // MADE hidden stack: h = tanh(W0m z + b0 + gate), then NB x h = tanh(Wb h + bb); gate = tanh(Wc c + bc) is
 // computed once per transform by the caller.  `hs` (optional) receives the activation after every layer.
-template <int KSH>
+template <int VAR>
+__device__ __forceinline__ float maf_act(float x) { return VAR == 0 ? tanh_f(x) : fmaxf(x, 0.f); }
+// derivative of the activation expressed through its OUTPUT h
+template <int VAR>
+__device__ __forceinline__ float maf_act_grad(float h) { return VAR == 0 ? 1.f - h * h : (h > 0.f ? 1.f : 0.f); }
+
+template <int KSH, int VAR>
 __device__ __forceinline__ void made_hidden(const float* __restrict__ lds, const NsfPlan& pl, const ShapeDesc& S,
                                             const LaneId& id, const float* __restrict__ cin_row,
                                             const f4 (&gate)[NSF_HT], f4 (&h)[NSF_HT],
                                             f4 (*hs)[NSF_HT] = nullptr) {
   acc_init_bias(lds, S.lin[0], id, h);
-  gemm_blds(lds, S.lin[0], id, cin_row, h);
+  gemm_blds(lds, S.lin[0], id, cin_row, h);   // VAR 1: the layer's input is [z ; context] (one masked linear)
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[mt][r] = tanh_f(h[mt][r] + gate[mt][r]);
+    for (int r = 0; r < 4; ++r) h[mt][r] = maf_act<VAR>(VAR == 0 ? h[mt][r] + gate[mt][r] : h[mt][r]);
   if (hs) {
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt) hs[0][mt] = h[mt];
@@ -125,7 +139,7 @@ __device__ __forceinline__ void made_hidden(const float* __restrict__ lds, const
 #pragma unroll
       for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[mt][r] = tanh_f(u[mt][r]);
+        for (int r = 0; r < 4; ++r) h[mt][r] = maf_act<VAR>(u[mt][r]);
       if (hs) {
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) hs[b + 1][mt] = h[mt];
@@ -163,7 +177,7 @@ __device__ __forceinline__ void permute_rows(float* __restrict__ zs, int ZW, int
   wave_lds_fence();
 }
 
-template <int K, int KSH, bool INV>
+template <int K, int KSH, bool INV, int VAR>
 __global__ void __launch_bounds__(512)
 maf_flow_kernel(const MafPlan mp, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
@@ -216,11 +230,11 @@ maf_flow_kernel(const MafPlan mp, const float* __restrict__ packed, const float*
         if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
     }
     f4 gate[NSF_HT], h[NSF_HT];
-    made_gate<KSH>(lds, S, id, cin_row + D, gate);
+    if (VAR == 0) made_gate<KSH>(lds, S, id, cin_row + D, gate);
     if (!INV) {
       for (int k = id.g; k < D; k += 4) cin[id.j * pl.CINW + k] = zs[id.j * pl.ZW + k];
       wave_lds_fence();
-      made_hidden<KSH>(lds, pl, S, id, cin_row, gate, h);
+      made_hidden<KSH, VAR>(lds, pl, S, id, cin_row, gate, h);
       // all D dims are transformed, parameters from the ORIGINAL inputs (already folded into h)
       const int nchunks = (D + 1) / 2;
       for (int c = 0; c < nchunks; ++c) {
@@ -233,25 +247,28 @@ maf_flow_kernel(const MafPlan mp, const float* __restrict__ packed, const float*
         const int dd = 2 * c + sl;
         const int zi = id.j * pl.ZW + dd;
         float y, ld;
-        rq_spline_pair<K, false>(pst + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part, y, ld);
+        rq_spline_pair<K, false, NoYield, VAR>(pst + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part, y, ld);
         zs[zi] = y;   // idle lanes recompute slot 0's task and store the same value
         ld_acc += (live && part == 0) ? ld : 0.f;
         wave_lds_fence();
       }
-      permute_rows(zs, pl.ZW, D, lds + mp.l_perm, id);
+      if (VAR == 0) permute_rows(zs, pl.ZW, D, lds + mp.l_perm, id);
     } else {
-      permute_rows(zs, pl.ZW, D, lds + mp.l_iperm, id);   // inverse of the permutation that FOLLOWS the transform
+      // inverse of the permutation that FOLLOWS the transform (zuko: none, the order lives in the masks)
+      if (VAR == 0) permute_rows(zs, pl.ZW, D, lds + mp.l_iperm, id);
       for (int k = id.g; k < D; k += 4) cin[id.j * pl.CINW + k] = 0.f;
       wave_lds_fence();
       // autoregressive inverse (autoregressive.py: D passes from zeros): pass i sees the exact outputs of the
       // dims < i, which is all dim i depends on, so only dim i's parameters and spline are evaluated
-      for (int i = 0; i < D; ++i) {
-        made_hidden<KSH>(lds, pl, S, id, cin_row, gate, h);
+      for (int pass = 0; pass < D; ++pass) {
+        // maf_rqs: natural order (degrees 1..D); zuko: the feature whose autoregressive order is `pass`
+        const int i = VAR == 0 ? pass : __float_as_int(lds[mp.l_iperm + pass]);
+        made_hidden<KSH, VAR>(lds, pl, S, id, cin_row, gate, h);
         final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, i);
         wave_lds_fence();
         const int part = id.g >> 1;
         float y, ld;
-        rq_spline_pair<K, true>(pst + id.j * pl.PSW, zs[id.j * pl.ZW + i], pl, part, y, ld);
+        rq_spline_pair<K, true, NoYield, VAR>(pst + id.j * pl.PSW, zs[id.j * pl.ZW + i], pl, part, y, ld);
         cin[id.j * pl.CINW + i] = y;
         us[id.j * pl.ZW + i] = y;
         ld_acc += (id.g == 0) ? ld : 0.f;
@@ -302,7 +319,7 @@ struct MafBwdArgs {
   float* GP;               // (n, DP)  gradient wrt the raw spline parameters, rows padded to 16*PT per dim
   float* ACT;              // (n, (NB+1)*64) h_0 .. h_NB
   float* G;                // (n, (NB+2)*64) slot 0: d/d(a1), slot 1: d/d(context pre-activation), 2+b: block b
-  float* CTX;              // (n, 32) standardized context
+  float* CTX;              // (n, MAF_CW) conditioner input rows [z ; standardized context]
   int t, is_last;
 };
 
@@ -345,7 +362,7 @@ __device__ __forceinline__ void store_frag_rows(float* __restrict__ dst, int ld,
     for (int r = 0; r < 4; ++r) dst[row * ld + 16 * mt + 4 * r + id.g] = v[mt][r];
 }
 
-template <int K, int KSH>
+template <int K, int KSH, int VAR>
 __global__ void __launch_bounds__(256)
 maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
   constexpr int PT = (3 * K - 1 + 15) / 16;
@@ -379,23 +396,24 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
       const float z = valid ? a.z_in[rs * D + d] : 0.f;
       zs[id.j * pl.ZW + d] = z;
       cin[id.j * pl.CINW + d] = z;
+      if (valid) a.CTX[row * MAF_CW + d] = z;
       // undo the permutation on the way back: out[d] = in[perm[d]]  =>  g_in[k] = g_out[iperm[k]]
-      const int src = __float_as_int(lds[mp.l_iperm + d]);
+      const int src = VAR == 0 ? __float_as_int(lds[mp.l_iperm + d]) : d;
       const float g = valid ? a.gz_up[rs * D + src] : 0.f;
       gys[id.j * pl.ZW + d] = a.is_last ? wn * g : g;
     }
     for (int c = id.g; c < C; c += 4) {
       const float v = ((valid ? a.x[xr * C + c] : 0.f) - x_mean[c]) / x_std[c];
       cin[id.j * pl.CINW + D + c] = v;
-      if (valid) a.CTX[row * MAF_CW + c] = v;
+      if (valid) a.CTX[row * MAF_CW + D + c] = v;
     }
   }
   wave_lds_fence();
   const float* cin_row = cin + id.j * pl.CINW + id.g;
   // ---- recompute the conditioner (activations stay in registers)
   f4 gate[NSF_HT], h[NSF_HT], hs[MAF_MAX_NB + 1][NSF_HT];
-  made_gate<KSH>(lds, S, id, cin_row + D, gate);
-  made_hidden<KSH>(lds, pl, S, id, cin_row, gate, h, hs);
+  if (VAR == 0) made_gate<KSH>(lds, S, id, cin_row + D, gate);
+  made_hidden<KSH, VAR>(lds, pl, S, id, cin_row, gate, h, hs);
 #pragma unroll
   for (int b = 0; b <= MAF_MAX_NB; ++b)
     if (b <= NB) store_frag_rows(a.ACT + 64 * b, (MAF_MAX_NB + 1) * MAF_AW, row, valid, id, hs[b]);
@@ -416,7 +434,7 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
       float* pp = pst + slot * pl.DS + id.j * pl.PSW;
       const int zi = id.j * pl.ZW + dd;
       float yv, gxv;
-      rq_spline_pair_bwd<K>(pp, mp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);
+      rq_spline_pair_bwd<K, VAR>(pp, mp.PTW, zs[zi], gys[zi], gld, pl, part, yv, gxv);
       if (part == 0) gxs[zi] = gxv;
     }
     wave_lds_fence();
@@ -438,7 +456,7 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float hv = hs[b + 1][mt][r];
-          gb[mt][r] = gh[mt][r] * (1.f - hv * hv);
+          gb[mt][r] = gh[mt][r] * maf_act_grad<VAR>(hv);
           gh[mt][r] = 0.f;
         }
       store_frag_rows(a.G + 64 * (2 + b), GW, row, valid, id, gb);
@@ -451,12 +469,15 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float hv = hs[0][mt][r], gt = gate[mt][r];
-        g0[mt][r] = gh[mt][r] * (1.f - hv * hv);          // d / d(W0 z + b0 + gate)
-        gc[mt][r] = g0[mt][r] * (1.f - gt * gt);          // d / d(Wc c + bc)
+        const float hv = hs[0][mt][r];
+        g0[mt][r] = gh[mt][r] * maf_act_grad<VAR>(hv);    // d / d(W0 z + b0 + gate)
+        if (VAR == 0) {
+          const float gt = gate[mt][r];
+          gc[mt][r] = g0[mt][r] * (1.f - gt * gt);        // d / d(Wc c + bc)
+        }
       }
     store_frag_rows(a.G, GW, row, valid, id, g0);
-    store_frag_rows(a.G + 64, GW, row, valid, id, gc);
+    if (VAR == 0) store_frag_rows(a.G + 64, GW, row, valid, id, gc);
     gin[0] = {0.f, 0.f, 0.f, 0.f};
     gemm_T_breg<KSH, 1>(lds, S.lin[0], id, g0, gin);     // through the (masked) initial layer: dims < their own
 #pragma unroll
@@ -479,13 +500,14 @@ struct MafLin {
   int out, in;      // natural dims
   int group, group_pad;   // output o lives at column (o / group) * group_pad + o % group  (final layer: P -> 16*PT)
   int g_w, g_b;     // offsets inside the transform's parameter block
-  int kind;         // mask kind (maf_mask)
+  int kind;         // mask kind (maf_mask) when no mask buffer is given
 };
 struct MafDwArgs {
   MafLin lin[3 + MAF_MAX_NB];
   long long n;
   int rows_per_chunk, nchunks, n_layer, D, P;
   float* partial;   // (nchunks, n_layer) for this transform
+  const float* mask;   // optional (n_layer) 0/1 mask of this transform's parameter block (zuko adjacency masks)
 };
 
 #ifdef MAF_MAIN_TU
@@ -535,7 +557,8 @@ maf_dw_kernel(const MafDwArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
           const int i = 16 * nt + j;
           if (nt < ntiles && i < L.in)
-            part[L.g_w + o * L.in + i] = maf_mask(L.kind, o, i, a.D, a.P) ? acc[nt][r] : 0.f;
+            part[L.g_w + o * L.in + i] =
+                (a.mask ? a.mask[L.g_w + o * L.in + i] != 0.f : maf_mask(L.kind, o, i, a.D, a.P)) ? acc[nt][r] : 0.f;
         }
         if (j == 0) part[L.g_b + o] = accb[r];
       }
@@ -564,12 +587,12 @@ maf_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad, i
 #endif
 
 // ------------------------------------------------------------------ per-K launchers (instantiated per TU)
-template <int K, int KSH, bool INV>
+template <int K, int KSH, bool INV, int VAR>
 static int maf_launch_flow(const MafPlan& mp, int nw, const float* packed, const float* zstats, const float* in,
                            const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                            float* z_stash, hipStream_t st) {
   const int lds_bytes = 4 * (mp.n.lds_w_floats + nw * mp.sc_total);
-  auto kern = maf_flow_kernel<K, KSH, INV>;
+  auto kern = maf_flow_kernel<K, KSH, INV, VAR>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t grid = (n + 16 * nw - 1) / (16 * nw);
@@ -578,10 +601,10 @@ static int maf_launch_flow(const MafPlan& mp, int nw, const float* packed, const
   return (int)hipGetLastError();
 }
 
-template <int K, int KSH>
+template <int K, int KSH, int VAR>
 static int maf_launch_bwd(const MafPlan& mp, int nw, const MafBwdArgs& a, hipStream_t st) {
   const int lds_bytes = 4 * (mp.n.lds_w_floats + nw * mp.sc_total);
-  auto kern = maf_bwd_kernel<K, KSH>;
+  auto kern = maf_bwd_kernel<K, KSH, VAR>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t grid = (a.n + 16 * nw - 1) / (16 * nw);
@@ -590,16 +613,23 @@ static int maf_launch_bwd(const MafPlan& mp, int nw, const MafBwdArgs& a, hipStr
 }
 
 // mode 0: log_prob (+ stash), 1: inverse, 2: backward of one transform
+template <int K, int KSH, int VAR>
+static int maf_dispatch_kv(const MafPlan& mp, int nw, int mode, const float* packed, const float* zstats,
+                           const float* in, const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
+                           float* z_stash, const MafBwdArgs* bwd, hipStream_t st) {
+  if (mode == 0)
+    return maf_launch_flow<K, KSH, false, VAR>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+  if (mode == 1)
+    return maf_launch_flow<K, KSH, true, VAR>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
+  return maf_launch_bwd<K, KSH, VAR>(mp, nw, *bwd, st);
+}
+
 template <int K>
 int maf_dispatch_k(const MafPlan& mp, int nw, int mode, const float* packed, const float* zstats, const float* in,
                    const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux, float* z_stash,
                    const MafBwdArgs* bwd, hipStream_t st) {
-  const bool k13 = mp.n.KSH == 13;
-  if (mode == 0)
-    return k13 ? maf_launch_flow<K, 13, false>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st)
-               : maf_launch_flow<K, 16, false>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-  if (mode == 1)
-    return k13 ? maf_launch_flow<K, 13, true>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st)
-               : maf_launch_flow<K, 16, true>(mp, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, st);
-  return k13 ? maf_launch_bwd<K, 13>(mp, nw, *bwd, st) : maf_launch_bwd<K, 16>(mp, nw, *bwd, st);
+#define MAF_KV(KS, V) maf_dispatch_kv<K, KS, V>(mp, nw, mode, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, bwd, st)
+  if (mp.n.KSH == 13) return mp.variant ? MAF_KV(13, 1) : MAF_KV(13, 0);
+  return mp.variant ? MAF_KV(16, 1) : MAF_KV(16, 0);
+#undef MAF_KV
 }

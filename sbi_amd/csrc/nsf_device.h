@@ -480,14 +480,33 @@ struct NoYield {
   __device__ __forceinline__ void operator()(int) {}
 };
 
-template <int K, class Y = NoYield>
+// Spline parametrisation variants (VAR): 0 = nflows (rational_quadratic.py: softmax with minimum bin size,
+// softplus + min_derivative knot slopes, logits optionally / sqrt(hidden), bins closed on the left, last knot
+// bumped by 1e-6); 1 = zuko's MonotonicRQSTransform (transforms.py: logits soft-clipped by w / (1 + |2 w / ln slope|),
+// slopes exp(d / (1 + |d / ln slope|)), plain softmax, bins closed on the right, identity outside (-B, B]).
+// The rational-quadratic map, its inverse and its log-derivative are the same function of (knots, slopes).
+#define ZUKO_CW 0.28952965460216784f   /* 2 / |ln 1e-3| */
+#define ZUKO_CD 0.14476482730108392f   /* 1 / |ln 1e-3| */
+template <int VAR>
+__device__ __forceinline__ float spline_logit(float q, const NsfPlan& pl) {
+  return VAR == 0 ? q * pl.inv_sqrt_h : q * rcp_f(1.f + fabsf(q) * ZUKO_CW);
+}
+// d logit' / d logit
+template <int VAR>
+__device__ __forceinline__ float spline_logit_grad(float q, const NsfPlan& pl) {
+  if (VAR == 0) return pl.inv_sqrt_h;
+  const float r = rcp_f(1.f + fabsf(q) * ZUKO_CW);
+  return r * r;
+}
+
+template <int K, class Y = NoYield, int VAR = 0>
 __device__ __forceinline__ void spline_side(const float* __restrict__ q, const NsfPlan& pl, int part,
                                             SplineSide<K>& S, Y&& y = Y()) {
   const float B = pl.B;
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    S.e[k] = q[k] * pl.inv_sqrt_h;   // `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
+    S.e[k] = spline_logit<VAR>(q[k], pl);   // nflows: `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
     m = fmaxf(m, S.e[k]);
     y(k);
   }
@@ -510,7 +529,7 @@ __device__ __forceinline__ void spline_side(const float* __restrict__ q, const N
     S.c[k + 1] = (2.f * B) * cum + (-B);
     y(2 * K + k);
   }
-  S.c[K] = B;
+  if (VAR == 0) S.c[K] = B;   // nflows overwrites the end knots; zuko keeps B (2 cumsum - 1)
 }
 
 struct SplineSel {   // per-task scalars both lanes hold after the exchange
@@ -519,21 +538,29 @@ struct SplineSel {   // per-task scalars both lanes hold after the exchange
   float cw_i, cw_n, ch_i, ch_n, d_i, d_n, ud_mine;
 };
 
-template <int K, bool INV, class Y = NoYield>
+template <int K, bool INV, class Y = NoYield, int VAR = 0>
 __device__ __forceinline__ void spline_select(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
                                               const SplineSide<K>& S, SplineSel& o, Y&& y = Y()) {
   const float B = pl.B;
-  o.inside = (x >= -B) && (x <= B);
   // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6; done by the
-  // side that owns the searched knots (widths forward, heights inverse)
+  // side that owns the searched knots (widths forward, heights inverse).
+  // zuko: torch.searchsorted(knots, x) - 1 = #(knots < x) - 1, transformed iff 0 <= bin < K.
   int cnt = 0;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    cnt += (x >= S.c[k]) ? 1 : 0;
+    cnt += (VAR == 0 ? (x >= S.c[k]) : (x > S.c[k])) ? 1 : 0;
     y(3 * K + k);
   }
-  cnt += (x >= (S.c[K] + 1e-6f)) ? 1 : 0;
+  cnt += (VAR == 0 ? (x >= (S.c[K] + 1e-6f)) : (x > S.c[K])) ? 1 : 0;
   int idx = cnt - 1;
+  if (VAR == 0) {
+    o.inside = (x >= -B) && (x <= B);
+  } else {
+    // the side that searched decides (both sides see the same x but own different knots)
+    const int in_mine = (idx >= 0 && idx <= K - 1) ? 1 : 0;
+    const int in_oth = xchg32i(in_mine);
+    o.inside = ((part == (INV ? 1 : 0)) ? in_mine : in_oth) != 0;
+  }
   idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
   const int idx_o = xchg32i(idx);
   idx = (part == (INV ? 1 : 0)) ? idx : idx_o;
@@ -555,9 +582,10 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
   const int kd = idx + part;
   const int kc = kd - 1 < 0 ? 0 : (kd - 1 > K - 2 ? K - 2 : kd - 1);   // always a valid slot: no branch
   const float ud_ld = p[2 * K + kc];
-  o.ud_mine = (kd == 0 || kd == K) ? pl.d_const : ud_ld;
+  o.ud_mine = (kd == 0 || kd == K) ? (VAR == 0 ? pl.d_const : 0.f) : ud_ld;
   y(5 * K - 1);
-  const float d_mine = pl.min_d + softplus_bf(o.ud_mine);
+  const float d_mine = VAR == 0 ? pl.min_d + softplus_bf(o.ud_mine)
+                                : exp_f(o.ud_mine * rcp_f(1.f + fabsf(o.ud_mine) * ZUKO_CD));   // boundary: exp(0) = 1
   y(5 * K);
   const float d_oth = xchg32(d_mine);
   o.d_i = part ? d_oth : d_mine;
@@ -566,13 +594,13 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
 
 // forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
 // receive y and ld.
-template <int K, bool INV, class Y = NoYield>
+template <int K, bool INV, class Y = NoYield, int VAR = 0>
 __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
                                                float& y, float& ld, Y&& yield = Y()) {
   SplineSide<K> S;
-  spline_side<K>(p + part * K, pl, part, S, yield);
+  spline_side<K, Y, VAR>(p + part * K, pl, part, S, static_cast<Y&&>(yield));
   SplineSel o;
-  spline_select<K, INV>(p, x, pl, part, S, o, yield);
+  spline_select<K, INV, Y, VAR>(p, x, pl, part, S, o, static_cast<Y&&>(yield));
   const float w_i = o.cw_n - o.cw_i;
   const float h_i = o.ch_n - o.ch_i;
   const float rw_i = rcp_f(w_i);

@@ -66,12 +66,13 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   tp->SA = TR_SA;
   tp->SB = TR_SB;
   {   // Bs row = [z_id ; context ; 1 ; 0...]: d W0 reads columns [0, 16 nt0), d Wc columns [d_id, d_id + 16 ntc).
-      // Stride = 8 (mod 16) keeps the four g groups of a read on (mostly) different banks.
     const int in0max = d_id_max + pl.C;
     const int nt0 = (in0max + 1 + 15) / 16, ntc = (pl.C + 1 + 15) / 16;
     int need = 16 * nt0 > d_id_max + 16 * ntc ? 16 * nt0 : d_id_max + 16 * ntc;
-    tp->SS = (need + 7) / 8 * 8;
-    if (tp->SS % 16 == 0) tp->SS += 8;
+    // 4 * odd: the row waves' row-major writes (row j, column g) and the grad waves' reads of rows krow + 4 g
+    // (4 * SS = 16 * odd mod 64) are both bank-conflict free
+    tp->SS = (need + 3) / 4 * 4;
+    if ((tp->SS / 4) % 2 == 0) tp->SS += 4;
   }
   int w = 0;
   tp->w_zs = w; w += 16 * pl.ZW;
@@ -134,6 +135,9 @@ __device__ __forceinline__ void stage_DB(float* __restrict__ st, int SB, int row
   }
 }
 
+// tile row of k-slot 0 in K-step s of the weight-gradient GEMMs (k-slot g adds 4 g): 0,1,2,3,16,17,18,19,32,...
+__device__ __forceinline__ constexpr int dw_krow(int s) { return 16 * (s >> 2) + (s & 3); }
+
 // weight-gradient tile(s): acc[nt] += sum_{rows of the 64-row tile} A[row][acol0+i] * B[row][bcol0+16nt+j]
 // Strides are compile time (every LDS read is base + immediate) and the operands of K-step s+2 are
 // requested before the MFMAs of step s issue, so the LDS latency hides under the matrix pipe.
@@ -143,29 +147,32 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
                                         int abl = 0) {
   if (abl & 1) return;
   constexpr int KS = TR_ROWS / 4, LA = TR_LA;
-  const float* ap = Ast + id.g * SA + acol0 + id.j;
+  // K-step s covers tile rows krow(s) + 4 g (not 4 s + g): with the gradient tiles' row stride 68 (= 4 mod 64,
+  // what keeps the ROW waves' accesses conflict-free) the four k-slots of an A read then sit 16 banks apart
+  // (4 * 68 = 16 mod 64) instead of 4, so the read is conflict-free as well (it was a 4-way conflict).
+  const float* ap = Ast + 4 * id.g * SA + acol0 + id.j;
   // interleaved B (bcol0 a multiple of 16): the NT operands of this lane are adjacent floats
-  const float* bp = IL ? Bst + id.g * SB + 4 * id.j + (bcol0 >> 4) : Bst + id.g * SB + bcol0 + id.j;
+  const float* bp = IL ? Bst + 4 * id.g * SB + 4 * id.j + (bcol0 >> 4) : Bst + 4 * id.g * SB + bcol0 + id.j;
   float a[LA + 1], b[LA + 1][NT];
   auto load_b = [&](int u, int s) {
     if (IL && NT == 4) {
-      const f4 w = *(const f4*)(bp + 4 * s * SB);
+      const f4 w = *(const f4*)(bp + dw_krow(s) * SB);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) b[u][nt] = w[nt];
     } else {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[u][nt] = bp[4 * s * SB + (IL ? nt : 16 * nt)];
+      for (int nt = 0; nt < NT; ++nt) b[u][nt] = bp[dw_krow(s) * SB + (IL ? nt : 16 * nt)];
     }
   };
 #pragma unroll
   for (int u = 0; u < LA; ++u) {
-    a[u] = ap[4 * u * SA];
+    a[u] = ap[dw_krow(u) * SA];
     load_b(u, u);
   }
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (s + LA < KS) {
-      a[(s + LA) % (LA + 1)] = ap[4 * (s + LA) * SA];
+      a[(s + LA) % (LA + 1)] = ap[dw_krow(s + LA) * SA];
       load_b((s + LA) % (LA + 1), s + LA);
     }
     // pin the order: hipcc otherwise sinks every load next to its MFMA (load, wait, 2 MFMAs, load, ...)
@@ -184,21 +191,21 @@ __device__ __forceinline__ void dw_gemm_rs(const float* __restrict__ Ast, const 
                                            int abl = 0) {
   if (abl & 1) return;
   constexpr int KS = TR_ROWS / 4, LA = TR_LA;
-  const float* ap = Ast + id.g * SA + acol0 + id.j;
-  const float* bp = Bst + id.g * SBr + bcol0 + id.j;
+  const float* ap = Ast + 4 * id.g * SA + acol0 + id.j;     // rows krow(s) + 4 g, see dw_gemm
+  const float* bp = Bst + 4 * id.g * SBr + bcol0 + id.j;
   float a[LA + 1], b[LA + 1][NT];
 #pragma unroll
   for (int u = 0; u < LA; ++u) {
-    a[u] = ap[4 * u * SA];
+    a[u] = ap[dw_krow(u) * SA];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[u][nt] = bp[4 * u * SBr + 16 * nt];
+    for (int nt = 0; nt < NT; ++nt) b[u][nt] = bp[dw_krow(u) * SBr + 16 * nt];
   }
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (s + LA < KS) {
-      a[(s + LA) % (LA + 1)] = ap[4 * (s + LA) * SA];
+      a[(s + LA) % (LA + 1)] = ap[dw_krow(s + LA) * SA];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[(s + LA) % (LA + 1)][nt] = bp[4 * (s + LA) * SBr + 16 * nt];
+      for (int nt = 0; nt < NT; ++nt) b[(s + LA) % (LA + 1)][nt] = bp[dw_krow(s + LA) * SBr + 16 * nt];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -380,14 +387,14 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
 // d(gy*y + gl*logabsdet)/d(raw outputs) on exit (entries [3K-1, plen) zeroed): part 0 writes the
 // width logits and all derivative slots but one, part 1 the height logits, its own derivative
 // slot and the padding.  Formulas: DESIGN.md "spline backward".
-template <int K>
+template <int K, int VAR = 0>
 __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int plen, float x, float gy, float gl,
                                                    const NsfPlan& pl, int part, float& y, float& gx) {
   const float B = pl.B;
   SplineSide<K> S;
-  spline_side<K>(p + part * K, pl, part, S);
+  spline_side<K, NoYield, VAR>(p + part * K, pl, part, S);
   SplineSel o;
-  spline_select<K, false>(p, x, pl, part, S, o);
+  spline_select<K, false, NoYield, VAR>(p, x, pl, part, S, o);
   const bool inside = o.inside;
   const int idx = o.idx;
   const float d_i = o.d_i, d_n = o.d_n;
@@ -458,10 +465,17 @@ __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int pl
   }
   float* q_out = p + part * K;
 #pragma unroll
-  for (int m = 0; m < K; ++m) q_out[m] = S.e[m] * (gsm[m] - dot) * pl.inv_sqrt_h;
+  for (int m = 0; m < K; ++m) q_out[m] = S.e[m] * (gsm[m] - dot) * spline_logit_grad<VAR>(q_out[m], pl);
   // ---- derivative slots: knot kd = idx + part is mine (interior knots only)
   const int kd = idx + part;
-  const float gud = (inside && kd >= 1 && kd <= K - 1) ? (part ? gdn : gdi) * sigmoid_f(o.ud_mine) : 0.f;
+  float dact;   // d slope / d raw parameter
+  if (VAR == 0) {
+    dact = sigmoid_f(o.ud_mine);
+  } else {
+    const float r = rcp_f(1.f + fabsf(o.ud_mine) * ZUKO_CD);
+    dact = (part ? d_n : d_i) * r * r;       // slope = exp(clip(u)): slope * clip'(u)
+  }
+  const float gud = (inside && kd >= 1 && kd <= K - 1) ? (part ? gdn : gdi) * dact : 0.f;
   if (part == 0) {
 #pragma unroll
     for (int k = 0; k < K - 1; ++k)

@@ -32,7 +32,7 @@ from torch.distributions import Distribution
 from sbi_amd.neural_nets.estimators.base import ConditionalDensityEstimator
 from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow
 from sbi_amd.neural_nets.factory import posterior_nn
-from sbi_amd.neural_nets.net_builders.estimator_configs import NSFConfig
+from sbi_amd.neural_nets.net_builders.estimator_configs import NSFConfig, ZukoNSFConfig
 from sbi_amd.utils.sbiutils import handle_invalid_x, warn_on_invalid_x
 from sbi_amd.utils.torchutils import check_if_prior_on_device, process_device
 
@@ -73,7 +73,7 @@ def check_estimator_arg(estimator) -> None:
         )
     if isinstance(estimator, type):
         raise TypeError("Pass a config *instance* (e.g. NSFConfig()), not the config class.")
-    if not (isinstance(estimator, (str, NSFConfig)) or callable(estimator)):
+    if not (isinstance(estimator, (str, NSFConfig, ZukoNSFConfig)) or callable(estimator)):
         raise TypeError(f"Unsupported density_estimator argument of type {type(estimator).__name__}")
 
 
@@ -128,7 +128,7 @@ class PosteriorEstimatorTrainer:
                 "`from sbi_amd.neural_nets import NSFConfig`.", FutureWarning, stacklevel=3,
             )
             self._build_neural_net = posterior_nn(model=density_estimator)
-        elif isinstance(density_estimator, NSFConfig):
+        elif isinstance(density_estimator, (NSFConfig, ZukoNSFConfig)):
             self._build_neural_net = density_estimator.build
         else:
             self._build_neural_net = density_estimator

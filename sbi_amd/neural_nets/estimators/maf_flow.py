@@ -46,7 +46,7 @@ class MAFHyper:
     def c_config(self) -> _lib.MAFConfigC:
         return _lib.MAFConfigC(self.D, self.C, self.hidden_features, self.num_bins, self.num_transforms,
                                self.num_blocks, self.tail_bound, self.min_bin_width, self.min_bin_height,
-                               self.min_derivative, int(self.scale_by_sqrt_hidden))
+                               self.min_derivative, int(self.scale_by_sqrt_hidden), 0)
 
     def layer_entries(self) -> List[Tuple[str, Tuple[int, ...], int]]:
         """(nflows sub-key, shape, mask kind) in flat order for one transform (kinds as csrc/maf_kernel.h maf_mask)."""
@@ -167,6 +167,10 @@ class MAFNet(nn.Module):
             self.zstats[2 * h.D + h.C :].copy_(sd[prefix + "_embedding_net.0._std"].reshape(-1).expand(h.C))
         self.__dict__.pop("_packed_cache", None)
 
+    def kernel_masks(self) -> Optional[Tensor]:
+        """Mask buffer handed to the kernels (None: the MADE degree formulas are evaluated on the device)."""
+        return None
+
     # -- fused training pass -----------------------------------------------------------------------
     def train_workspace_floats(self, n: int) -> int:
         need = _lib.load().sbi_amd_maf_train_workspace_floats(self.hyper.c_config(), n)
@@ -199,7 +203,8 @@ def maf_packed_weights(net: MAFNet) -> Tensor:
         torch.zeros(int(n), dtype=torch.float32, device=dev)
     perms = net.perms.contiguous()
     with torch.cuda.device(dev):
-        rc = lib.sbi_amd_maf_pack(cfg, _lib.ptr(fp), perms.data_ptr(), _lib.ptr(packed), _lib.current_stream(dev))
+        rc = lib.sbi_amd_maf_pack(cfg, _lib.ptr(fp), perms.data_ptr(), _lib.ptr(net.kernel_masks()), _lib.ptr(packed),
+                                  _lib.current_stream(dev))
     _lib.check(rc, "maf_pack")
     net.__dict__["_packed_cache"] = (key, packed)
     return packed
@@ -253,7 +258,8 @@ def maf_loss_fwd_bwd(net: MAFNet, theta: Tensor, x: Tensor, row_weight: Optional
     packed = maf_packed_weights(net)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_maf_loss_fwd_bwd(net.hyper.c_config(), _lib.ptr(packed), _lib.ptr(net.zstats),
-                                          _lib.ptr(theta), _lib.ptr(x), n, x.shape[0], _lib.ptr(row_weight),
+                                          _lib.ptr(net.kernel_masks()), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
+                                          _lib.ptr(row_weight),
                                           float(uniform_weight), _lib.ptr(loss), _lib.ptr(grad_out), _lib.ptr(gtheta),
                                           _lib.ptr(workspace), _lib.current_stream(dev))
     _lib.check(rc, "maf_loss_fwd_bwd")

@@ -14,7 +14,7 @@ from typing import Any, Callable, Optional
 
 from torch import Tensor, nn
 
-from sbi_amd.neural_nets.net_builders.estimator_configs import MAFRQSConfig, NSFConfig
+from sbi_amd.neural_nets.net_builders.estimator_configs import MAFRQSConfig, NSFConfig, ZukoNSFConfig
 
 _NSF_FIELDS = {"hidden_features", "num_transforms", "num_bins", "num_blocks", "dropout_probability",
                "use_batch_norm", "tail_bound", "hidden_layers_spline_context", "dtype"}
@@ -41,9 +41,14 @@ def posterior_nn(
         warnings.warn(f"Unknown kwargs {sorted(unknown)} are forwarded to the builder.", UserWarning, stacklevel=2)
 
     def build_fn(batch_theta: Tensor, batch_x: Tensor):
+        if model == "zuko_nsf":
+            return ZukoNSFConfig(z_score_input=z_score_theta, z_score_condition=z_score_x,
+                                 embedding_net=None if isinstance(embedding_net, nn.Identity) else embedding_net,
+                                 hidden_features=hidden_features, num_transforms=num_transforms, num_bins=num_bins,
+                                 extra_kwargs={**known, **unknown}).build(batch_theta, batch_x)
         if model not in _MODELS:
             raise NotImplementedError(
-                f"sbi_amd implements the 'nsf' and 'maf_rqs' posterior estimators (got model={model!r}); other "
+                f"sbi_amd implements the 'nsf', 'maf_rqs' and 'zuko_nsf' posterior estimators (got model={model!r}); other "
                 "model families are outside the accelerated path."
             )
         cfg = _MODELS[model][0](

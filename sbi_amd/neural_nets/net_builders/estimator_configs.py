@@ -90,3 +90,33 @@ class MAFRQSConfig(NSFConfig):
         from sbi_amd.neural_nets.net_builders.flow import build_maf_rqs
 
         return build_maf_rqs(batch_x=batch_input, batch_y=batch_condition, **self._build_kwargs())
+
+
+@dataclass(frozen=True)
+class ZukoNSFConfig:
+    """Mirror of sbi's ``ZukoNSFConfig`` (estimator_configs.py: zuko flow base fields + ``num_bins``)."""
+
+    z_score_input: Optional[str] = "independent"
+    z_score_condition: Optional[str] = "independent"
+    embedding_net: Optional[nn.Module] = None
+    hidden_features: Any = 50
+    num_transforms: int = 5
+    num_bins: int = 10
+    extra_kwargs: Dict[str, Any] = field(default_factory=dict)
+
+    def __post_init__(self):
+        for name in ("z_score_input", "z_score_condition"):
+            v = getattr(self, name)
+            if v is None:
+                object.__setattr__(self, name, "none")
+            elif v not in _Z_SCORE_VALUES:
+                raise ValueError(f"{name} must be one of {_Z_SCORE_VALUES} or None, got {v!r}")
+
+    def build(self, batch_input: Tensor, batch_condition: Tensor):
+        from sbi_amd.neural_nets.net_builders.flow import build_zuko_nsf
+
+        return build_zuko_nsf(batch_x=batch_input, batch_y=batch_condition, z_score_x=self.z_score_input,
+                              z_score_y=self.z_score_condition, hidden_features=self.hidden_features,
+                              num_transforms=self.num_transforms, num_bins=self.num_bins,
+                              embedding_net=nn.Identity() if self.embedding_net is None else self.embedding_net,
+                              **self.extra_kwargs)

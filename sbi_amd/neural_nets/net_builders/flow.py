@@ -174,3 +174,44 @@ def build_maf_rqs(
                      min_bin_height=float(min_bin_height), min_derivative=float(min_derivative))
     net = MAFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy, dtype=kwargs.get("dtype", torch.float32))
     return MAFRQSFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape, embedding_net=embedding)
+
+
+def build_zuko_nsf(
+    batch_x: Tensor,
+    batch_y: Tensor,
+    z_score_x: Optional[str] = "independent",
+    z_score_y: Optional[str] = "independent",
+    hidden_features=50,
+    num_transforms: int = 5,
+    embedding_net: nn.Module = nn.Identity(),
+    num_bins: int = 10,
+    **kwargs,
+):
+    """Same signature and meaning as the reference ``build_zuko_nsf`` (flow.py:578-640 -> build_zuko_flow
+    :1082-1173 -> zuko.flows.NSF): fully autoregressive spline flow, hyper-nets with
+    ``[hidden_features] * num_transforms`` hidden layers (sbi's convention), spline domain [-5, 5].  Runs on the maf
+    kernels in their zuko configuration; zuko keyword arguments that change the architecture (``passes``,
+    ``randperm``, ``residual``, ``activation``) and ``z_score_x="transform_to_unconstrained"`` are refused."""
+    from sbi_amd.neural_nets.estimators.zuko_flow import ZukoHyper, ZukoNSFFlow, ZukoNSFNet
+
+    check_data_device(batch_x, batch_y)
+    if z_score_x == "transform_to_unconstrained":
+        raise NotImplementedError("sbi_amd.build_zuko_nsf: z_score_x='transform_to_unconstrained' (prior-support "
+                                  "bijection in front of the flow) is not implemented in the HIP path")
+    nflow_specific = {"num_blocks", "dropout_probability", "use_batch_norm", "tail_bound", "tails",
+                      "hidden_layers_spline_context", "num_components", "dtype", "min_bin_width", "min_bin_height",
+                      "min_derivative"}                      # build_zuko_flow drops these (flow.py:1140)
+    extra = {k: v for k, v in kwargs.items() if k not in nflow_specific}
+    if extra:
+        raise NotImplementedError(f"sbi_amd.build_zuko_nsf: zuko keyword arguments {sorted(extra)} are not "
+                                  "implemented in the HIP path")
+    hidden = [hidden_features] * num_transforms if isinstance(hidden_features, int) else list(hidden_features)
+    if len(set(hidden)) != 1 or not 1 <= len(hidden) <= 5:
+        raise NotImplementedError("sbi_amd.build_zuko_nsf: the hyper-net needs 1..5 hidden layers of one width "
+                                  f"(got {hidden}); note that sbi passes [hidden_features] * num_transforms")
+    D, C, zstats, zx, zy, embedding = _flow_inputs(batch_x, batch_y, z_score_x, z_score_y, embedding_net,
+                                                  "build_zuko_nsf")
+    hyper = ZukoHyper(D=D, C=C, hidden_features=int(hidden[0]), num_transforms=num_transforms, num_bins=num_bins,
+                      num_hidden_layers=len(hidden))
+    net = ZukoNSFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy)
+    return ZukoNSFFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape, embedding_net=embedding)
