@@ -337,8 +337,33 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
         sample_obj = {"metric": "FMPE posterior.sample draws/sec (ODE, atol 1e-6 rtol 1e-5)", "value": n_draw / dt,
                       "unit": "draws/s", "draws_per_call": n_draw, "ms_per_call": dt * 1e3,
                       "velocity_evals_per_call": calls[0] / reps}
+    # BASELINE configs[4] through the trainer itself: FMPE.train() on 10^6 simulations (theta-dim 50), batch 65 536,
+    # validation at 10 fixed times, EMA / early-stopping bookkeeping and the per-epoch host read included
+    loop_obj = None
+    if args.mode == "fmpe" and not args.skip_sampling:
+        import warnings
+
+        from sbi_amd.inference import FMPE
+
+        n_sims, ep = 1_000_000, 4
+        th_all, x_all = make_data(n_sims, "cpu", seed=7, dim=DF)
+        torch.manual_seed(1)
+        trainer = FMPE(prior=None, device=str(device), show_progress_bars=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            trainer.append_simulations(th_all, x_all)
+            trainer.train(training_batch_size=B, max_num_epochs=1, stop_after_epochs=10**9)     # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trainer.train(training_batch_size=B, max_num_epochs=1 + ep, stop_after_epochs=10**9, resume_training=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        steps_ep = int(0.9 * n_sims) // B
+        loop_obj = {"metric": "FMPE.train() (theta,x)-pairs/sec, 10^6 simulations", "value": B * steps_ep * ep / dt,
+                    "unit": "pairs/s", "epochs": ep, "train_steps": steps_ep * ep, "ms_per_epoch": dt / ep * 1e3,
+                    "validation_rows_per_epoch": ((n_sims - int(0.9 * n_sims)) // B) * B * 10, "n_gpus": world}
     return {
-        "posterior_sample": sample_obj,
+        "posterior_sample": sample_obj, "train_loop": loop_obj,
         "metric": "FMPE train (theta,x)-pairs/sec", "value": B * world * args.steps / wall,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,

@@ -52,7 +52,9 @@ struct TrainPlan {
 //     register row when staging); LDS-fed MFMA loops are limited by the number of LDS instructions.
 //   Bs (static conditioner input): row major, stride 48 (= 48 mod 64: the g groups hit disjoint banks).
 static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
-  if (pl.D > 15 || pl.H > 63 || pl.NB > 2 || (pl.NB < 1 && !pl.ctx_mlp)) return SBI_AMD_E_UNSUPPORTED;
+  // hidden_features == 64 has no spare activation-tile column for the bias trick: the kernel then takes the bias
+  // gradients from one extra MFMA per K-step against a ones vector (template flag HB)
+  if (pl.D > 15 || pl.H > 64 || pl.NB > 2 || (pl.NB < 1 && !pl.ctx_mlp)) return SBI_AMD_E_UNSUPPORTED;
   const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
   if (d_id_max + pl.C + 1 > 32 || pl.C + 1 > 32) return SBI_AMD_E_UNSUPPORTED;
   tp->DCHB = 4 / pl.PT;
@@ -144,8 +146,9 @@ __device__ __forceinline__ constexpr int dw_krow(int s) { return 16 * (s >> 2) +
 template <int NT, int SA, int SB, bool IL = false>
 __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const float* __restrict__ Bst,
                                         int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT,
-                                        int abl = 0) {
+                                        int abl = 0, f4* accb = nullptr) {
   if (abl & 1) return;
+  const float ones_b = id.j == 0 ? 1.f : 0.f;   // B operand of the bias-gradient MFMA: column 0 = sum over the rows
   constexpr int KS = TR_ROWS / 4, LA = TR_LA;
   // K-step s covers tile rows krow(s) + 4 g (not 4 s + g): with the gradient tiles' row stride 68 (= 4 mod 64,
   // what keeps the ROW waves' accesses conflict-free) the four k-slots of an A read then sit 16 banks apart
@@ -180,6 +183,7 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)   // NT == 1: no guard (a guard per MFMA costs a basic block and an s_waitcnt each)
       if (NT == 1 || nt < nt_on) acc[nt] = MFMA16(a[s % (LA + 1)], b[s % (LA + 1)][nt], acc[nt]);
+    if (accb) *accb = MFMA16(a[s % (LA + 1)], ones_b, *accb);   // compile-time null in the H < 64 instantiations
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -566,6 +570,16 @@ __device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDe
     }
   }
 }
+// bias gradients from the ones-vector accumulator (HB instantiations): lane column 0 holds the row sums
+__device__ __forceinline__ void write_bias(float* __restrict__ part, const LinDesc& L, int out0, const LaneId& id,
+                                           const f4& accb) {
+  if (id.j != 0) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int out = out0 + 4 * id.g + r;
+    if (out < L.out) part[L.g_b + out] = accb[r];
+  }
+}
 
 // ------------------------------------------------------------------ backward kernel
 // Wave specialisation, one workgroup = 64-row tile:
@@ -584,8 +598,8 @@ __device__ __forceinline__ void write_tile(float* __restrict__ part, const LinDe
 // residual-net instantiations carry none of its code or registers).
 // NTW = n-tiles of the narrow input-side weight gradients (d W0, d Wc): 1 when their inputs (+ bias column) fit
 // 16 columns, which frees 12 accumulator registers in the grad waves.
-template <int K, int KSH, int NBT, int NCH, int NTW>
-__global__ void __launch_bounds__(128 * TR_NW, 2)
+template <int K, int KSH, int NBT, int NCH, int NTW, bool HB>
+__global__ void __launch_bounds__(128 * TR_NW, HB ? 1 : 2)
 nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const float* __restrict__ packed,
                      const float* __restrict__ zstats, const float* __restrict__ z_in,
                      const float* __restrict__ x, const float* __restrict__ gz_up,
@@ -822,7 +836,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[1][mt][r] > 0.f ? gh[mt][r] : 0.f;
         stage_D(lds + o_AY, SA, trow, id, ga, false);
         stage_DB(Bt, SB, trow, id, hpre[0], true);
-        if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
+        if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
         __syncthreads();                           // X1
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
@@ -852,7 +866,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
               ctx_grad_update<KSH>(lds, S.lin[1 + 3 * b], id, gc, 0, C, xs, gx_row, valid, is_last && b == NB - 1);
           }
           stage_DB(Bt, SB, trow, id, bt1, true);
-          if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;      // bias column
+          if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;      // bias column
           ast_load(ast, 4 * b, hpre[0]);                  // h_b: needed two phases from now
           if (b > 0) {   // next (earlier) block's t2 / gate: fetch under this block's GEMM phases
             ast_load(ast, 2 + 4 * (b - 1), bt2);
@@ -874,7 +888,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
           TS(23 + 8 * b);
           stage_D(lds + o_AY, SA, trow, id, ga, false);
           stage_DB(Bt, SB, trow, id, hpre[0], true);
-          if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
+          if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
           __syncthreads();                         // X3: (g_t1, relu h_b) published
           TS(24 + 8 * b);
 #pragma unroll
@@ -939,6 +953,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     int sync_target = 0;
     // weight-gradient accumulators owned by this wave (m-tile = wave) for the whole launch
     f4 acc0[NTW], accC[NB][NTW], acc1[NB][4], acc2[NB][4], accF[NCH][4], accLU[1];
+    f4 acc1b[HB ? NB : 1], acc2b[HB ? NB : 1], accFb[HB ? NCH : 1];   // bias gradients when hidden_features == 64
+  #pragma unroll
+    for (int i = 0; i < (HB ? NB : 1); ++i) { acc1b[i] = zero4; acc2b[i] = zero4; }
+  #pragma unroll
+    for (int i = 0; i < (HB ? NCH : 1); ++i) accFb[i] = zero4;
   #pragma unroll
     for (int i = 0; i < NTW; ++i) acc0[i] = zero4;
   #pragma unroll
@@ -978,7 +997,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       // ---- prologue: h_last of the partner's rows (stash, D-fragment order = MFMA B operand; requested
       // during the previous tile), its activation-tile rows, and the spline parameters of chunk 0
       stage_DB(Bt, SB, trow, id, hl, false);
-      if (id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
+      if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
       if (!(pl.ablate & 32)) final_layer_chunk_T<PT, KSH>(ldsF, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
       f4 gh[NSF_HT];
   #pragma unroll
@@ -992,7 +1011,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         if (k <= nch) {
           if (k >= 1) {
             const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
-            dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate);
+            dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate,
+                                           HB ? &accFb[k - 1 < NCH ? k - 1 : 0] : nullptr);
             TS(13 + k);
             if (!(pl.ablate & 2)) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
           }
@@ -1015,19 +1035,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       }
       if (cm) {
         __syncthreads();                           // X1
-        dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, pl.ablate);
+        dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, pl.ablate, HB ? &acc1b[0] : nullptr);
       } else {
   #pragma unroll
         for (int b = NB - 1; b >= 0; --b) {
           __syncthreads();                         // X1
           TS(21 + 8 * b);
-          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl.ablate);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl.ablate, HB ? &acc2b[b] : nullptr);
           dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl.ablate);
           TS(22 + 8 * b);
           __syncthreads();                         // X2
           __syncthreads();                         // X3
           TS(24 + 8 * b);
-          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[b], 4, pl.ablate);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[b], 4, pl.ablate, HB ? &acc1b[b] : nullptr);
           TS(25 + 8 * b);
           if (b > 0) __syncthreads();              // X4
         }
@@ -1050,6 +1070,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
     if (cm) {
   #pragma unroll
       for (int nt = 0; nt < 4; ++nt) write_tile(part, S.lin[1], out0, nt, id, acc1[0][nt]);   // hidden H->H layer
+      if (HB) write_bias(part, S.lin[1], out0, id, acc1b[0]);
     } else {
   #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -1059,6 +1080,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         for (int nt = 0; nt < 4; ++nt) {
           write_tile(part, S.lin[2 + 3 * b], out0, nt, id, acc1[b][nt]);
           write_tile(part, S.lin[3 + 3 * b], out0, nt, id, acc2[b][nt]);
+        }
+        if (HB) {
+          write_bias(part, S.lin[2 + 3 * b], out0, id, acc1b[b]);
+          write_bias(part, S.lin[3 + 3 * b], out0, id, acc2b[b]);
         }
       }
     }
@@ -1078,6 +1103,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
                 const int out = dd * pl.P + p;
                 if (in < LF.in) part[LF.g_w + out * LF.in + in] = accF[c][nt][r];
                 else if (in == LF.in) part[LF.g_b + out] = accF[c][nt][r];
+                if (HB && nt == 0 && id.j == 0) part[LF.g_b + out] = accFb[c][r];
               }
             }
         }
@@ -1112,12 +1138,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
 
 
 // ---- launch helpers
-template <int K, int KSH, int NB, int NCH, int NTW>
+template <int K, int KSH, int NB, int NCH, int NTW, bool HB = false>
 static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
                       const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
                       int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
                       const float* astash, long long* dbg, hipStream_t st) {
-  auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH, NTW>;
+  auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH, NTW, HB>;
   const int lds_bytes = 4 * tp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
@@ -1145,9 +1171,20 @@ int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* pac
   }
   if (pl.ctx_mlp) {   // theta-dim 1: one transformed dim => one chunk
     if (pl.KSH == 13) return wide ? launch_bwd<K, 13, 0, 1, 2>(BWD_ARGS) : launch_bwd<K, 13, 0, 1, 1>(BWD_ARGS);
+    if (pl.H == 64) return wide ? launch_bwd<K, 16, 0, 1, 2, true>(BWD_ARGS) : launch_bwd<K, 16, 0, 1, 1, true>(BWD_ARGS);
     return wide ? launch_bwd<K, 16, 0, 1, 2>(BWD_ARGS) : launch_bwd<K, 16, 0, 1, 1>(BWD_ARGS);
   }
   if (pl.KSH == 13) { if (pl.NB <= 1) { BWD_NCH(13, 1) } else { BWD_NCH(13, 2) } }
+  if (pl.H == 64) {   // bias gradients through the ones-vector MFMA
+#define BWD_NCH_HB(NBV) \
+  switch (nchmax) { \
+    case 1: return wide ? launch_bwd<K, 16, NBV, 1, 2, true>(BWD_ARGS) : launch_bwd<K, 16, NBV, 1, 1, true>(BWD_ARGS); \
+    case 2: case 3: return wide ? launch_bwd<K, 16, NBV, 3, 2, true>(BWD_ARGS) : launch_bwd<K, 16, NBV, 3, 1, true>(BWD_ARGS); \
+    default: return wide ? launch_bwd<K, 16, NBV, 4, 2, true>(BWD_ARGS) : launch_bwd<K, 16, NBV, 4, 1, true>(BWD_ARGS); \
+  }
+    if (pl.NB <= 1) { BWD_NCH_HB(1) } else { BWD_NCH_HB(2) }
+#undef BWD_NCH_HB
+  }
   if (pl.NB <= 1) { BWD_NCH(16, 1) } else { BWD_NCH(16, 2) }
 #undef BWD_NCH
 #undef BWD_ARGS

@@ -35,6 +35,12 @@ CONFIGS = [
     dict(D=15, C=20, num_transforms=3),
     dict(D=10, C=10, hidden_features=60, num_transforms=2),
     dict(D=13, C=4, num_bins=8, num_transforms=2),
+    # hidden_features = 64: no spare activation-tile column for the bias trick, the bias gradients come from an extra
+    # MFMA against a ones vector (template flag HB of the backward kernel)
+    dict(D=10, C=10, hidden_features=64, num_transforms=2),
+    dict(D=4, C=4, hidden_features=64, num_transforms=3, num_blocks=1),
+    dict(D=12, C=10, hidden_features=64, num_transforms=2, num_bins=8),
+    dict(D=1, C=5, hidden_features=64, num_transforms=2),
     # seed 2: with seed 1, row 91 enters the last transform exactly ON an fp32 knot, where the spline's second
     # derivative (hence d loss/d params) is two-valued and either bin is a correct answer
     dict(D=1, C=7, hidden_features=32, num_transforms=3, seed=2),
