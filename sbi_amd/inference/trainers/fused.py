@@ -58,6 +58,16 @@ class FusedTrainStep:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
 
+    # -- device snapshots for the software-pipelined epoch loop of NPE.train() -------------------
+    def snapshot(self) -> dict:
+        return {"params": self.net.flat_params.data.clone(), "exp_avg": self.exp_avg.clone(),
+                "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count}
+
+    def restore_optimizer(self, snap: dict) -> None:
+        self.exp_avg.copy_(snap["exp_avg"])
+        self.exp_avg_sq.copy_(snap["exp_avg_sq"])
+        self.step_count = int(snap["step"])
+
     def _workspace(self, n: int) -> Tensor:
         need = self.net.train_workspace_floats(n)
         if self.workspace is None or self.workspace.numel() < need:

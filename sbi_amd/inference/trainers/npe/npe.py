@@ -407,8 +407,12 @@ class PosteriorEstimatorTrainer:
                 return losses * calibration_kernel(xx) if calibration_kernel is not None else losses
 
         perm_of = self._epoch_permutations()
-        while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
-            t0 = time.time()
+        import os as _os
+
+        def launch_epoch(e: int) -> dict:
+            """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here
+            waits for the device.  Returns the record `finish_epoch` turns into the epoch's host bookkeeping."""
+            rec = {"epoch": e, "t0": time.time()}
             net.train()
             order = perm_of(n_train)   # SubsetRandomSampler
             epoch_idx = train_idx[order]
@@ -416,6 +420,8 @@ class PosteriorEstimatorTrainer:
             for b in range(n_train_batches):
                 idx = my_slice(epoch_idx[b * B : (b + 1) * B])
                 sums[0] += batch_losses(idx, True, B).sum()
+            if pipelined:
+                rec["snap"] = self._stepper.snapshot()      # weights + optimizer state after this epoch's steps
             net.eval()
             val_epoch_idx = val_idx[perm_of(n_val)]
             for b in range(n_val_batches):
@@ -423,17 +429,59 @@ class PosteriorEstimatorTrainer:
                 sums[1] += batch_losses(idx, False, Bv).sum()
             if d is not None:
                 d.all_reduce(sums, op=d.ReduceOp.SUM)
-            host = sums.cpu()                                   # the one sync of the epoch
+            if pipelined:
+                rec["host"] = torch.empty(2, dtype=sums.dtype, pin_memory=True)
+                rec["host"].copy_(sums, non_blocking=True)
+                rec["event"] = torch.cuda.Event()
+                rec["event"].record()
+            else:
+                rec["host"] = sums.cpu()                        # the one sync of the epoch
+            return rec
+
+        def finish_epoch(rec: dict) -> None:
+            if "event" in rec:
+                rec["event"].synchronize()
+            host = rec["host"]
             if not torch.isfinite(host).all():
                 raise AssertionError("NaN/Inf present in NPE loss.")
             train_loss = float(host[0]) / (n_train_batches * B)
             self._val_loss = float(host[1]) / (n_val_batches * Bv)
             self._summary["training_loss"].append(train_loss)
             self._summary["validation_loss"].append(self._val_loss)
-            self._summary["epoch_durations_sec"].append(time.time() - t0)
-            self.epoch += 1
+            self._summary["epoch_durations_sec"].append(time.time() - rec["t0"])
+            self.epoch = rec["epoch"] + 1
             if self._show_progress_bars and rank == 0:
                 print("\r", f"Training neural network. Epochs trained: {self.epoch}", end="")
+
+        # Fused path: epochs are software-pipelined against the host.  Epoch e+1 is enqueued BEFORE the losses of
+        # epoch e are read back, so the device never waits for the early-stopping bookkeeping (one pinned-memory
+        # read per epoch, one epoch late).  The decisions are the reference's, in the reference's order: the
+        # weights + optimizer state after every epoch are snapshotted on the device, `_converged` scores epoch e with
+        # that snapshot, and if it says stop, the speculative epoch e+1 is thrown away (its summary entries are never
+        # written, the optimizer state is rolled back, the best weights restored as always).
+        pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"
+        if not pipelined:
+            while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
+                finish_epoch(launch_epoch(self.epoch))
+        else:
+            in_flight = None
+            while True:
+                if in_flight is None:
+                    if self.epoch > cfg.max_num_epochs or self._converged(self.epoch, cfg.stop_after_epochs):
+                        break
+                    in_flight = launch_epoch(self.epoch)
+                    continue
+                nxt = in_flight["epoch"] + 1
+                spec = launch_epoch(nxt) if nxt <= cfg.max_num_epochs else None
+                finish_epoch(in_flight)                      # -> self.epoch == nxt, self._val_loss of that epoch
+                if self.epoch > cfg.max_num_epochs:
+                    break
+                if self._converged(self.epoch, cfg.stop_after_epochs, snapshot=in_flight["snap"]):
+                    if spec is not None:
+                        spec["event"].synchronize()
+                        self._stepper.restore_optimizer(in_flight["snap"])
+                    break
+                in_flight = spec
 
         if self.epoch > cfg.max_num_epochs:
             # the final epoch was never scored by `_converged` (base.py:1122-1129)
@@ -460,14 +508,21 @@ class PosteriorEstimatorTrainer:
         if inner is not None:
             inner.__dict__.pop("_packed_cache", None)
 
-    def _converged(self, epoch: int, stop_after_epochs: int) -> bool:
-        """Early stopping with best-weights bookkeeping (base.py:1254-1284)."""
+    def _converged(self, epoch: int, stop_after_epochs: int, snapshot: Optional[dict] = None) -> bool:
+        """Early stopping with best-weights bookkeeping (base.py:1254-1284).  `snapshot` (pipelined fused loop): the
+        device copy of the flat parameters the scored epoch ended with -- the live ones may already belong to the
+        next, speculative epoch."""
         converged = False
         net = self._neural_net
         if epoch == 0 or self._val_loss < self._best_val_loss:
             self._best_val_loss = self._val_loss
             self._epochs_since_last_improvement = 0
-            self._best_model_state_dict = deepcopy(net.state_dict())
+            if snapshot is None:
+                self._best_model_state_dict = deepcopy(net.state_dict())
+            else:
+                self._best_model_state_dict = type(net.state_dict())(
+                    (k, snapshot["params"].clone() if k == "net.flat_params" else v.clone())
+                    for k, v in net.state_dict().items())
         else:
             self._epochs_since_last_improvement += 1
         if self._epochs_since_last_improvement > stop_after_epochs - 1:

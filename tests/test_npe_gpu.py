@@ -143,3 +143,39 @@ def test_reference_ci_scenario_nsf_npe_c_dim4_wall_time():
     print(f"reference CI scenario: wall {wall:.2f} s (reference CI: 41.7 s), epochs {inf.summary['epochs_trained'][-1]}, "
           f"c2st {score:.3f}")
     assert 0.4 <= score <= 0.6
+
+
+@pytest.mark.parametrize("stop_kind", ["early_stopping", "max_epochs"])
+def test_pipelined_epoch_loop_takes_the_eager_loops_decisions(stop_kind, monkeypatch):
+    """NPE.train() enqueues epoch e+1 before it reads epoch e's losses (one pinned read per epoch, one epoch
+    late) and throws the speculative epoch away when the reference's rule says stop.  Same seeds => the same
+    loss history, epoch count, best validation loss, returned weights and optimizer state as the loop that syncs
+    every epoch (SBI_AMD_EAGER_EPOCH_SYNC=1)."""
+    dim, n = 2, 700
+    shift, cov = -1.0 * torch.ones(dim), 0.3 * torch.eye(dim)
+
+    def run(eager: bool):
+        monkeypatch.setenv("SBI_AMD_EAGER_EPOCH_SYNC", "1" if eager else "0")
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        prior = MultivariateNormal(torch.zeros(dim, device="cuda"), torch.eye(dim, device="cuda"))
+        theta = prior.sample((n,)).cpu()
+        x = linear_gaussian(theta, shift, cov)
+        torch.manual_seed(1)
+        inf = NPE(prior=prior, density_estimator=NSFConfig(num_transforms=2), device="cuda", show_progress_bars=False)
+        kw = dict(stop_after_epochs=3) if stop_kind == "early_stopping" else dict(max_num_epochs=7)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            est = inf.append_simulations(theta, x).train(training_batch_size=100, learning_rate=5e-3, **kw)
+        return inf, est
+
+    a, est_a = run(eager=True)
+    b, est_b = run(eager=False)
+    assert a.summary["epochs_trained"] == b.summary["epochs_trained"]
+    assert a.summary["validation_loss"] == b.summary["validation_loss"]
+    assert a.summary["training_loss"] == b.summary["training_loss"]
+    assert a.summary["best_validation_loss"] == b.summary["best_validation_loss"]
+    assert torch.equal(est_a.net.flat_params, est_b.net.flat_params)
+    assert torch.equal(a._stepper.exp_avg, b._stepper.exp_avg) and a._stepper.step_count == b._stepper.step_count
+    if stop_kind == "early_stopping":
+        assert a.summary["epochs_trained"][-1] < 200
