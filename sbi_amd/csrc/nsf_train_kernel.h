@@ -22,6 +22,10 @@
 #define TR_GRID_MAX 256    // persistent workgroups (one per CU)
 #define TR_SA 68           // row stride of the gradient tiles A0/A1
 #define TR_SB 68           // row stride of the activation tile B (column-interleaved, see stage_DB)
+// Column where dim slot 1 of a spline-parameter tile row starts: one float past the first slot's 16*PT, so that the
+// four (slot, widths | heights) lane classes of the spline phase fall into four different bank residues mod 4 for the
+// default 10 bins (rows are 4 banks apart: stride 68) -- it was a 2-way conflict on every parameter access.
+#define TR_SLOT(PT) (16 * (PT) + 1)
 #define TR_LDK_FAST 50     // image row stride of the default hidden_features = 50: compiled-in fast path
 #ifndef TR_LA
 #define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
@@ -383,7 +387,7 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) arow[id.j * tp.SA + sl * 16 * PT + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+      for (int r = 0; r < 4; ++r) arow[id.j * tp.SA + sl * TR_SLOT(PT) + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
 }
 
 // RQ spline forward + reverse-mode gradient for one (row, dim) task on a lane pair (see
@@ -513,7 +517,7 @@ __device__ __forceinline__ void wft_chunk_ldk(const float* __restrict__ lds, con
     const int dd = d0 + sl;
     if (dd < S.d_tr) {
       const float* wrow = lds + LF.l_w + (dd * pl.P + id.g) * ldk;
-      const float* brow = Arow + id.j * SA + sl * 16 * PT + id.g;
+      const float* brow = Arow + id.j * SA + sl * TR_SLOT(PT) + id.g;
       const float* wcol[NSF_HT];
 #pragma unroll
       for (int mt = 0; mt < NSF_HT; ++mt) wcol[mt] = wrow + col[mt];
@@ -775,7 +779,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         const int d0 = c * DCHB;
         const int slot = id.g & 1, part = id.g >> 1;
         const int dd = d0 + slot;
-        float* pp = lds + ((c & 1) ? tp.o_A1 : tp.o_A0) + trow * SA + slot * tp.PTW;
+        float* pp = lds + ((c & 1) ? tp.o_A1 : tp.o_A0) + trow * SA + slot * TR_SLOT(PT);
         if (slot < DCHB) {
           if (dd < S.d_tr && !(pl.ablate & 4)) {
             const int zi = id.j * pl.ZW + 2 * dd + par;
@@ -1011,7 +1015,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
         if (k <= nch) {
           if (k >= 1) {
             const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
-            dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw, 0, id, accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate,
+            // m-tile gw = 16 spline-parameter columns of dim slot gw / PT (the second slot starts one float late)
+            dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw + (gw / PT < DCHB ? gw / PT : 0), 0, id,
+                                           accF[k - 1 < NCH ? k - 1 : 0], 4, pl.ablate,
                                            HB ? &accFb[k - 1 < NCH ? k - 1 : 0] : nullptr);
             TS(13 + k);
             if (!(pl.ablate & 2)) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
