@@ -198,7 +198,7 @@ extern "C" int sbi_amd_maf_sample(const sbi_amd_maf_config* cfg, const float* pa
 
 // ---- training workspace layout (floats)
 struct MafWs {
-  int64_t stash, noise, logp, gza, gzb, gp, act, gbuf, ctx, part, total;
+  int64_t stash, noise, logp, gza, gzb, gp, act, gbuf, ctx, part, total, npad;
   int nchunks, rows_per_chunk;
 };
 static MafWs maf_ws_layout(const MafPlan& mp, int64_t n) {
@@ -211,16 +211,14 @@ static MafWs maf_ws_layout(const MafPlan& mp, int64_t n) {
   w.logp = take(n);
   w.gza = take(n * D);
   w.gzb = take(n * D);
-  w.gp = take(n * mp.DP);
-  w.act = take(n * (MAF_MAX_NB + 1) * MAF_AW);
-  w.gbuf = take(n * (MAF_MAX_NB + 2) * MAF_AW);
-  w.ctx = take(n * MAF_CW);
-  int nch = (int)((n + 63) / 64);
-  if (nch > 256) nch = 256;
-  if (nch < 1) nch = 1;
-  w.nchunks = nch;
-  w.rows_per_chunk = (int)(((n + nch - 1) / nch + 3) / 4 * 4);
-  w.nchunks = (int)((n + w.rows_per_chunk - 1) / w.rows_per_chunk);
+  const int64_t npad = (n + MAF_DW_ROWS - 1) / MAF_DW_ROWS * MAF_DW_ROWS;   // the dW kernel reads whole chunks
+  w.npad = npad;
+  w.gp = take(npad * mp.DP);
+  w.act = take(npad * (MAF_MAX_NB + 1) * MAF_AW);
+  w.gbuf = take(npad * (MAF_MAX_NB + 2) * MAF_AW);
+  w.ctx = take(npad * MAF_CW);
+  w.rows_per_chunk = MAF_DW_ROWS;
+  w.nchunks = (int)((n + MAF_DW_ROWS - 1) / MAF_DW_ROWS);
   w.part = take((int64_t)T * w.nchunks * mp.n_layer);
   w.total = o;
   return w;
@@ -276,30 +274,36 @@ extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const flo
     a.gz_dn = gz[t & 1];
     a.grad_theta = grad_theta_out;
     a.GP = workspace + w.gp; a.ACT = workspace + w.act; a.G = workspace + w.gbuf; a.CTX = workspace + w.ctx;
+    a.npad = w.npad;
     a.t = t; a.is_last = (t == T - 1);
     rc = maf_dispatch(mpb, nwb, 2, packed, zstats, nullptr, x, n, x_rows, nullptr, nullptr, nullptr, &a, st);
     if (rc) return rc;
     MafDwArgs d;
     memset(&d, 0, sizeof(d));
     const ShapeDesc& S = mp.n.shape[0];
-    const int GW = (MAF_MAX_NB + 2) * MAF_AW, AWS = (MAF_MAX_NB + 1) * MAF_AW;
-    auto set = [&](int i, const float* G, int ldg, const float* A, int lda, const LinDesc& L, int group, int gpad,
-                   int kind) {
-      d.lin[i].G = G; d.lin[i].ldg = ldg; d.lin[i].A = A; d.lin[i].lda = lda;
+    const int AWS = (MAF_MAX_NB + 1) * MAF_AW;
+    const int64_t gts = w.npad * 16;     // floats per m-tile plane
+    auto set = [&](int i, const float* G, const float* A, int lda, const LinDesc& L, int group, int gpad, int kind) {
+      d.lin[i].G = G; d.lin[i].gts = gts; d.lin[i].A = A; d.lin[i].lda = lda;
       d.lin[i].out = L.out; d.lin[i].in = L.in; d.lin[i].group = group; d.lin[i].group_pad = gpad;
       d.lin[i].g_w = L.g_w; d.lin[i].g_b = L.g_b; d.lin[i].kind = kind;
     };
     // largest first (the final layer has D*(3K-1) outputs)
-    set(0, a.GP, mp.DP, a.ACT + 64 * NB, AWS, S.lin[S.fin], mp.n.P, mp.PTW, 3);
-    for (int b = 0; b < NB; ++b) set(1 + b, a.G + 64 * (2 + b), GW, a.ACT + 64 * b, AWS, S.lin[2 + b], mp.n.H, 64, 2);
-    set(1 + NB, a.G, GW, a.CTX, MAF_CW, S.lin[0], mp.n.H, 64, 0);     // inputs: CTX rows = [z ; context]
+    set(0, a.GP, a.ACT + 64 * NB, AWS, S.lin[S.fin], mp.n.P, mp.PTW, 3);
+    for (int b = 0; b < NB; ++b) set(1 + b, a.G + 4 * (2 + b) * gts, a.ACT + 64 * b, AWS, S.lin[2 + b], mp.n.H, 64, 2);
+    set(1 + NB, a.G, a.CTX, MAF_CW, S.lin[0], mp.n.H, 64, 0);     // inputs: CTX rows = [z ; context]
     int nlin = 2 + NB;
-    if (mp.variant == 0) { set(2 + NB, a.G + 64, GW, a.CTX + D, MAF_CW, S.lin[1], mp.n.H, 64, 1); nlin = 3 + NB; }
+    if (mp.variant == 0) { set(2 + NB, a.G + 4 * gts, a.CTX + D, MAF_CW, S.lin[1], mp.n.H, 64, 1); nlin = 3 + NB; }
     d.mask = masks ? masks + (int64_t)t * mp.n_layer : nullptr;
     d.n = n; d.rows_per_chunk = w.rows_per_chunk; d.nchunks = w.nchunks; d.n_layer = mp.n_layer;
     d.D = D; d.P = mp.n.P;
     d.partial = workspace + w.part + (int64_t)t * w.nchunks * mp.n_layer;
-    hipLaunchKernelGGL(maf_dw_kernel, dim3(w.nchunks, nlin), dim3(256), 0, st, d);
+    {
+      const int dw_lds = (MAF_DW_ROWS * MAF_DW_SA + 4 * MAF_DW_ROWS * MAF_DW_GS) * 4;
+      hipError_t e = hipFuncSetAttribute((const void*)maf_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(maf_dw_kernel, dim3(w.nchunks, nlin), dim3(256), (size_t)dw_lds, st, d);
+    }
     rc = (int)hipGetLastError();
     if (rc) return rc;
   }

@@ -316,9 +316,13 @@ struct MafBwdArgs {
   long long n, x_rows;
   float* gz_dn;            // (n, D) gradient wrt this transform's input (t > 0)
   float* grad_theta;       // optional (n, D), written by t == 0
-  float* GP;               // (n, DP)  gradient wrt the raw spline parameters, rows padded to 16*PT per dim
-  float* ACT;              // (n, (NB+1)*64) h_0 .. h_NB
-  float* G;                // (n, (NB+2)*64) slot 0: d/d(a1), slot 1: d/d(context pre-activation), 2+b: block b
+  // gradient operands of the weight-gradient GEMMs are stored M-TILE MAJOR: column c of row r lives at
+  // plane (c >> 4) * npad * 16 + r * 16 + (c & 15), so that maf_dw_kernel streams a (256 rows x 16 columns) tile
+  // as one contiguous 16 KB block
+  float* GP;               // DP / 16 planes: gradient wrt the raw spline parameters, 16*PT columns per dim
+  float* ACT;              // (n, (NB+1)*64) h_0 .. h_NB, row major (inputs of the GEMMs)
+  float* G;                // (NB+2) x 4 planes; slot 0: d/d(a1), slot 1: d/d(context pre-activation), 2+b: block b
+  long long npad;          // rows padded to whole dW chunks
   float* CTX;              // (n, MAF_CW) conditioner input rows [z ; standardized context]
   int t, is_last;
 };
@@ -360,6 +364,16 @@ __device__ __forceinline__ void store_frag_rows(float* __restrict__ dst, int ld,
   for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[row * ld + 16 * mt + 4 * r + id.g] = v[mt][r];
+}
+
+// D fragments -> four m-tile planes (tile-major gradient operand, see MafBwdArgs)
+__device__ __forceinline__ void store_frag_planes(float* __restrict__ plane0, long long npad, long long row, bool valid,
+                                                  const LaneId& id, const f4 (&v)[NSF_HT]) {
+  if (!valid) return;
+#pragma unroll
+  for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) plane0[(mt * npad + row) * 16 + 4 * r + id.g] = v[mt][r];
 }
 
 template <int K, int KSH, int VAR>
@@ -440,13 +454,14 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
     wave_lds_fence();
     // g_p rows -> HBM (operand of d Wf), 16*PT floats per (row, dim)
     for (int sl = 0; sl < nact; ++sl)
-      for (int k = id.g; k < mp.PTW; k += 4)
-        if (valid) a.GP[row * mp.DP + (2 * c + sl) * mp.PTW + k] = pst[sl * pl.DS + id.j * pl.PSW + k];
+      for (int k = id.g; k < mp.PTW; k += 4) {
+        const int col = (2 * c + sl) * mp.PTW + k;
+        if (valid) a.GP[((col >> 4) * a.npad + row) * 16 + (col & 15)] = pst[sl * pl.DS + id.j * pl.PSW + k];
+      }
     maf_wft_chunk<PT>(lds, LF, pl, id, pst, 2 * c, nact, gh);
     wave_lds_fence();
   }
   // ---- back through the feed-forward blocks: G_b = g (1 - h_{b+1}^2), g <- W_b^T G_b
-  const int GW = (MAF_MAX_NB + 2) * MAF_AW;
 #pragma unroll
   for (int b = MAF_MAX_NB - 1; b >= 0; --b) {
     if (b < NB) {
@@ -459,7 +474,7 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
           gb[mt][r] = gh[mt][r] * maf_act_grad<VAR>(hv);
           gh[mt][r] = 0.f;
         }
-      store_frag_rows(a.G + 64 * (2 + b), GW, row, valid, id, gb);
+      store_frag_planes(a.G + (long long)(4 * (2 + b)) * a.npad * 16, a.npad, row, valid, id, gb);
       gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + b], id, gb, gh);
     }
   }
@@ -476,8 +491,8 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
           gc[mt][r] = g0[mt][r] * (1.f - gt * gt);        // d / d(Wc c + bc)
         }
       }
-    store_frag_rows(a.G, GW, row, valid, id, g0);
-    if (VAR == 0) store_frag_rows(a.G + 64, GW, row, valid, id, gc);
+    store_frag_planes(a.G, a.npad, row, valid, id, g0);
+    if (VAR == 0) store_frag_planes(a.G + 4 * a.npad * 16, a.npad, row, valid, id, gc);
     gin[0] = {0.f, 0.f, 0.f, 0.f};
     gemm_T_breg<KSH, 1>(lds, S.lin[0], id, g0, gin);     // through the (masked) initial layer: dims < their own
 #pragma unroll
@@ -494,9 +509,10 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
 
 // ------------------------------------------------------------------ training: weight gradients
 struct MafLin {
-  const float* G;   // (n, ldg): per-row gradient wrt the layer's outputs (padded column layout, see group_pad)
+  const float* G;   // m-tile-major gradient wrt the layer's outputs: plane t = columns [16 t, 16 t + 16) of all rows
   const float* A;   // (n, lda): per-row inputs of the layer
-  int ldg, lda;
+  long long gts;    // floats between consecutive planes (= padded rows x 16)
+  int lda;
   int out, in;      // natural dims
   int group, group_pad;   // output o lives at column (o / group) * group_pad + o % group  (final layer: P -> 16*PT)
   int g_w, g_b;     // offsets inside the transform's parameter block
@@ -508,57 +524,129 @@ struct MafDwArgs {
   int rows_per_chunk, nchunks, n_layer, D, P;
   float* partial;   // (nchunks, n_layer) for this transform
   const float* mask;   // optional (n_layer) 0/1 mask of this transform's parameter block (zuko adjacency masks)
+  int abl;             // timing experiments only (tools/ubench/maf_dw_bench.hip): 1 no MFMA sweep, 2 no G tile load,
+                       // 4 no input staging, 8 no write-out; 0 in the library
 };
 
+#define MAF_DW_ROWS 256    // rows per chunk (one workgroup per chunk and linear)
+#define MAF_DW_SA 68       // LDS row stride of the staged input tile: rows 4 apart sit 16 banks apart (ds_read_b32: 32 banks)
+#define MAF_DW_GS 20       // row stride of a wave's 16-column G tile (4 * 20 = 16 mod 32 as well)
+template <int NT>
+__device__ __forceinline__ void maf_dw_sweep(const float* __restrict__ ap, const float* __restrict__ bp, float one,
+                                             f4 (&acc)[4], f4& accb) {
+  constexpr int KS = MAF_DW_ROWS / 4;
+#pragma unroll 16
+  for (int s = 0; s < KS; ++s) {
+    const int kr = 16 * (s >> 2) + (s & 3);
+    const float a_ = ap[kr * MAF_DW_GS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA16(a_, bp[kr * MAF_DW_SA + 16 * nt], acc[nt]);
+    accb = MFMA16(a_, one, accb);
+  }
+}
+
 #ifdef MAF_MAIN_TU
+// dW = G^T A of one linear over one chunk of rows.  The chunk's input rows A (<= 64 columns) are staged in LDS once
+// (batched loads), every wave then sweeps its 16-output m-tiles: a tile of G (256 rows x 16 columns) goes through the
+// wave's private LDS region with coalesced 16-byte loads, the NEXT tile's loads are in flight while the current one
+// is contracted; K-step s covers rows krow(s) + 4 g (the conflict-free assignment of the NSF backward kernel's
+// dw_gemm).  Bias gradients: one more MFMA per K-step against a ones vector.  Masks are applied on the way out;
+// partial slabs are summed by maf_reduce_kernel.
+__device__ __forceinline__ void maf_dw_load_tile(const MafLin& L, long long r0, int mt, int lane, float4 (&v)[16]) {
+  // four lanes per row (lane l of load `it` holds row (64 it + l) / 4, columns 4 (l & 3) ..); the planes are padded
+  // to whole chunks, so every load is in bounds
+  const float4* gsrc = reinterpret_cast<const float4*>(L.G + (long long)mt * L.gts + r0 * 16);   // 16 KB contiguous
+#pragma unroll
+  for (int it = 0; it < 16; ++it) v[it] = gsrc[it * 64 + lane];
+}
+
 __global__ void __launch_bounds__(256)
 maf_dw_kernel(const MafDwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float As[];
   const MafLin& L = a.lin[blockIdx.y];
   const int chunk = blockIdx.x;
-  const long long r0 = (long long)chunk * a.rows_per_chunk;
-  long long r1 = r0 + a.rows_per_chunk;
+  const long long r0 = (long long)chunk * MAF_DW_ROWS;
+  long long r1 = r0 + MAF_DW_ROWS;
   if (r1 > a.n) r1 = a.n;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = (int)(r1 - r0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int mcols = (L.out + L.group - 1) / L.group * L.group_pad;   // padded output columns
   const int mtiles = (mcols + 15) / 16;
   const int ntiles = (L.in + 15) / 16;
+  float4 v[16];
+  if (wave < mtiles && !(a.abl & 2)) maf_dw_load_tile(L, r0, wave, lane, v);   // first G tile: under the A staging
+  if (!(a.abl & 4)) {
+    // thread = (column c, row phase): 64 rows each, loads issued 16 at a time (clamped addresses + selects: a
+    // predicated load would sit in its own basic block with its own s_waitcnt)
+    const int c = tid & 63, cc = c < L.in ? c : 0;
+    const float* ap0 = L.A + r0 * L.lda + cc;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = (tid >> 6) + 4 * (16 * b + u);
+        t[u] = ap0[(long long)r * L.lda];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = (tid >> 6) + 4 * (16 * b + u);
+        As[r * MAF_DW_SA + c] = (r < nrows && c < L.in) ? t[u] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
   float* part = a.partial + (long long)chunk * a.n_layer;
   const float one = (j == 0) ? 1.f : 0.f;
+  // mask inputs that do not depend on the m-tile: the degree of this lane's input column in every n-tile
+  int deg_in[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) deg_in[nt] = L.kind == 0 ? 16 * nt + j + 1 : maf_hidden_degree(16 * nt + j, a.D);
+  float* Gs = As + MAF_DW_ROWS * MAF_DW_SA + wave * (MAF_DW_ROWS * MAF_DW_GS);
+  const float* ap = Gs + 4 * g * MAF_DW_GS + j;
+  const float* bp = As + 4 * g * MAF_DW_SA + j;
   for (int mt = wave; mt < mtiles; mt += 4) {
     f4 acc[4], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = {0.f, 0.f, 0.f, 0.f};
-    const int mcol = 16 * mt + j;
-    const bool mok = mcol < mcols;
-#pragma unroll 4
-    for (long long k0 = r0; k0 < r1; k0 += 4) {
-      const long long row = k0 + g;
-      const bool ok = row < r1;
-      const float av = (ok && mok) ? L.G[row * L.ldg + mcol] : 0.f;
-      float bv[4];
+    if (!(a.abl & 2)) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int col = 16 * nt + j;
-        bv[nt] = (ok && nt < ntiles && col < L.in) ? L.A[row * L.lda + col] : 0.f;
+      for (int it = 0; it < 16; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 2;
+        const float4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4*>(Gs + row * MAF_DW_GS + 4 * (idx & 3)) = row < nrows ? v[it] : z;
       }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        if (nt < ntiles) acc[nt] = MFMA16(av, bv[nt], acc[nt]);
-      accb = MFMA16(av, ok ? one : 0.f, accb);
     }
+    wave_lds_fence();
+    // next tile: requested AFTER the fence (a fence drains vmcnt too) so that the loads fly under this sweep
+    if (!(a.abl & 2) && mt + 4 < mtiles) maf_dw_load_tile(L, r0, mt + 4, lane, v);
+    // one guard-free MFMA stream per input width (a guard per MFMA costs a basic block and an s_waitcnt each)
+    if (!(a.abl & 1))
+    switch (ntiles) {
+      case 1: maf_dw_sweep<1>(ap, bp, one, acc, accb); break;
+      case 2: maf_dw_sweep<2>(ap, bp, one, acc, accb); break;
+      case 3: maf_dw_sweep<3>(ap, bp, one, acc, accb); break;
+      default: maf_dw_sweep<4>(ap, bp, one, acc, accb); break;
+    }
+    wave_lds_fence();
+    if (!(a.abl & 8))
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = 16 * mt + 4 * g + r;           // padded output column of this accumulator row
       const int grp = m / L.group_pad, p = m - grp * L.group_pad;
       const int o = grp * L.group + p;
       if (p < L.group && o < L.out) {
+        const int deg_out = L.kind == 3 ? grp + 1 : maf_hidden_degree(o, a.D);   // kind 3: o / P + 1 with group = P
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int i = 16 * nt + j;
-          if (nt < ntiles && i < L.in)
-            part[L.g_w + o * L.in + i] =
-                (a.mask ? a.mask[L.g_w + o * L.in + i] != 0.f : maf_mask(L.kind, o, i, a.D, a.P)) ? acc[nt][r] : 0.f;
+          if (nt < ntiles && i < L.in) {
+            bool keep;
+            if (a.mask) keep = a.mask[L.g_w + o * L.in + i] != 0.f;
+            else keep = L.kind == 1 ? true : (L.kind == 3 ? deg_out > deg_in[nt] : deg_out >= deg_in[nt]);
+            part[L.g_w + o * L.in + i] = keep ? acc[nt][r] : 0.f;
+          }
         }
         if (j == 0) part[L.g_b + o] = accb[r];
       }
