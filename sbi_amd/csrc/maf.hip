@@ -6,6 +6,22 @@
 #define MAF_MAIN_TU
 #include "maf_kernel.h"
 
+// launch wrappers of the two non-template kernels defined in this translation unit: the generic NSF training
+// path (nsf_gtrain.hip) contracts its weight gradients with the same kernels
+int maf_launch_dw(const MafDwArgs& d, int nlin, hipStream_t st) {
+  const int dw_lds = (MAF_DW_ROWS * MAF_DW_SA + 4 * MAF_DW_ROWS * MAF_DW_GS) * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)maf_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(maf_dw_kernel, dim3(d.nchunks, nlin), dim3(256), (size_t)dw_lds, st, d);
+  return (int)hipGetLastError();
+}
+int maf_launch_reduce(const float* partial, float* out, int n_layer, int nchunks, int T, hipStream_t st) {
+  const int64_t total = (int64_t)T * n_layer;
+  hipLaunchKernelGGL(maf_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, out, n_layer,
+                     nchunks, T);
+  return (int)hipGetLastError();
+}
+
 static int m_round_up(int v, int m) { return (v + m - 1) / m * m; }
 static int m_two_odd(int v) {
   int x = (v + 1) / 2;
@@ -285,7 +301,8 @@ extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const flo
     const int64_t gts = w.npad * 16;     // floats per m-tile plane
     auto set = [&](int i, const float* G, const float* A, int lda, const LinDesc& L, int group, int gpad, int kind) {
       d.lin[i].G = G; d.lin[i].gts = gts; d.lin[i].A = A; d.lin[i].lda = lda;
-      d.lin[i].out = L.out; d.lin[i].in = L.in; d.lin[i].group = group; d.lin[i].group_pad = gpad;
+      d.lin[i].out = L.out; d.lin[i].in = L.in; d.lin[i].in_total = L.in; d.lin[i].col0 = 0;
+      d.lin[i].group = group; d.lin[i].group_pad = gpad;
       d.lin[i].g_w = L.g_w; d.lin[i].g_b = L.g_b; d.lin[i].kind = kind;
     };
     // largest first (the final layer has D*(3K-1) outputs)
@@ -298,17 +315,8 @@ extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const flo
     d.n = n; d.rows_per_chunk = w.rows_per_chunk; d.nchunks = w.nchunks; d.n_layer = mp.n_layer;
     d.D = D; d.P = mp.n.P;
     d.partial = workspace + w.part + (int64_t)t * w.nchunks * mp.n_layer;
-    {
-      const int dw_lds = (MAF_DW_ROWS * MAF_DW_SA + 4 * MAF_DW_ROWS * MAF_DW_GS) * 4;
-      hipError_t e = hipFuncSetAttribute((const void*)maf_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds);
-      if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(maf_dw_kernel, dim3(w.nchunks, nlin), dim3(256), (size_t)dw_lds, st, d);
-    }
-    rc = (int)hipGetLastError();
+    rc = maf_launch_dw(d, nlin, st);
     if (rc) return rc;
   }
-  const int64_t total = (int64_t)T * mp.n_layer;
-  hipLaunchKernelGGL(maf_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace + w.part,
-                     grad_out, mp.n_layer, w.nchunks, T);
-  return (int)hipGetLastError();
+  return maf_launch_reduce(workspace + w.part, grad_out, mp.n_layer, w.nchunks, T, st);
 }

@@ -513,13 +513,15 @@ struct MafLin {
   const float* A;   // (n, lda): per-row inputs of the layer
   long long gts;    // floats between consecutive planes (= padded rows x 16)
   int lda;
-  int out, in;      // natural dims
+  int out, in;      // natural dims (`in` <= 64: a wider input is handed over as several column pieces)
+  int in_total, col0;   // row length of the weight in the parameter block and first column of this piece
   int group, group_pad;   // output o lives at column (o / group) * group_pad + o % group  (final layer: P -> 16*PT)
   int g_w, g_b;     // offsets inside the transform's parameter block
   int kind;         // mask kind (maf_mask) when no mask buffer is given
 };
+#define MAF_DW_MAX_LIN 28
 struct MafDwArgs {
-  MafLin lin[3 + MAF_MAX_NB];
+  MafLin lin[MAF_DW_MAX_LIN];
   long long n;
   int rows_per_chunk, nchunks, n_layer, D, P;
   float* partial;   // (nchunks, n_layer) for this transform
@@ -642,13 +644,14 @@ maf_dw_kernel(const MafDwArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
           const int i = 16 * nt + j;
           if (nt < ntiles && i < L.in) {
+            const int widx = L.g_w + o * L.in_total + L.col0 + i;
             bool keep;
-            if (a.mask) keep = a.mask[L.g_w + o * L.in + i] != 0.f;
+            if (a.mask) keep = a.mask[widx] != 0.f;
             else keep = L.kind == 1 ? true : (L.kind == 3 ? deg_out > deg_in[nt] : deg_out >= deg_in[nt]);
-            part[L.g_w + o * L.in + i] = keep ? acc[nt][r] : 0.f;
+            part[widx] = keep ? acc[nt][r] : 0.f;
           }
         }
-        if (j == 0) part[L.g_b + o] = accb[r];
+        if (j == 0 && L.col0 == 0) part[L.g_b + o] = accb[r];
       }
     }
   }
@@ -673,6 +676,10 @@ maf_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad, i
 }
 
 #endif
+
+// defined in maf.hip (the translation unit that owns maf_dw_kernel / maf_reduce_kernel)
+int maf_launch_dw(const MafDwArgs& d, int nlin, hipStream_t st);
+int maf_launch_reduce(const float* partial, float* out, int n_layer, int nchunks, int T, hipStream_t st);
 
 // ------------------------------------------------------------------ per-K launchers (instantiated per TU)
 template <int K, int KSH, bool INV, int VAR>

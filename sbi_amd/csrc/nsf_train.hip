@@ -61,6 +61,16 @@ __global__ void neg_copy_kernel(const float* __restrict__ in, float* __restrict_
 }
 
 // ------------------------------------------------------------------ host side
+// generic training pass (nsf_gtrain.hip) for the shapes the wave-specialised backward kernel refuses
+int64_t nsf_g_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n);
+int nsf_g_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
+                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* workspace, void* stream);
+int nsf_g_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed, const float* zstats,
+                         const float* x, int64_t n, int64_t x_rows, const float* row_weight, float uniform_weight,
+                         float* grad_out, float* grad_theta_out, float* workspace, void* stream);
+const float* nsf_g_logp(const sbi_amd_nsf_config* cfg, int64_t n, const float* workspace);
+static bool fast_path_refuses(int rc) { return rc == SBI_AMD_E_UNSUPPORTED || rc == SBI_AMD_E_LDS; }
+
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
                        float* z_stash, float* astash, void* stream);
@@ -90,6 +100,10 @@ extern "C" int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* 
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   TrainPlan tp;
   rc = build_train_plan(pl, n > 0 ? n : 1, &tp);
+  if (fast_path_refuses(rc)) {
+    const int64_t g = nsf_g_workspace_floats(cfg, n);
+    return (g >= 0 || g == SBI_AMD_E_LDS) ? g : rc;
+  }
   if (rc) return rc;
   int64_t a, b, c, d, e, f, g;
   return ws_layout(pl, tp, n > 0 ? n : 1, &a, &b, &c, &d, &e, &f, &g);
@@ -123,6 +137,10 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   TrainPlan tp;
   rc = build_train_plan(pl, n, &tp);
+  if (fast_path_refuses(rc)) {
+    const int rg = nsf_g_train_forward(cfg, packed, zstats, theta, x, n, x_rows, logp_out, workspace, stream);
+    return fast_path_refuses(rg) ? rc : rg;
+  }
   if (rc) return rc;
   int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
   ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
@@ -153,6 +171,12 @@ extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const f
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   TrainPlan tp;
   rc = build_train_plan(pl, n, &tp);
+  if (fast_path_refuses(rc)) {
+    if (grad_x_out) return rc;   // d loss / d embedded x comes from the wave-specialised kernel only
+    const int rg = nsf_g_train_backward(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight,
+                                        grad_out, grad_theta_out, workspace, stream);
+    return fast_path_refuses(rg) ? rc : rg;
+  }
   if (rc) return rc;
   tp.grad_x = grad_x_out;
   hipStream_t st = (hipStream_t)stream;
@@ -198,11 +222,19 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
     TrainPlan tp;
     rc = nsf_build_plan(cfg, TR_NW, &pl);
     if (rc && rc != SBI_AMD_E_LDS) return rc;
-    if ((rc = build_train_plan(pl, n, &tp))) return rc;
-    int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
-    ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
-    hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       workspace + o_logp, loss_out, (long long)n);
+    const float* logp;
+    rc = build_train_plan(pl, n, &tp);
+    if (fast_path_refuses(rc)) {
+      logp = nsf_g_logp(cfg, n, workspace);
+      if (!logp) return rc;
+    } else {
+      if (rc) return rc;
+      int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
+      ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
+      logp = workspace + o_logp;
+    }
+    hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logp,
+                       loss_out, (long long)n);
   }
   return sbi_amd_nsf_train_backward(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
                                     grad_theta_out, grad_x_out, workspace, stream);

@@ -41,6 +41,17 @@ CONFIGS = [
     dict(D=4, C=4, hidden_features=64, num_transforms=3, num_blocks=1),
     dict(D=12, C=10, hidden_features=64, num_transforms=2, num_bins=8),
     dict(D=1, C=5, hidden_features=64, num_transforms=2),
+    # shapes the wave-specialised backward refuses: they train on the generic row-parallel backward + split-K
+    # weight-gradient GEMMs (csrc/nsf_gtrain_kernel.h)
+    dict(D=10, C=10, num_blocks=3, num_transforms=2),
+    dict(D=20, C=10, num_transforms=2),
+    dict(D=32, C=6, num_transforms=3, num_bins=8),
+    dict(D=16, C=40, num_transforms=2),
+    dict(D=12, C=70, num_transforms=2, hidden_features=48),
+    # (seeds 2 and 3 agree to 3e-6; seed 1 has a row on an fp32 knot like the D=1 case below: 1.1e-4)
+    dict(D=6, C=60, num_transforms=2, num_blocks=4, hidden_features=32, seed=2),
+    dict(D=6, C=60, num_transforms=2, num_blocks=4, hidden_features=32, seed=3),
+    dict(D=17, C=3, num_transforms=3, num_bins=5, num_blocks=1),
     # seed 2: with seed 1, row 91 enters the last transform exactly ON an fp32 knot, where the spline's second
     # derivative (hence d loss/d params) is two-valued and either bin is a correct answer
     dict(D=1, C=7, hidden_features=32, num_transforms=3, seed=2),

@@ -21,7 +21,7 @@ int main() {
   int g = 0;
   const long long gts = n * 16;
   auto set = [&](int i, const float* Gp, int, const float* A, int lda, int out, int in, int group, int gpad, int kind) {
-    d.lin[i].G = Gp; d.lin[i].gts = gts; d.lin[i].A = A; d.lin[i].lda = lda; d.lin[i].out = out; d.lin[i].in = in;
+    d.lin[i].G = Gp; d.lin[i].gts = gts; d.lin[i].A = A; d.lin[i].lda = lda; d.lin[i].out = out; d.lin[i].in = in; d.lin[i].in_total = in; d.lin[i].col0 = 0;
     d.lin[i].group = group; d.lin[i].group_pad = gpad; d.lin[i].g_w = g; g += out * in; d.lin[i].g_b = g; g += out;
     d.lin[i].kind = kind;
   };
