@@ -16,6 +16,11 @@ static int g_build_plan(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, G
   int rc = nsf_build_plan(cfg, 1, pl);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   if (pl->ctx_mlp) return SBI_AMD_E_UNSUPPORTED;     // theta-dim 1 trains on the wave-specialised kernel only
+  {                                                  // the stash-writing forward pass must fit as well
+    NsfPlan fw;
+    int fnw;
+    if ((rc = nsf_plan_for_rows(cfg, n, &fw, &fnw))) return rc;
+  }
   const int D = pl->D, C = pl->C, NB = pl->NB;
   const int d_id_max = pl->shape[0].d_id > pl->shape[1].d_id ? pl->shape[0].d_id : pl->shape[1].d_id;
   const int d_tr_max = pl->shape[0].d_tr;

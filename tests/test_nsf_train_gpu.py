@@ -92,8 +92,12 @@ def test_loss_and_param_grad_match_autograd(cfg):
         assert (a - b).abs().max().item() <= tol, key
 
 
-def test_autograd_bridge_theta_and_param_grads():
-    oracle, est, theta_d, x_d = matched_pair(D=4, C=7)
+GENERIC = dict(D=18, C=20, num_transforms=2, num_blocks=3)   # trains on the generic backward (nsf_gtrain_kernel.h)
+
+
+@pytest.mark.parametrize("cfg", [dict(D=4, C=7), GENERIC], ids=["fast", "generic"])
+def test_autograd_bridge_theta_and_param_grads(cfg):
+    oracle, est, theta_d, x_d = matched_pair(**cfg)
     theta, x = theta_d[:200], x_d[:200]
     w = torch.linspace(0.5, 1.5, 200)
     th_o = theta.clone().requires_grad_(True)
@@ -156,12 +160,14 @@ def test_training_reduces_loss_full_batch_65536():
     assert last < first - 0.05
 
 
-@pytest.mark.parametrize("n", [1, 15, 16, 17, 64, 65, 129])
-def test_tiny_and_ragged_batches_match_autograd(n):
-    """Tile (64 rows) and wave-tile (16 rows) boundaries: a single row, one short of / one past a boundary."""
+@pytest.mark.parametrize("cfg", [dict(D=4, C=7), GENERIC], ids=["fast", "generic"])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 64, 65, 129, 257])
+def test_tiny_and_ragged_batches_match_autograd(n, cfg):
+    """Tile (64 rows), wave-tile (16 rows) and split-K chunk (256 rows) boundaries: a single row, one short of /
+    one past a boundary."""
     from sbi_amd.inference.trainers.fused import FusedTrainStep
 
-    oracle, est, theta_d, x_d = matched_pair(D=4, C=7)
+    oracle, est, theta_d, x_d = matched_pair(**cfg)
     theta, x = theta_d[:n], x_d[:n]
     w = torch.linspace(0.5, 1.5, n)
     oracle.zero_grad()
@@ -182,11 +188,38 @@ def test_tiny_and_ragged_batches_match_autograd(n):
     assert (got - gref).abs().max() <= 3e-4 * gref.abs().max()
 
 
-def test_single_condition_broadcast_in_training_pass():
+def test_generic_backward_trains_wide_problem_through_npe():
+    """theta-dim 20, x-dim 30: NPE.train() on the generic backward lowers the validation loss and the
+    posterior tightens around the true parameter of a linear-Gaussian task."""
+    from sbi_amd.inference import NPE
+    from sbi_amd.neural_nets import NSFConfig
+
+    torch.manual_seed(0)
+    D, Cx = 20, 30
+    prior = torch.distributions.MultivariateNormal(torch.zeros(D, device="cuda"), torch.eye(D, device="cuda"))
+    theta = prior.sample((20000,))
+    A = torch.randn(D, Cx, device="cuda") / D**0.5
+    x = theta @ A + 0.1 * torch.randn(20000, Cx, device="cuda")
+    inf = NPE(prior=prior, density_estimator=NSFConfig(num_transforms=3), device="cuda")
+    inf.append_simulations(theta.cpu(), x.cpu())
+    inf.train(training_batch_size=4096, max_num_epochs=40)
+    s = inf.summary
+    assert s["validation_loss"][-1] < s["validation_loss"][0] - 1.0
+    post = inf.build_posterior()
+    th0 = prior.sample((1,))
+    x0 = th0 @ A
+    draws = post.sample((2000,), x=x0, show_progress_bars=False)
+    assert torch.isfinite(draws).all()
+    # x pins down the 20 parameters through a full-rank 20 x 30 map with noise 0.1: posterior mean near th0
+    assert (draws.mean(0) - th0[0]).abs().mean() < 0.5 * th0[0].abs().mean() + 0.2
+
+
+@pytest.mark.parametrize("cfg", [dict(D=4, C=7), GENERIC], ids=["fast", "generic"])
+def test_single_condition_broadcast_in_training_pass(cfg):
     """x with one row (the sampler / MAP case: every theta conditioned on the same x_o)."""
     from sbi_amd.neural_nets.estimators.nsf_flow import loss_fwd_bwd
 
-    oracle, est, theta_d, x_d = matched_pair(D=4, C=7)
+    oracle, est, theta_d, x_d = matched_pair(**cfg)
     n = 300
     theta, x1 = theta_d[:n], x_d[:1]
     oracle.zero_grad()
