@@ -69,7 +69,10 @@ int nsf_g_train_backward(const sbi_amd_nsf_config* cfg, const float* params, con
                          const float* x, int64_t n, int64_t x_rows, const float* row_weight, float uniform_weight,
                          float* grad_out, float* grad_theta_out, float* workspace, void* stream);
 const float* nsf_g_logp(const sbi_amd_nsf_config* cfg, int64_t n, const float* workspace);
-static bool fast_path_refuses(int rc) { return rc == SBI_AMD_E_UNSUPPORTED || rc == SBI_AMD_E_LDS; }
+// SBI_AMD_ABLATE bit 2048 (diagnostic): route every shape through the generic pass
+static bool fast_path_refuses(int rc) {
+  return rc == SBI_AMD_E_UNSUPPORTED || rc == SBI_AMD_E_LDS || (rc == 0 && (sbi_amd_dbg_ablate() & 2048));
+}
 
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
