@@ -23,8 +23,9 @@ _ERRORS = {
     "(need 1<=D<=64, H<=64, num_bins in {4,5,8,10,16}, num_transforms<=16, num_blocks<=4)",
     E_BADARG: "bad argument",
     E_LDS: "configuration needs more than 160 KiB of LDS per workgroup (one transform's weight image plus the "
-    "kernel's tiles must fit: e.g. training with hidden_features=50, 10 bins reaches theta-dim 15 with x-dim 20, "
-    "hidden_features=60 reaches theta-dim = x-dim = 10; smaller hidden_features / theta-dim / x-dim fit more)",
+    "kernel's tiles must fit: e.g. with hidden_features=50, 10 bins, 2 blocks training reaches x-dim 94 at theta-dim "
+    "10, x-dim 54 at theta-dim 20, theta-dim 24 with x-dim 32; hidden_features=32 reaches theta-dim 32 with x-dim 48; "
+    "smaller hidden_features / theta-dim / x-dim / num_bins fit more, an embedding_net shrinks x-dim)",
 }
 
 
