@@ -12,7 +12,13 @@
 #define RED_GROUPS 8
 __global__ void __launch_bounds__(64 * RED_GROUPS)
 nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __restrict__ params,
-                       const float* __restrict__ partial, float* __restrict__ grad) {
+                       const float* __restrict__ partial, float* __restrict__ grad,
+                       const float* __restrict__ logp, float* __restrict__ loss_out, long long n_rows) {
+  // rider (saves a launch per step): the per-row loss of the one-call form, loss = -log p
+  if (loss_out)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
+         i += (long long)gridDim.x * blockDim.x)
+      loss_out[i] = -logp[i];
   __shared__ float red[RED_GROUPS][64];
   __shared__ float red_sgl[RED_GROUPS][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -158,12 +164,12 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
   return 0;
 }
 
-// backward half: consumes the stash the preceding sbi_amd_nsf_train_forward left in `workspace`
-// (same cfg, n, x, x_rows, packed image and stream order); grad_out = d( sum_n w_n * (-log p_n) ) / d params
-extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
-                                          const float* zstats, const float* x, int64_t n, int64_t x_rows,
-                                          const float* row_weight, float uniform_weight, float* grad_out,
-                                          float* grad_theta_out, float* grad_x_out, float* workspace, void* stream) {
+// backward half; loss_out (optional) = -log p of the stash's forward pass, written by the reduction kernel
+static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
+                               const float* zstats, const float* x, int64_t n, int64_t x_rows,
+                               const float* row_weight, float uniform_weight, float* grad_out,
+                               float* grad_theta_out, float* grad_x_out, float* workspace, float* loss_out,
+                               void* stream) {
   if (!cfg || !params || !packed || !zstats || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
     return SBI_AMD_E_BADARG;
   if (grad_x_out && x_rows != n) return SBI_AMD_E_BADARG;   // one context row per theta row (no reduction here)
@@ -176,6 +182,12 @@ extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const f
   rc = build_train_plan(pl, n, &tp);
   if (fast_path_refuses(rc)) {
     if (grad_x_out) return rc;   // d loss / d embedded x comes from the wave-specialised kernel only
+    if (loss_out) {
+      const float* logp = nsf_g_logp(cfg, n, workspace);
+      if (!logp) return rc;
+      hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logp,
+                         loss_out, (long long)n);
+    }
     const int rg = nsf_g_train_backward(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight,
                                         grad_out, grad_theta_out, workspace, stream);
     return fast_path_refuses(rg) ? rc : rg;
@@ -206,8 +218,18 @@ extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const f
     if (rc) return rc;
   }
   hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64 * RED_GROUPS), 0, st, pl, tp, params,
-                     partial, grad_out);
+                     partial, grad_out, (const float*)(workspace + o_logp), loss_out, (long long)n);
   return (int)hipGetLastError();
+}
+
+// backward half: consumes the stash the preceding sbi_amd_nsf_train_forward left in `workspace`
+// (same cfg, n, x, x_rows, packed image and stream order); grad_out = d( sum_n w_n * (-log p_n) ) / d params
+extern "C" int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
+                                          const float* zstats, const float* x, int64_t n, int64_t x_rows,
+                                          const float* row_weight, float uniform_weight, float* grad_out,
+                                          float* grad_theta_out, float* grad_x_out, float* workspace, void* stream) {
+  return train_backward_impl(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
+                             grad_theta_out, grad_x_out, workspace, nullptr, stream);
 }
 
 // one-call form: forward + backward with weights known up front (plain NPE loss)
@@ -220,25 +242,6 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
     return SBI_AMD_E_BADARG;
   int rc = sbi_amd_nsf_train_forward(cfg, packed, zstats, theta, x, n, x_rows, nullptr, workspace, stream);
   if (rc) return rc;
-  if (loss_out) {
-    NsfPlan pl;
-    TrainPlan tp;
-    rc = nsf_build_plan(cfg, TR_NW, &pl);
-    if (rc && rc != SBI_AMD_E_LDS) return rc;
-    const float* logp;
-    rc = build_train_plan(pl, n, &tp);
-    if (fast_path_refuses(rc)) {
-      logp = nsf_g_logp(cfg, n, workspace);
-      if (!logp) return rc;
-    } else {
-      if (rc) return rc;
-      int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
-      ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
-      logp = workspace + o_logp;
-    }
-    hipLaunchKernelGGL(neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logp,
-                       loss_out, (long long)n);
-  }
-  return sbi_amd_nsf_train_backward(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
-                                    grad_theta_out, grad_x_out, workspace, stream);
+  return train_backward_impl(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
+                             grad_theta_out, grad_x_out, workspace, loss_out, stream);
 }

@@ -156,8 +156,11 @@ class FusedTrainStep:
                 _lib.ptr(self.scratch), _lib.current_stream(dev),
             )
         _lib.check(rc, "adam_clip_step")
-        # parameters changed in place behind autograd's back: invalidate the packed image
-        self.net.__dict__.pop("_packed_cache", None)
+        # parameters changed in place behind autograd's back: invalidate the packed image (the buffer itself is kept:
+        # its alignment gaps are zero and stay zero, a fresh torch.zeros per step is a launch for nothing)
+        cache = self.net.__dict__.get("_packed_cache")
+        if cache is not None:
+            self.net.__dict__["_packed_cache"] = (None, cache[1])
 
     def step(self, theta: Tensor, x: Tensor, global_batch: Optional[int] = None) -> Tensor:
         losses = self.loss_and_grad(theta, x, global_batch)
