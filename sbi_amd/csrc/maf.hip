@@ -9,11 +9,36 @@
 // launch wrappers of the two non-template kernels defined in this translation unit: the generic NSF training
 // path (nsf_gtrain.hip) contracts its weight gradients with the same kernels
 int maf_launch_dw(const MafDwArgs& d, int nlin, hipStream_t st) {
-  const int dw_lds = (MAF_DW_ROWS * MAF_DW_SA + 4 * MAF_DW_ROWS * MAF_DW_GS) * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)maf_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds);
+  hipError_t e = hipFuncSetAttribute((const void*)maf_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     MAF_DW_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(maf_dw_kernel, dim3(d.nchunks, nlin), dim3(256), (size_t)dw_lds, st, d);
-  return (int)hipGetLastError();
+  // the callers describe whole linears; a workgroup keeps at most 4 waves x MAF_DW_MTW m-tiles of accumulators, so
+  // wider outputs (the final layer: D x 16 PT columns) are cut into pieces here; largest pieces first
+  MafDwArgs x = d;
+  int np = 0;
+  auto flush = [&]() {
+    if (np == 0) return 0;
+    hipLaunchKernelGGL(maf_dw_kernel, dim3(d.nchunks, np), dim3(256), (size_t)MAF_DW_LDS_BYTES, st, x);
+    np = 0;
+    return (int)hipGetLastError();
+  };
+  const int cap = 4 * MAF_DW_MTW;
+  for (int pass = 0; pass < 2; ++pass)          // pass 0: full-size pieces, pass 1: the remainders
+    for (int i = 0; i < nlin; ++i) {
+      const MafLin& L = d.lin[i];
+      const int mcols = (L.out + L.group - 1) / L.group * L.group_pad;
+      const int mtiles = (mcols + 15) / 16;
+      for (int mt0 = 0; mt0 < mtiles; mt0 += cap) {
+        const int mtn = mtiles - mt0 < cap ? mtiles - mt0 : cap;
+        if ((mtn == cap) != (pass == 0)) continue;
+        if (np == MAF_DW_MAX_LIN) { const int rc = flush(); if (rc) return rc; }
+        x.lin[np] = L;
+        x.lin[np].mt0 = mt0;
+        x.lin[np].mtn = mtn;
+        ++np;
+      }
+    }
+  return flush();
 }
 int maf_launch_reduce(const float* partial, float* out, int n_layer, int nchunks, int T, hipStream_t st) {
   const int64_t total = (int64_t)T * n_layer;
@@ -227,14 +252,14 @@ static MafWs maf_ws_layout(const MafPlan& mp, int64_t n) {
   w.logp = take(n);
   w.gza = take(n * D);
   w.gzb = take(n * D);
-  const int64_t npad = (n + MAF_DW_ROWS - 1) / MAF_DW_ROWS * MAF_DW_ROWS;   // the dW kernel reads whole chunks
+  const int64_t npad = (n + MAF_DW_CHUNK - 1) / MAF_DW_CHUNK * MAF_DW_CHUNK;   // the dW kernel reads whole chunks
   w.npad = npad;
   w.gp = take(npad * mp.DP);
   w.act = take(npad * (MAF_MAX_NB + 1) * MAF_AW);
   w.gbuf = take(npad * (MAF_MAX_NB + 2) * MAF_AW);
   w.ctx = take(npad * MAF_CW);
-  w.rows_per_chunk = MAF_DW_ROWS;
-  w.nchunks = (int)((n + MAF_DW_ROWS - 1) / MAF_DW_ROWS);
+  w.rows_per_chunk = MAF_DW_CHUNK;
+  w.nchunks = (int)((n + MAF_DW_CHUNK - 1) / MAF_DW_CHUNK);
   w.part = take((int64_t)T * w.nchunks * mp.n_layer);
   w.total = o;
   return w;

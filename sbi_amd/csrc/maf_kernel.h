@@ -518,8 +518,9 @@ struct MafLin {
   int group, group_pad;   // output o lives at column (o / group) * group_pad + o % group  (final layer: P -> 16*PT)
   int g_w, g_b;     // offsets inside the transform's parameter block
   int kind;         // mask kind (maf_mask) when no mask buffer is given
+  int mt0, mtn;     // m-tile range of this piece (filled in by maf_launch_dw: at most 4 * MAF_DW_MTW tiles each)
 };
-#define MAF_DW_MAX_LIN 28
+#define MAF_DW_MAX_LIN 44
 struct MafDwArgs {
   MafLin lin[MAF_DW_MAX_LIN];
   long long n;
@@ -530,12 +531,22 @@ struct MafDwArgs {
                        // 4 no input staging, 8 no write-out; 0 in the library
 };
 
-#define MAF_DW_ROWS 256    // rows per chunk (one workgroup per chunk and linear)
+#ifndef MAF_DW_ROWS
+#define MAF_DW_ROWS 128    // rows per sub-chunk staged in LDS (multiple of 64)
+#endif
+#ifndef MAF_DW_SUB
+#define MAF_DW_SUB 4       // sub-chunks per workgroup: the accumulators persist, ONE partial slab per MAF_DW_CHUNK rows
+#endif
+#define MAF_DW_CHUNK (MAF_DW_ROWS * MAF_DW_SUB)
+#define MAF_DW_MTW 4       // m-tiles per wave and piece (their accumulators live in registers across the sub-chunks)
+#define MAF_DW_TV (MAF_DW_ROWS / 16)   // float4 per lane of one 16-column G tile
+#define MAF_DW_AV (MAF_DW_ROWS / 4)    // staged input values per thread
 #define MAF_DW_SA 68       // LDS row stride of the staged input tile: rows 4 apart sit 16 banks apart (ds_read_b32: 32 banks)
 #define MAF_DW_GS 20       // row stride of a wave's 16-column G tile (4 * 20 = 16 mod 32 as well)
+#define MAF_DW_LDS_BYTES ((MAF_DW_ROWS * MAF_DW_SA + 4 * MAF_DW_ROWS * MAF_DW_GS) * 4)
 template <int NT>
-__device__ __forceinline__ void maf_dw_sweep(const float* __restrict__ ap, const float* __restrict__ bp, float one,
-                                             f4 (&acc)[4], f4& accb) {
+__device__ __forceinline__ void maf_dw_sweep(const float* __restrict__ ap, const float* __restrict__ bp,
+                                             f4 (&acc)[4]) {
   constexpr int KS = MAF_DW_ROWS / 4;
 #pragma unroll 16
   for (int s = 0; s < KS; ++s) {
@@ -543,99 +554,138 @@ __device__ __forceinline__ void maf_dw_sweep(const float* __restrict__ ap, const
     const float a_ = ap[kr * MAF_DW_GS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA16(a_, bp[kr * MAF_DW_SA + 16 * nt], acc[nt]);
-    accb = MFMA16(a_, one, accb);
   }
 }
 
 #ifdef MAF_MAIN_TU
-// dW = G^T A of one linear over one chunk of rows.  The chunk's input rows A (<= 64 columns) are staged in LDS once
-// (batched loads), every wave then sweeps its 16-output m-tiles: a tile of G (256 rows x 16 columns) goes through the
-// wave's private LDS region with coalesced 16-byte loads, the NEXT tile's loads are in flight while the current one
-// is contracted; K-step s covers rows krow(s) + 4 g (the conflict-free assignment of the NSF backward kernel's
-// dw_gemm).  Bias gradients: one more MFMA per K-step against a ones vector.  Masks are applied on the way out;
-// partial slabs are summed by maf_reduce_kernel.
-__device__ __forceinline__ void maf_dw_load_tile(const MafLin& L, long long r0, int mt, int lane, float4 (&v)[16]) {
+// dW = G^T A of one linear (one piece of <= 16 m-tiles of it) over MAF_DW_SUB sub-chunks of MAF_DW_ROWS rows.  Per
+// sub-chunk the input rows A (<= 64 columns) are staged in LDS by the whole workgroup, then every wave contracts its
+// m-tiles: a tile of G (ROWS x 16) goes through the wave's private LDS region with coalesced 16-byte loads.  Nothing
+// waits on HBM in steady state: the NEXT G tile (next m-tile, or the first one of the next sub-chunk) and the NEXT
+// sub-chunk's input rows are requested before the current tile's MFMA sweep and land under it; two workgroups per CU
+// (76 KB of LDS each) cover what is left.  The accumulators of all the wave's m-tiles stay in registers across the
+// sub-chunks, so one partial slab is written per 512 rows.  K-step s covers rows krow(s) + 4 g (the conflict-free
+// assignment of the NSF backward kernel's dw_gemm).  Bias gradients (column sums of G): VALU adds on the tile's
+// registers on their way into LDS, one cross-lane reduction at the end.
+// Masks are applied on the way out; partial slabs are summed by maf_reduce_kernel.
+__device__ __forceinline__ void maf_dw_load_tile(const MafLin& L, long long r0, int mt, int lane, float4 (&v)[MAF_DW_TV]) {
   // four lanes per row (lane l of load `it` holds row (64 it + l) / 4, columns 4 (l & 3) ..); the planes are padded
   // to whole chunks, so every load is in bounds
-  const float4* gsrc = reinterpret_cast<const float4*>(L.G + (long long)mt * L.gts + r0 * 16);   // 16 KB contiguous
+  const float4* gsrc = reinterpret_cast<const float4*>(L.G + (long long)(L.mt0 + mt) * L.gts + r0 * 16);
 #pragma unroll
-  for (int it = 0; it < 16; ++it) v[it] = gsrc[it * 64 + lane];
+  for (int it = 0; it < MAF_DW_TV; ++it) v[it] = gsrc[it * 64 + lane];
+}
+// thread = (column c, row phase): rows phase + 4 u (clamped addresses + selects at the LDS store: a predicated load
+// would sit in its own basic block with its own s_waitcnt)
+__device__ __forceinline__ void maf_dw_load_rows(const MafLin& L, long long r0, int tid, float (&t)[MAF_DW_AV]) {
+  const int c = tid & 63, cc = c < L.in ? c : 0;
+  const float* ap0 = L.A + (r0 + (tid >> 6)) * L.lda + cc;
+#pragma unroll
+  for (int u = 0; u < MAF_DW_AV; ++u) t[u] = ap0[(long long)(4 * u) * L.lda];
+}
+// orders this wave's LDS writes before its LDS reads WITHOUT draining the vector-memory counter (the prefetches in
+// flight must stay in flight): DS ops of one wave execute in issue order, the asm only pins the compiler
+__device__ __forceinline__ void maf_dw_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 maf_dw_kernel(const MafDwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float As[];
   const MafLin& L = a.lin[blockIdx.y];
   const int chunk = blockIdx.x;
-  const long long r0 = (long long)chunk * MAF_DW_ROWS;
-  long long r1 = r0 + MAF_DW_ROWS;
-  if (r1 > a.n) r1 = a.n;
-  const int nrows = (int)(r1 - r0);
+  const long long R0 = (long long)chunk * MAF_DW_CHUNK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int mcols = (L.out + L.group - 1) / L.group * L.group_pad;   // padded output columns
-  const int mtiles = (mcols + 15) / 16;
+  const int mtn = L.mtn;
   const int ntiles = (L.in + 15) / 16;
-  float4 v[16];
-  if (wave < mtiles && !(a.abl & 2)) maf_dw_load_tile(L, r0, wave, lane, v);   // first G tile: under the A staging
-  if (!(a.abl & 4)) {
-    // thread = (column c, row phase): 64 rows each, loads issued 16 at a time (clamped addresses + selects: a
-    // predicated load would sit in its own basic block with its own s_waitcnt)
-    const int c = tid & 63, cc = c < L.in ? c : 0;
-    const float* ap0 = L.A + r0 * L.lda + cc;
+  long long left = a.n - R0;
+  int nsub = left <= 0 ? 0 : (int)((left + MAF_DW_ROWS - 1) / MAF_DW_ROWS);
+  if (nsub > MAF_DW_SUB) nsub = MAF_DW_SUB;
+  float4 v[MAF_DW_TV];
+  float ta[MAF_DW_AV];
+  const bool g_on = !(a.abl & 2), a_on = !(a.abl & 4);
+  if (nsub > 0) {
+    if (wave < mtn && g_on) maf_dw_load_tile(L, R0, wave, lane, v);
+    if (a_on) maf_dw_load_rows(L, R0, tid, ta);
+  }
+  f4 acc[MAF_DW_MTW][4];
+  float4 accb[MAF_DW_MTW];      // per lane: sums of columns 4 (lane & 3) .. + 3 over the rows this lane loaded
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      float t[16];
+  for (int q = 0; q < MAF_DW_MTW; ++q) {
+    accb[q] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int r = (tid >> 6) + 4 * (16 * b + u);
-        t[u] = ap0[(long long)r * L.lda];
-      }
+    for (int nt = 0; nt < 4; ++nt) acc[q][nt] = {0.f, 0.f, 0.f, 0.f};
+  }
+  float* Gs = As + MAF_DW_ROWS * MAF_DW_SA + wave * (MAF_DW_ROWS * MAF_DW_GS);
+  const float* ap = Gs + 4 * g * MAF_DW_GS + j;
+  const float* bp = As + 4 * g * MAF_DW_SA + j;
+  for (int sc = 0; sc < nsub; ++sc) {
+    const long long r0 = R0 + (long long)sc * MAF_DW_ROWS;
+    const long long rem = a.n - r0;
+    const int nrows = rem < MAF_DW_ROWS ? (int)rem : MAF_DW_ROWS;
+    if (sc > 0) __syncthreads();          // every wave is done reading the previous sub-chunk's input tile
+    if (a_on) {
+      const int c = tid & 63;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int r = (tid >> 6) + 4 * (16 * b + u);
-        As[r * MAF_DW_SA + c] = (r < nrows && c < L.in) ? t[u] : 0.f;
+      for (int u = 0; u < MAF_DW_AV; ++u) {
+        const int r = (tid >> 6) + 4 * u;
+        As[r * MAF_DW_SA + c] = (r < nrows && c < L.in) ? ta[u] : 0.f;
       }
     }
+    __syncthreads();
+    const bool more = sc + 1 < nsub;
+#pragma unroll
+    for (int q = 0; q < MAF_DW_MTW; ++q) {
+      const int mt = wave + 4 * q;
+      if (mt < mtn) {
+        if (g_on) {
+#pragma unroll
+          for (int it = 0; it < MAF_DW_TV; ++it) {
+            const int idx = it * 64 + lane, row = idx >> 2;
+            float4 val = v[it];       // (component selects: a ?: between two float4 lvalues keeps v[] in scratch)
+            const bool in = row < nrows;
+            val.x = in ? val.x : 0.f; val.y = in ? val.y : 0.f; val.z = in ? val.z : 0.f; val.w = in ? val.w : 0.f;
+            *reinterpret_cast<float4*>(Gs + row * MAF_DW_GS + 4 * (idx & 3)) = val;
+            accb[q].x += val.x; accb[q].y += val.y; accb[q].z += val.z; accb[q].w += val.w;
+          }
+        }
+        maf_dw_lds_fence();
+        // requests that fly under this sweep: the next G tile and (once per sub-chunk) the next input rows
+        if (g_on) {
+          if (mt + 4 < mtn) maf_dw_load_tile(L, r0, mt + 4, lane, v);
+          else if (more) maf_dw_load_tile(L, r0 + MAF_DW_ROWS, wave, lane, v);
+        }
+        if (q == 0 && more && a_on) maf_dw_load_rows(L, r0 + MAF_DW_ROWS, tid, ta);
+        // one guard-free MFMA stream per input width (a guard per MFMA costs a basic block and an s_waitcnt each)
+        if (!(a.abl & 1))
+        switch (ntiles) {
+          case 1: maf_dw_sweep<1>(ap, bp, acc[q]); break;
+          case 2: maf_dw_sweep<2>(ap, bp, acc[q]); break;
+          case 3: maf_dw_sweep<3>(ap, bp, acc[q]); break;
+          default: maf_dw_sweep<4>(ap, bp, acc[q]); break;
+        }
+        maf_dw_lds_fence();
+      }
+    }
+    // (a wave without m-tiles in this piece still stages input rows; its row prefetch rides on q == 0 above only when
+    // it owns a tile, so give it the same request here)
+    if (wave >= mtn && more && a_on) maf_dw_load_rows(L, r0 + MAF_DW_ROWS, tid, ta);
   }
-  __syncthreads();
+  if (a.abl & 8) return;
   float* part = a.partial + (long long)chunk * a.n_layer;
-  const float one = (j == 0) ? 1.f : 0.f;
   // mask inputs that do not depend on the m-tile: the degree of this lane's input column in every n-tile
   int deg_in[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) deg_in[nt] = L.kind == 0 ? 16 * nt + j + 1 : maf_hidden_degree(16 * nt + j, a.D);
-  float* Gs = As + MAF_DW_ROWS * MAF_DW_SA + wave * (MAF_DW_ROWS * MAF_DW_GS);
-  const float* ap = Gs + 4 * g * MAF_DW_GS + j;
-  const float* bp = As + 4 * g * MAF_DW_SA + j;
-  for (int mt = wave; mt < mtiles; mt += 4) {
-    f4 acc[4], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = {0.f, 0.f, 0.f, 0.f};
-    if (!(a.abl & 2)) {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int idx = it * 64 + lane, row = idx >> 2;
-        const float4 z = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<float4*>(Gs + row * MAF_DW_GS + 4 * (idx & 3)) = row < nrows ? v[it] : z;
-      }
-    }
-    wave_lds_fence();
-    // next tile: requested AFTER the fence (a fence drains vmcnt too) so that the loads fly under this sweep
-    if (!(a.abl & 2) && mt + 4 < mtiles) maf_dw_load_tile(L, r0, mt + 4, lane, v);
-    // one guard-free MFMA stream per input width (a guard per MFMA costs a basic block and an s_waitcnt each)
-    if (!(a.abl & 1))
-    switch (ntiles) {
-      case 1: maf_dw_sweep<1>(ap, bp, one, acc, accb); break;
-      case 2: maf_dw_sweep<2>(ap, bp, one, acc, accb); break;
-      case 3: maf_dw_sweep<3>(ap, bp, one, acc, accb); break;
-      default: maf_dw_sweep<4>(ap, bp, one, acc, accb); break;
-    }
-    wave_lds_fence();
-    if (!(a.abl & 8))
+  for (int q = 0; q < MAF_DW_MTW; ++q) {
+    const int mt = wave + 4 * q;
+    if (mt >= mtn) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = 16 * mt + 4 * g + r;           // padded output column of this accumulator row
+      const int m = 16 * (L.mt0 + mt) + 4 * g + r;           // padded output column of this accumulator row
       const int grp = m / L.group_pad, p = m - grp * L.group_pad;
       const int o = grp * L.group + p;
       if (p < L.group && o < L.out) {
@@ -648,10 +698,27 @@ maf_dw_kernel(const MafDwArgs a) {
             bool keep;
             if (a.mask) keep = a.mask[widx] != 0.f;
             else keep = L.kind == 1 ? true : (L.kind == 3 ? deg_out > deg_in[nt] : deg_out >= deg_in[nt]);
-            part[widx] = keep ? acc[nt][r] : 0.f;
+            part[widx] = keep ? acc[q][nt][r] : 0.f;
           }
         }
-        if (j == 0 && L.col0 == 0) part[L.g_b + o] = accb[r];
+      }
+    }
+    if (L.col0 == 0) {
+      // column sums: lanes with equal (lane & 3) hold the same four columns for different rows
+      float bs[4] = {accb[q].x, accb[q].y, accb[q].z, accb[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) bs[e] += __shfl_xor(bs[e], off, 64);
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = 16 * (L.mt0 + mt) + 4 * lane + e;
+          const int grp = m / L.group_pad, p = m - grp * L.group_pad;
+          const int o = grp * L.group + p;
+          if (p < L.group && o < L.out) part[L.g_b + o] = bs[e];
+        }
       }
     }
   }

@@ -66,8 +66,8 @@ static GWs g_ws_layout(const NsfPlan& pl, const GTrainPlan& gp, int64_t n) {
   int64_t o = 0;
   auto take = [&](int64_t sz) { const int64_t at = o; o += (sz + 3) / 4 * 4; return at; };
   const int D = pl.D, T = pl.T;
-  w.npad = (n + MAF_DW_ROWS - 1) / MAF_DW_ROWS * MAF_DW_ROWS;
-  w.nchunks = (int)(w.npad / MAF_DW_ROWS);
+  w.npad = (n + MAF_DW_CHUNK - 1) / MAF_DW_CHUNK * MAF_DW_CHUNK;
+  w.nchunks = (int)(w.npad / MAF_DW_CHUNK);
   w.stash = take((int64_t)T * n * D);
   w.noise = take(n * D);
   w.logp = take(n);
@@ -194,7 +194,7 @@ int nsf_g_train_backward(const sbi_amd_nsf_config* cfg, const float* params, con
     add(a.LUG, a.LUA, gp.lua_w, D + 1, D, D + 1, du_pad, gp.o_dU, gp.o_dUb);                 // dU (+ logabsdet column)
     add(a.LUG + (int64_t)(du_pad >> 4) * gts, a.LUA + dwp, gp.lua_w, D, D, D, dz_pad, gp.o_dL, gp.o_dLb);   // dL, d bias
     if (nl >= MAF_DW_MAX_LIN) return SBI_AMD_E_UNSUPPORTED;
-    d.n = n; d.rows_per_chunk = MAF_DW_ROWS; d.nchunks = w.nchunks; d.n_layer = gp.slab; d.D = D; d.P = pl.P;
+    d.n = n; d.rows_per_chunk = MAF_DW_CHUNK; d.nchunks = w.nchunks; d.n_layer = gp.slab; d.D = D; d.P = pl.P;
     d.partial = workspace + w.part + (int64_t)t * w.nchunks * gp.slab;
     rc = maf_launch_dw(d, nl, st);
     if (rc) return rc;

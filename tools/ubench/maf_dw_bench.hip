@@ -14,7 +14,7 @@ int main() {
   hipMalloc(&GP, n * DP * 4); hipMalloc(&ACT, n * AWS * 4); hipMalloc(&G, n * GW * 4); hipMalloc(&CTX, n * MAF_CW * 4);
   hipMemset(GP, 0, n * DP * 4); hipMemset(ACT, 0, n * AWS * 4); hipMemset(G, 0, n * GW * 4); hipMemset(CTX, 0, n * MAF_CW * 4);
   const int n_layer = H * D + H + H * 10 + H + NB * (H * H + H) + D * P * H + D * P;
-  const int nchunks = (int)(n / MAF_DW_ROWS);
+  const int nchunks = (int)(n / MAF_DW_CHUNK);
   hipMalloc(&part, (size_t)nchunks * n_layer * 4);
   MafDwArgs d;
   __builtin_memset((void*)&d, 0, sizeof(d));
@@ -30,8 +30,8 @@ int main() {
   set(2, G + 4 * 3 * gts, GW, ACT + 64, AWS, H, H, H, 64, 2);
   set(3, G, GW, CTX, MAF_CW, H, D, H, 64, 0);
   set(4, G + 4 * gts, GW, CTX + D, MAF_CW, H, 10, H, 64, 1);
-  d.n = n; d.rows_per_chunk = MAF_DW_ROWS; d.nchunks = nchunks; d.n_layer = n_layer; d.D = D; d.P = P; d.partial = part;
-  const int lds = (MAF_DW_ROWS * MAF_DW_SA + 4 * MAF_DW_ROWS * MAF_DW_GS) * 4;
+  d.n = n; d.rows_per_chunk = MAF_DW_CHUNK; d.nchunks = nchunks; d.n_layer = n_layer; d.D = D; d.P = P; d.partial = part;
+  const int lds = MAF_DW_LDS_BYTES;
   hipFuncSetAttribute((const void*)maf_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -39,9 +39,20 @@ int main() {
   for (int abl : abls) {
     d.abl = abl;
     for (int only = -1; only < (abl == 0 ? 5 : 0); ++only) {      // abl 0: also each linear alone
-      dim3 grid(nchunks, only < 0 ? 5 : 1);
       MafDwArgs dd = d;
-      if (only >= 0) dd.lin[0] = d.lin[only];
+      int np = 0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < 5; ++i) {
+          if (only >= 0 && i != only) continue;
+          const MafLin& L = d.lin[i];
+          const int mtiles = ((L.out + L.group - 1) / L.group * L.group_pad + 15) / 16, cap = 4 * MAF_DW_MTW;
+          for (int mt0 = 0; mt0 < mtiles; mt0 += cap) {
+            const int mtn = mtiles - mt0 < cap ? mtiles - mt0 : cap;
+            if ((mtn == cap) != (pass == 0)) continue;
+            dd.lin[np] = L; dd.lin[np].mt0 = mt0; dd.lin[np].mtn = mtn; ++np;
+          }
+        }
+      dim3 grid(nchunks, np);
       for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(maf_dw_kernel, grid, dim3(256), lds, 0, dd);
       hipEventRecord(e0);
       for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL(maf_dw_kernel, grid, dim3(256), lds, 0, dd);
