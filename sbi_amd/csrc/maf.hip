@@ -150,7 +150,7 @@ static int maf_build_plan(const sbi_amd_maf_config* c, int nw, MafPlan* mp) {
 static int maf_plan_for_rows(const sbi_amd_maf_config* cfg, int64_t n, int cap, MafPlan* mp, int* nw_out) {
   int nw = cap;
   while (nw > 1 && (n + 16 * nw - 1) / (16 * nw) < 256) nw >>= 1;
-  for (; nw >= 1; nw >>= 1) {
+  for (; nw >= 1; --nw) {       // any wave count works (16 rows per wave): take the largest that fits LDS
     const int rc = maf_build_plan(cfg, nw, mp);
     if (rc == 0) { *nw_out = nw; return 0; }
     if (rc != SBI_AMD_E_LDS) return rc;
@@ -298,10 +298,11 @@ extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const flo
   if (loss_out)
     hipLaunchKernelGGL(maf_neg_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace + w.logp,
                        loss_out, (long long)n);
-  // backward kernels: one wave per SIMD (the activation set of the whole conditioner lives in registers)
+  // backward kernels: up to two waves per SIMD (<= 256 VGPRs: the activation set of the whole conditioner lives in
+  // registers), as many as the LDS left over by the weight image allows
   MafPlan mpb;
   int nwb = 0;
-  rc = maf_plan_for_rows(cfg, n, 4, &mpb, &nwb);
+  rc = maf_plan_for_rows(cfg, n, 8, &mpb, &nwb);
   if (rc) return rc;
   float* gz[2] = {workspace + w.gza, workspace + w.gzb};
   for (int t = T - 1; t >= 0; --t) {

@@ -377,7 +377,7 @@ __device__ __forceinline__ void store_frag_planes(float* __restrict__ plane0, lo
 }
 
 template <int K, int KSH, int VAR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
   constexpr int PT = (3 * K - 1 + 15) / 16;
   const NsfPlan& pl = mp.n;

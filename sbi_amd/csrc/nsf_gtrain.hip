@@ -47,10 +47,11 @@ static int g_build_plan(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, G
   gp->o_dL = g_round_up(gp->o_dUb + D + 1, 4);
   gp->o_dLb = gp->o_dL + D * D;
   gp->slab = g_round_up(gp->o_dLb + D, 4);
-  // 4 waves (one per SIMD: the kernel holds a residual block's activations in registers) when enough rows, else fewer
-  int nw = 4;
+  // up to 8 waves (two per SIMD; the kernel holds a residual block's activations in registers, <= 256 VGPRs) when
+  // there are enough rows; any count works (16 rows per wave): the largest that fits next to the weight image
+  int nw = 8;
   while (nw > 1 && (n + 16 * nw - 1) / (16 * nw) < 256) nw >>= 1;
-  for (; nw >= 1; nw >>= 1)
+  for (; nw >= 1; --nw)
     if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * gp->sc_total) <= NSF_LDS_LIMIT_BYTES) break;
   if (nw < 1) return SBI_AMD_E_LDS;
   *nw_out = nw;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void gt_store_rows(float* __restrict__ dst, int ld, l
 }
 
 template <int K, int KSH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 nsf_gbwd_kernel(const NsfPlan pl, const GTrainPlan gp, const GBwdArgs a) {
   constexpr int PT = (3 * K - 1 + 15) / 16;
   const ShapeDesc& S = pl.shape[a.par];
