@@ -325,18 +325,23 @@ extern "C" int sbi_amd_maf_loss_fwd_bwd(const sbi_amd_maf_config* cfg, const flo
     const ShapeDesc& S = mp.n.shape[0];
     const int AWS = (MAF_MAX_NB + 1) * MAF_AW;
     const int64_t gts = w.npad * 16;     // floats per m-tile plane
-    auto set = [&](int i, const float* G, const float* A, int lda, const LinDesc& L, int group, int gpad, int kind) {
+    auto set = [&](int i, const float* G, const float* A, int lda, const LinDesc& L, int group, int gpad, int kind,
+                   int gperm, int aperm) {
       d.lin[i].G = G; d.lin[i].gts = gts; d.lin[i].A = A; d.lin[i].lda = lda;
       d.lin[i].out = L.out; d.lin[i].in = L.in; d.lin[i].in_total = L.in; d.lin[i].col0 = 0;
       d.lin[i].group = group; d.lin[i].group_pad = gpad;
       d.lin[i].g_w = L.g_w; d.lin[i].g_b = L.g_b; d.lin[i].kind = kind;
+      d.lin[i].gperm = gperm; d.lin[i].aperm = aperm;
     };
     // largest first (the final layer has D*(3K-1) outputs)
-    set(0, a.GP, a.ACT + 64 * NB, AWS, S.lin[S.fin], mp.n.P, mp.PTW, 3);
-    for (int b = 0; b < NB; ++b) set(1 + b, a.G + 4 * (2 + b) * gts, a.ACT + 64 * b, AWS, S.lin[2 + b], mp.n.H, 64, 2);
-    set(1 + NB, a.G, a.CTX, MAF_CW, S.lin[0], mp.n.H, 64, 0);     // inputs: CTX rows = [z ; context]
+    // (G planes of the hidden layers and the ACT rows are written in fragment order by the backward kernel; the
+    // spline-parameter planes GP and the CTX rows in natural order)
+    set(0, a.GP, a.ACT + 64 * NB, AWS, S.lin[S.fin], mp.n.P, mp.PTW, 3, 0, 1);
+    for (int b = 0; b < NB; ++b)
+      set(1 + b, a.G + 4 * (2 + b) * gts, a.ACT + 64 * b, AWS, S.lin[2 + b], mp.n.H, 64, 2, 1, 1);
+    set(1 + NB, a.G, a.CTX, MAF_CW, S.lin[0], mp.n.H, 64, 0, 1, 0);     // inputs: CTX rows = [z ; context]
     int nlin = 2 + NB;
-    if (mp.variant == 0) { set(2 + NB, a.G + 4 * gts, a.CTX + D, MAF_CW, S.lin[1], mp.n.H, 64, 1); nlin = 3 + NB; }
+    if (mp.variant == 0) { set(2 + NB, a.G + 4 * gts, a.CTX + D, MAF_CW, S.lin[1], mp.n.H, 64, 1, 1, 0); nlin = 3 + NB; }
     d.mask = masks ? masks + (int64_t)t * mp.n_layer : nullptr;
     d.n = n; d.rows_per_chunk = w.rows_per_chunk; d.nchunks = w.nchunks; d.n_layer = mp.n_layer;
     d.D = D; d.P = mp.n.P;

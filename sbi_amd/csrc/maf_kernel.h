@@ -356,24 +356,42 @@ __device__ __forceinline__ void maf_wft_chunk(const float* __restrict__ lds, con
     for (int r = 0; r < 4; ++r) gh[mt][r] = (16 * mt + 4 * r + id.g < LF.in) ? gh[mt][r] : 0.f;
 }
 
-// D fragments -> one 64-float row segment per batch row in HBM
+// D fragments -> one 64-float row segment per batch row in HBM, in FRAGMENT ORDER: lane (row j, slot g) holds
+// features 16 mt + 4 r + g in register r and stores them as ONE 16-byte word at position 16 mt + 4 g, i.e. position
+// 4 g + r of a 16-block holds feature 4 r + g (a natural-order store would be 16 scattered 4-byte stores per lane).
+// The weight-gradient kernel undoes the permutation in its index arithmetic (MafLin.aperm / gperm); ld % 4 == 0.
 __device__ __forceinline__ void store_frag_rows(float* __restrict__ dst, int ld, long long row, bool valid,
                                                 const LaneId& id, const f4 (&v)[NSF_HT]) {
   if (!valid) return;
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dst[row * ld + 16 * mt + 4 * r + id.g] = v[mt][r];
+    *reinterpret_cast<float4*>(dst + row * ld + 16 * mt + 4 * id.g) = float4{v[mt][0], v[mt][1], v[mt][2], v[mt][3]};
 }
 
-// D fragments -> four m-tile planes (tile-major gradient operand, see MafBwdArgs)
+// D fragments -> four m-tile planes (tile-major gradient operand, see MafBwdArgs), fragment order inside a tile
 __device__ __forceinline__ void store_frag_planes(float* __restrict__ plane0, long long npad, long long row, bool valid,
                                                   const LaneId& id, const f4 (&v)[NSF_HT]) {
   if (!valid) return;
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt)
+    *reinterpret_cast<float4*>(plane0 + (mt * npad + row) * 16 + 4 * id.g) =
+        float4{v[mt][0], v[mt][1], v[mt][2], v[mt][3]};
+}
+
+// spline-parameter gradients of `nact` dims (LDS rows of 16 PT floats) -> planes of GP in natural column order:
+// lane (row j, slot g) moves columns 4 g .. 4 g + 3 of every 16-block as one 16-byte store
+template <int PT>
+__device__ __forceinline__ void store_param_planes(float* __restrict__ GP, long long npad, long long row, bool valid,
+                                                   const LaneId& id, const float* __restrict__ pst, int DS, int PSW,
+                                                   int dim0, int nact) {
+  if (!valid) return;
+  for (int sl = 0; sl < nact; ++sl) {
+    const float* src = pst + sl * DS + id.j * PSW + 4 * id.g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) plane0[(mt * npad + row) * 16 + 4 * r + id.g] = v[mt][r];
+    for (int h = 0; h < PT; ++h)
+      *reinterpret_cast<float4*>(GP + (((long long)(dim0 + sl) * PT + h) * npad + row) * 16 + 4 * id.g) =
+          float4{src[16 * h], src[16 * h + 1], src[16 * h + 2], src[16 * h + 3]};
+  }
 }
 
 template <int K, int KSH, int VAR>
@@ -453,11 +471,7 @@ maf_bwd_kernel(const MafPlan mp, const MafBwdArgs a) {
     }
     wave_lds_fence();
     // g_p rows -> HBM (operand of d Wf), 16*PT floats per (row, dim)
-    for (int sl = 0; sl < nact; ++sl)
-      for (int k = id.g; k < mp.PTW; k += 4) {
-        const int col = (2 * c + sl) * mp.PTW + k;
-        if (valid) a.GP[((col >> 4) * a.npad + row) * 16 + (col & 15)] = pst[sl * pl.DS + id.j * pl.PSW + k];
-      }
+    store_param_planes<PT>(a.GP, a.npad, row, valid, id, pst, pl.DS, pl.PSW, 2 * c, nact);
     maf_wft_chunk<PT>(lds, LF, pl, id, pst, 2 * c, nact, gh);
     wave_lds_fence();
   }
@@ -518,9 +532,10 @@ struct MafLin {
   int group, group_pad;   // output o lives at column (o / group) * group_pad + o % group  (final layer: P -> 16*PT)
   int g_w, g_b;     // offsets inside the transform's parameter block
   int kind;         // mask kind (maf_mask) when no mask buffer is given
+  int gperm, aperm; // G tiles / A rows are in fragment order (store_frag_planes / store_frag_rows) instead of natural
   int mt0, mtn;     // m-tile range of this piece (filled in by maf_launch_dw: at most 4 * MAF_DW_MTW tiles each)
 };
-#define MAF_DW_MAX_LIN 44
+#define MAF_DW_MAX_LIN 40
 struct MafDwArgs {
   MafLin lin[MAF_DW_MAX_LIN];
   long long n;
@@ -578,7 +593,8 @@ __device__ __forceinline__ void maf_dw_load_tile(const MafLin& L, long long r0, 
 // thread = (column c, row phase): rows phase + 4 u (clamped addresses + selects at the LDS store: a predicated load
 // would sit in its own basic block with its own s_waitcnt)
 __device__ __forceinline__ void maf_dw_load_rows(const MafLin& L, long long r0, int tid, float (&t)[MAF_DW_AV]) {
-  const int c = tid & 63, cc = c < L.in ? c : 0;
+  // (fragment-ordered rows: every position of the 16-blocks up to round_up(in, 16) exists and holds a finite value)
+  const int c = tid & 63, cc = c < (L.aperm ? ((L.in + 15) & ~15) : L.in) ? c : 0;
   const float* ap0 = L.A + (r0 + (tid >> 6)) * L.lda + cc;
 #pragma unroll
   for (int u = 0; u < MAF_DW_AV; ++u) t[u] = ap0[(long long)(4 * u) * L.lda];
@@ -628,10 +644,11 @@ maf_dw_kernel(const MafDwArgs a) {
     if (sc > 0) __syncthreads();          // every wave is done reading the previous sub-chunk's input tile
     if (a_on) {
       const int c = tid & 63;
+      const int cfeat = L.aperm ? (c & 48) + 4 * (c & 3) + ((c >> 2) & 3) : c;   // feature held by column position c
 #pragma unroll
       for (int u = 0; u < MAF_DW_AV; ++u) {
         const int r = (tid >> 6) + 4 * u;
-        As[r * MAF_DW_SA + c] = (r < nrows && c < L.in) ? ta[u] : 0.f;
+        As[r * MAF_DW_SA + c] = (r < nrows && cfeat < L.in) ? ta[u] : 0.f;
       }
     }
     __syncthreads();
@@ -677,22 +694,24 @@ maf_dw_kernel(const MafDwArgs a) {
   float* part = a.partial + (long long)chunk * a.n_layer;
   // mask inputs that do not depend on the m-tile: the degree of this lane's input column in every n-tile
   int deg_in[4];
+  const int ji = L.aperm ? 4 * (j & 3) + (j >> 2) : j;     // input feature (inside its 16-block) of B column j
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) deg_in[nt] = L.kind == 0 ? 16 * nt + j + 1 : maf_hidden_degree(16 * nt + j, a.D);
+  for (int nt = 0; nt < 4; ++nt) deg_in[nt] = L.kind == 0 ? 16 * nt + ji + 1 : maf_hidden_degree(16 * nt + ji, a.D);
 #pragma unroll
   for (int q = 0; q < MAF_DW_MTW; ++q) {
     const int mt = wave + 4 * q;
     if (mt >= mtn) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = 16 * (L.mt0 + mt) + 4 * g + r;           // padded output column of this accumulator row
+      // padded output column of this accumulator row (tile position 4 g + r)
+      const int m = 16 * (L.mt0 + mt) + (L.gperm ? 4 * r + g : 4 * g + r);
       const int grp = m / L.group_pad, p = m - grp * L.group_pad;
       const int o = grp * L.group + p;
       if (p < L.group && o < L.out) {
         const int deg_out = L.kind == 3 ? grp + 1 : maf_hidden_degree(o, a.D);   // kind 3: o / P + 1 with group = P
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const int i = 16 * nt + j;
+          const int i = 16 * nt + ji;
           if (nt < ntiles && i < L.in) {
             const int widx = L.g_w + o * L.in_total + L.col0 + i;
             bool keep;
@@ -714,7 +733,7 @@ maf_dw_kernel(const MafDwArgs a) {
       if (lane < 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int m = 16 * (L.mt0 + mt) + 4 * lane + e;
+          const int m = 16 * (L.mt0 + mt) + (L.gperm ? 4 * e + lane : 4 * lane + e);
           const int grp = m / L.group_pad, p = m - grp * L.group_pad;
           const int o = grp * L.group + p;
           if (p < L.group && o < L.out) part[L.g_b + o] = bs[e];

@@ -172,28 +172,32 @@ int nsf_g_train_backward(const sbi_amd_nsf_config* cfg, const float* params, con
     memset((void*)&d, 0, sizeof(d));
     int nl = 0;
     auto add = [&](const float* G, const float* A, int lda, int out, int in_total, int group, int gpad, int g_w,
-                   int g_b) {
+                   int g_b, int gperm, int aperm) {
       for (int col0 = 0; col0 < in_total && nl < MAF_DW_MAX_LIN; col0 += 64) {
         MafLin& L = d.lin[nl++];
         L.G = G; L.gts = gts; L.A = A + col0; L.lda = lda;
         L.out = out; L.in = in_total - col0 < 64 ? in_total - col0 : 64; L.in_total = in_total; L.col0 = col0;
         L.group = group; L.group_pad = gpad; L.g_w = g_w; L.g_b = g_b; L.kind = 1;
+        L.gperm = gperm; L.aperm = aperm;
       }
     };
     const LinDesc& LF = S.lin[S.fin];
-    add(a.GP, a.ACT, gp.act_w, LF.out, H, pl.P, gp.PTW, LF.g_w, LF.g_b);                       // final layer
+    // (fragment order: the G planes of the hidden layers and the ACT rows; natural: GP, LUG, CIN, LUA)
+    add(a.GP, a.ACT, gp.act_w, LF.out, H, pl.P, gp.PTW, LF.g_w, LF.g_b, 0, 1);                 // final layer
     for (int b = 0; b < NB; ++b) {
       const LinDesc& Lc = S.lin[1 + 3 * b];
       const LinDesc& L1 = S.lin[2 + 3 * b];
       const LinDesc& L2 = S.lin[3 + 3 * b];
-      add(a.G + (int64_t)(4 * (3 + 3 * b)) * gts, a.ACT + 64 * (1 + 2 * b), gp.act_w, H, H, H, 64, L2.g_w, L2.g_b);
-      add(a.G + (int64_t)(4 * (2 + 3 * b)) * gts, a.ACT + 64 * (2 + 2 * b), gp.act_w, H, H, H, 64, L1.g_w, L1.g_b);
-      add(a.G + (int64_t)(4 * (1 + 3 * b)) * gts, a.CIN + S.d_id, gp.cin_w, H, C, H, 64, Lc.g_w, Lc.g_b);
+      add(a.G + (int64_t)(4 * (3 + 3 * b)) * gts, a.ACT + 64 * (1 + 2 * b), gp.act_w, H, H, H, 64, L2.g_w, L2.g_b,
+          1, 1);
+      add(a.G + (int64_t)(4 * (2 + 3 * b)) * gts, a.ACT + 64 * (2 + 2 * b), gp.act_w, H, H, H, 64, L1.g_w, L1.g_b,
+          1, 1);
+      add(a.G + (int64_t)(4 * (1 + 3 * b)) * gts, a.CIN + S.d_id, gp.cin_w, H, C, H, 64, Lc.g_w, Lc.g_b, 1, 0);
     }
-    add(a.G, a.CIN, gp.cin_w, H, S.in0, H, 64, S.lin[0].g_w, S.lin[0].g_b);                  // initial layer
+    add(a.G, a.CIN, gp.cin_w, H, S.in0, H, 64, S.lin[0].g_w, S.lin[0].g_b, 1, 0);            // initial layer
     const int du_pad = 16 * ((D + 1 + 15) / 16), dz_pad = 16 * ((D + 15) / 16), dwp = gp.lua_w >> 1;
-    add(a.LUG, a.LUA, gp.lua_w, D + 1, D, D + 1, du_pad, gp.o_dU, gp.o_dUb);                 // dU (+ logabsdet column)
-    add(a.LUG + (int64_t)(du_pad >> 4) * gts, a.LUA + dwp, gp.lua_w, D, D, D, dz_pad, gp.o_dL, gp.o_dLb);   // dL, d bias
+    add(a.LUG, a.LUA, gp.lua_w, D + 1, D, D + 1, du_pad, gp.o_dU, gp.o_dUb, 0, 0);           // dU (+ logabsdet column)
+    add(a.LUG + (int64_t)(du_pad >> 4) * gts, a.LUA + dwp, gp.lua_w, D, D, D, dz_pad, gp.o_dL, gp.o_dLb, 0, 0);   // dL, d bias
     if (nl >= MAF_DW_MAX_LIN) return SBI_AMD_E_UNSUPPORTED;
     d.n = n; d.rows_per_chunk = MAF_DW_CHUNK; d.nchunks = w.nchunks; d.n_layer = gp.slab; d.D = D; d.P = pl.P;
     d.partial = workspace + w.part + (int64_t)t * w.nchunks * gp.slab;

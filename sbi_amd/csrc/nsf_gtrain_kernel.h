@@ -53,12 +53,11 @@ __device__ __forceinline__ void gt_store_rows(float* __restrict__ dst, int ld, l
                                               const LaneId& id, const f4 (&v)[NSF_HT], bool relu) {
   if (!valid) return;
 #pragma unroll
-  for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float a = v[mt][r];
-      dst[row * ld + 16 * mt + 4 * r + id.g] = relu ? fmaxf(a, 0.f) : a;
-    }
+  for (int mt = 0; mt < NSF_HT; ++mt) {     // fragment order, one 16-byte store per m-tile (see store_frag_rows)
+    float4 o = {v[mt][0], v[mt][1], v[mt][2], v[mt][3]};
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(dst + row * ld + 16 * mt + 4 * id.g) = o;
+  }
 }
 
 template <int K, int KSH>
@@ -162,11 +161,7 @@ nsf_gbwd_kernel(const NsfPlan pl, const GTrainPlan gp, const GBwdArgs a) {
         }
       }
       wave_lds_fence();
-      for (int sl = 0; sl < nact; ++sl)
-        for (int k = id.g; k < gp.PTW; k += 4) {
-          const int col = (2 * c + sl) * gp.PTW + k;
-          if (valid) a.GP[((col >> 4) * a.npad + row) * 16 + (col & 15)] = pst[sl * pl.DS + id.j * pl.PSW + k];
-        }
+      store_param_planes<PT>(a.GP, a.npad, row, valid, id, pst, pl.DS, pl.PSW, 2 * c, nact);
       maf_wft_chunk<PT>(lds, LF, pl, id, pst, 2 * c, nact, gh);
       wave_lds_fence();
     }
