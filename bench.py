@@ -390,7 +390,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["both", "train", "log_prob", "log_prob_broadcast", "sample", "atomic", "mcmc", "fmpe",
-                                      "npe_train", "maf"],
+                                      "npe_train", "maf", "zuko"],
                     default=os.environ.get("SBI_AMD_BENCH_MODE", "both"))
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch pairs per GPU per step; strong: --batch pairs per step split over the GPUs")
@@ -526,20 +526,22 @@ def main(argv=None):
         if distributed:
             dist.destroy_process_group()
         return
-    if args.mode == "maf":
+    if args.mode in ("maf", "zuko"):
         # the maf_rqs sibling flow (MADE masked-linear conditioner, autoregressive RQ
         # splines) at the configs[1] shape: log_prob, sample for given noise (D conditioner passes per transform) and
         # the fused training step
         from sbi_amd.inference.trainers.fused import FusedTrainStep
-        from sbi_amd.neural_nets.net_builders.flow import build_maf_rqs
+        from sbi_amd.neural_nets.net_builders.flow import build_maf_rqs, build_zuko_nsf
 
         torch.manual_seed(1)
         th0, x0 = make_data(BATCH, "cpu", seed=0)
-        mest = build_maf_rqs(th0, x0).to(device)
+        flow_name = "maf_rqs" if args.mode == "maf" else "zuko_nsf"
+        mest = (build_maf_rqs if args.mode == "maf" else build_zuko_nsf)(th0, x0).to(device)
         h = mest.net.hyper
         H, P_, NBm = h.hidden_features, 3 * h.num_bins - 1, h.num_blocks
-        f_eval = h.num_transforms * 2.0 * (D * H + C * H + NBm * H * H + H * D * P_)   # dense FLOP per eval
-        # inverse: the context layer once, then D passes of [initial + blocks + ONE dim's final-layer rows]
+        # dense FLOP per eval: 2 x (weights of the masked linears, masked-out entries included: the kernels run dense)
+        f_eval = h.num_transforms * 2.0 * ((D + C) * H + NBm * H * H + H * D * P_)
+        # inverse: D passes of [initial + blocks + ONE dim's final-layer rows] (maf_rqs: the context layer only once)
         f_draw = h.num_transforms * 2.0 * (C * H + D * (D * H + NBm * H * H + H * P_))
         noise = torch.randn(B, D, device=device)
 
@@ -553,12 +555,13 @@ def main(argv=None):
         wall_t, dev_t = timed(lambda: stepper.step(theta, x, global_batch=GB), args.steps, args.warmup, device, dist)
         if rank == 0:
             print(json.dumps({
-                "metric": "maf_rqs train (theta,x)-pairs/sec", "value": GB * args.steps / wall_t, "unit": "pairs/s",
+                "metric": f"{flow_name} train (theta,x)-pairs/sec", "value": GB * args.steps / wall_t, "unit": "pairs/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_t / args.steps * 1e3,
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic",
-                "config": {"workload": f"maf_rqs (sbi defaults: hidden {H}, {h.num_transforms} transforms, {NBm} "
-                                       f"blocks, {h.num_bins} bins, {h.param_count()} parameters), theta-dim {D}, "
+                "config": {"workload": f"{flow_name} (sbi defaults: hidden {H}, {h.num_transforms} transforms, {NBm} "
+                                       f"hidden-to-hidden layers, {h.num_bins} bins, {h.param_count()} parameters), "
+                                       f"theta-dim {D}, "
                                        f"x-dim {C}, batch {B} per GPU", "parallelism": f"dp{world}"},
                 "roofline": roofline(3 * f_eval, B, args.steps, dev_t),
                 "log_prob": {"value": GB * args.steps / wall_lp, "unit": "evals/s",

@@ -269,28 +269,24 @@ __device__ __forceinline__ float softplus_bf(float x) {
 
 // ResidualNet hidden stack (nflows nn/nets/resnet.py, configuration flow.py:411-419):
 // h = W0 [z_id; c] + b0;  per block: t = W2 relu(W1 relu(h) + b1) + b2; h += t * sigmoid(Wc c + bc)
-// activation stash (training): one slot = this wave's 16x64 D-fragment array stored in register
-// order [mt*4+r][lane] (256-byte coalesced stores); slots: 0 h_0 | per block b: 1+4b t1 (pre-relu),
+// activation stash (training): one slot = this wave's 16x64 D-fragment array stored as [mt][lane][r]
+// (one 16-byte word per lane and m-tile: a wave store / load moves 1 KB contiguous; the base pointer handed to
+// ast_store / ast_load already includes 4 * lane); slots: 0 h_0 | per block b: 1+4b t1 (pre-relu),
 // 2+4b t2, 3+4b sigmoid(gate), 4+4b h_{b+1}.  The backward kernel reloads them instead of
 // recomputing the conditioner (trading ~0.75 GB/step of HBM traffic for 480 MFMAs per 16 rows).
 #define NSF_AST_SLOTS(NB) ((NB) > 0 ? 1 + 4 * (NB) : 2)   // ctx_mlp (NB == 0): h1, h2
 __device__ __forceinline__ void ast_store(float* __restrict__ ast, int slot, const f4 (&v)[NSF_HT]) {
 #pragma unroll
-  for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      // streaming (written once by the forward, read once by the backward): keep it out of L2, which the
-      // packed weight image lives in (measured -5 % step time)
-      __builtin_nontemporal_store(v[mt][r], &ast[(slot * 16 + mt * 4 + r) * 64]);
-    }
+  for (int mt = 0; mt < NSF_HT; ++mt) {
+    // streaming (written once by the forward, read once by the backward): keep it out of L2, which the
+    // packed weight image lives in (measured -5 % step time)
+    __builtin_nontemporal_store(v[mt], reinterpret_cast<f4*>(ast + (slot * 4 + mt) * 256));
+  }
 }
 __device__ __forceinline__ void ast_load(const float* __restrict__ ast, int slot, f4 (&v)[NSF_HT]) {
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[mt][r] = __builtin_nontemporal_load(&ast[(slot * 16 + mt * 4 + r) * 64]);
-    }
+    v[mt] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ast + (slot * 4 + mt) * 256));
 }
 
 template <int KSH>

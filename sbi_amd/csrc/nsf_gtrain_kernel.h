@@ -133,7 +133,7 @@ nsf_gbwd_kernel(const NsfPlan pl, const GTrainPlan gp, const GBwdArgs a) {
   const long long nt16 = (n + 15) / 16;
   const long long t16 = (long long)blockIdx.x * nw + wave;
   const long long wt16 = t16 < nt16 ? t16 : nt16 - 1;   // wave-tiles past the last row were never stashed
-  const float* ast = a.astash + (((long long)a.t * nt16 + wt16) * NSF_AST_SLOTS(NB)) * 1024 + id.lane;
+  const float* ast = a.astash + (((long long)a.t * nt16 + wt16) * NSF_AST_SLOTS(NB)) * 1024 + 4 * id.lane;
   f4 gh[NSF_HT];
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = {0.f, 0.f, 0.f, 0.f};

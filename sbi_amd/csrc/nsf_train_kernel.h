@@ -767,7 +767,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const long long nt16 = (n + 15) / 16;
       const long long wt16 = (long long)tile * TR_NW + wave < nt16 ? (long long)tile * TR_NW + wave : nt16 - 1;
       const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
-                         id.lane;
+                         4 * id.lane;
       TS(1);
       __syncthreads();                             // K0: spline parameters of chunk 0 are in A0
       TS(2);
@@ -983,7 +983,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl, const TrainPlan tp, const int t, const fl
       const long long nt16 = (n + 15) / 16;   // clamp as the row waves do: unstashed wave-tiles hold stale memory
       const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
       const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
-                         id0.lane;
+                         4 * id0.lane;
       ast_load(ast, cm ? 1 : 4 * NB, hl);
     };
     fetch_hl(blockIdx.x);
