@@ -96,8 +96,16 @@ def test_sample_from_noise_65536_matches_oracle():
     assert frac > 0.999
 
 
-def test_training_gradient_65536_matches_autograd():
-    """The fused step's flat gradient at the benchmarked batch (256 persistent workgroups x 4 tiles each).
+GRAD_CONFIGS = {
+    "D10-C10": dict(D=10, C=10),                                     # BASELINE configs[1]: wave-specialised backward
+    "generic-D20-C12-T3": dict(D=20, C=12, num_transforms=3),        # generic pass (nsf_gtrain_kernel.h + dW GEMMs)
+}
+
+
+@pytest.mark.parametrize("name", list(GRAD_CONFIGS))
+def test_training_gradient_65536_matches_autograd(name):
+    """The fused step's flat gradient at the benchmarked batch (256 persistent workgroups x 4 tiles each; for the
+    generic pass: 128 split-K chunks per linear).
 
     At this size (65 536 rows x 25 spline evaluations) a handful of spline inputs land within one fp32 ulp of a
     knot.  The RQ spline is C1: log p is continuous there, but d log p / d(parameters, theta) is two-valued (the
@@ -108,8 +116,14 @@ def test_training_gradient_65536_matches_autograd():
     from sbi_amd.neural_nets.estimators.nsf_flow import loss_fwd_bwd, train_workspace
     from tests.test_nsf_train_gpu import oracle_flat_grad
 
-    oracle, est, _, _ = matched_pair(D=10, C=10)
-    theta, x = _bench_data(seed=2)
+    cfg = GRAD_CONFIGS[name]
+    oracle, est, _, _ = matched_pair(**cfg)
+    if cfg["D"] == 10 and cfg["C"] == 10:
+        theta, x = _bench_data(seed=2)
+    else:
+        from tests.helpers import linear_gaussian_data
+
+        theta, x = linear_gaussian_data(N, cfg["D"], cfg["C"], seed=2)
 
     def oracle_pass(double, keep=None):
         """(per-row loss, flat param grad of sum_n keep_n loss_n / N, per-row d loss_n / d theta_n)"""
@@ -166,7 +180,7 @@ def test_training_gradient_65536_matches_autograd():
     for key, off, cnt, _ in est.net._slices():
         a, b = g_hk[off : off + cnt].double(), g64k[off : off + cnt]
         worst_block = max(worst_block, (a - b).abs().max().item() / max(b.abs().max().item(), 1e-3 * scale))
-    record("train_grad_65536", "D10-C10", rows=N, max_abs_grad_ref=scale, max_abs_loss_err_vs_oracle32=e_l,
+    record("train_grad_65536", name, rows=N, max_abs_grad_ref=scale, max_abs_loss_err_vs_oracle32=e_l,
            rel_grad_err_hip_vs_f64_all_rows=e_all, rel_grad_err_oracle32_vs_f64_all_rows=e_o64,
            knot_straddling_rows=int(outliers.numel()), rel_grad_err_hip_vs_f64_without_those_rows=e_keep,
            worst_block_rel_err_without_those_rows=worst_block, max_rel_row_grad_theta_err_other_rows=typical)
