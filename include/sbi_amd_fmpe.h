@@ -73,6 +73,27 @@ int sbi_amd_fmpe_loss_fwd_bwd(const sbi_amd_fmpe_config* cfg, const float* param
                               float uniform_weight, float* loss_out, float* grad_out, float* workspace,
                               void* stream);
 
+/* ---- ODE sampler: device-resident Dormand-Prince 5(4) step machinery (csrc/ode.hip) ---------------------------
+ * Replaces, for the probability-flow ODE of VectorFieldPosterior.sample (inference/posteriors/
+ * vector_field_posterior.py:436-466 -> samplers/ode_solvers/zuko_ode.py:19-124, zuko's adaptive odeint: a
+ * third-party solver, its controller is the textbook one here), everything of a step that is not the velocity
+ * evaluation.  `state` is a device buffer of SBI_AMD_DOPRI5_STATE_FLOATS fp32 slots owned by the caller:
+ *   slot 16: signed step h of the current attempt;  slots 17..22: times of stages 2..7 (hand slot 16+i to
+ *   sbi_amd_fmpe_velocity as its 1-element `times` for stage i+1);  slot 23: current t;  slot 24: 1.0 once t has
+ *   reached t1 (the only value the host ever reads; an attempt after that is a no-op);  slots 25/26: accepted /
+ *   rejected attempts;  slot 27: last error ratio;  slot 28: 1.0 if the current attempt reaches t1 when accepted.
+ *   Slots 0..15 are the controller's doubles.
+ * One attempt = for i = 1..6 { sbi_amd_dopri5_stage(i) -> y_stage; k[i] = velocity(y_stage, time slot 16+i) };
+ * sbi_amd_dopri5_finish (y5 = the stage-6 state; on acceptance y <- y5 and k[0] <- k[6] in place).
+ * k: HOST array of 7 DEVICE pointers k1..k7 (n floats each), n = rows x D. scratch: 256 doubles (device). */
+#define SBI_AMD_DOPRI5_STATE_FLOATS 32
+int sbi_amd_dopri5_init(float* state, double t0, double t1, double first_step, double atol, double rtol,
+                        void* stream);
+int sbi_amd_dopri5_stage(const float* y, const float* const* k, int32_t stage, const float* state, float* y_stage,
+                         int64_t n, void* stream);
+int sbi_amd_dopri5_finish(float* y, const float* y5, const float* const* k, float* state, double* scratch,
+                          int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ made with tensors that are not on a ROCm device, the call raises.
 from __future__ import annotations
 
 import ctypes
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
 
 import torch
@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 104    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 105    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -124,6 +124,9 @@ _SIGNATURES = {
         [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
          c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "sbi_amd_dopri5_init": (c_int, [c_void_p, c_double, c_double, c_double, c_double, c_double, c_void_p]),
+    "sbi_amd_dopri5_stage": (c_int, [c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sbi_amd_dopri5_finish": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_void_p]),
     "sbi_amd_maf_param_count": (c_int64, [POINTER(MAFConfigC)]),
     "sbi_amd_maf_packed_floats": (c_int64, [POINTER(MAFConfigC)]),
     "sbi_amd_maf_param_offset": (c_int64, [POINTER(MAFConfigC), c_int32, c_int32, c_int32]),

@@ -7,8 +7,9 @@ zuko is a third-party dependency that is absent here, so the step-size controlle
 boundary -- the ODE solution itself is unique, and tests compare against a tight-tolerance solve of the oracle's
 vector field.
 
-All state stays on the device; every right-hand-side evaluation is one launch of the HIP velocity kernel over
-the whole batch, and the controller reads one scalar per attempted step.
+All state stays on the device, the step-size controller included (csrc/ode.hip); every right-hand-side evaluation
+is one launch of the HIP velocity kernel over the whole batch, every stage combination one fused pass, and the host
+never blocks on the attempt it has just enqueued.
 """
 
 from __future__ import annotations
@@ -36,11 +37,115 @@ _B4 = (5179 / 57600, 0.0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 / 2100, 
 @torch.no_grad()
 def odeint_dopri5(f: Callable[[Tensor, Tensor], Tensor], y0: Tensor, t0: float, t1: float, atol: float = 1e-6,
                   rtol: float = 1e-5, max_steps: int = 10_000, first_step: float = 0.05) -> Tensor:
-    """Integrate dy/dt = f(t, y) from t0 to t1 (either direction); ``f`` takes a 1-element time tensor."""
+    """Integrate dy/dt = f(t, y) from t0 to t1 (either direction); ``f`` takes a 1-element time tensor.
+
+    fp32 state on a ROCm device: the device-resident stepper (csrc/ode.hip).  Anything else (the CPU tests of the
+    host logic, fp64 states): the same method written with torch ops and a host-side controller."""
+    if float(t1) == float(t0):
+        return y0.clone()
+    if y0.is_cuda and y0.dtype == torch.float32:
+        return _odeint_device(f, y0, float(t0), float(t1), atol, rtol, max_steps, first_step)
+    return _odeint_host(f, y0, float(t0), float(t1), atol, rtol, max_steps, first_step)
+
+
+def _odeint_device(f, y0: Tensor, t0: float, t1: float, atol: float, rtol: float, max_steps: int,
+                   first_step: float, use_graph: bool = False) -> Tensor:
+    """Time, step size, the accept / reject decision, the controller and the FSAL hand-over live in a 32-float state
+    block on the device (include/sbi_amd_fmpe.h); one attempt is a FIXED sequence of launches -- 6 x (stage
+    combination, velocity) and the finish pair -- with no host decision inside.  The host does not wait for the
+    attempt it has just enqueued: the two flags it needs ("t has reached t1", "the attempt now in flight reaches t1
+    if accepted") are copied to pinned memory after every attempt and read ONE ATTEMPT LATE; only when the second flag
+    says the attempt in flight may be the last does the host wait for it, so no attempt is enqueued behind the end.
+
+    ``use_graph``: capture the attempt once into a HIP graph and replay it.  Measured on MI355X
+    (tools/diag/ode_timing.py): capturing costs about as much as 10 eager attempts and a solve of the trained flows
+    takes 8-25, so it is off by default -- it pays only for callers that integrate for hundreds of attempts."""
+    from ctypes import c_void_p
+
+    from sbi_amd import _lib
+
+    lib = _lib.load()
+    dev = _lib.require_device(y0)
+    y = y0.contiguous().clone()
+    n = y.numel()
+    state = torch.zeros(32, dtype=torch.float32, device=dev)
+    scratch = torch.empty(256, dtype=torch.float64, device=dev)
+    y_stage = [torch.empty_like(y) for _ in range(2)]
+
+    def time_slot(i: int) -> Tensor:      # 1-element views the velocity kernel reads its time from
+        return state[i : i + 1]
+
+    def own(v: Tensor) -> Tensor:
+        if v.shape != y.shape or v.dtype != torch.float32 or not v.is_contiguous():
+            v = v.to(torch.float32).reshape(y.shape).contiguous()
+        return v
+
+    def attempt(k1: Tensor) -> None:
+        stream = _lib.current_stream(dev)
+        ks = [k1]
+        yi = y
+        for i in range(1, 7):
+            yi = y_stage[i & 1]
+            kp = (c_void_p * 7)(*[_lib.ptr(k) for k in ks], *([None] * (7 - len(ks))))
+            _lib.check(lib.sbi_amd_dopri5_stage(_lib.ptr(y), kp, i, _lib.ptr(state), _lib.ptr(yi), n, stream),
+                       "dopri5_stage")
+            ks.append(own(f(time_slot(16 + i), yi)))
+        kp = (c_void_p * 7)(*[_lib.ptr(k) for k in ks])
+        _lib.check(lib.sbi_amd_dopri5_finish(_lib.ptr(y), _lib.ptr(yi), kp, _lib.ptr(state), _lib.ptr(scratch), n,
+                                             stream), "dopri5_finish")
+
+    with torch.cuda.device(dev):
+        _lib.check(lib.sbi_amd_dopri5_init(_lib.ptr(state), t0, t1, float(first_step), float(atol), float(rtol),
+                                           _lib.current_stream(dev)), "dopri5_init")
+        k1 = own(f(time_slot(23), y)).clone()      # ours: the finish kernel overwrites it on acceptance (FSAL)
+        graph = None
+        flags = []
+        maybe_last = float(first_step) >= abs(t1 - t0)      # does the attempt about to be enqueued reach t1?
+        for it in range(max_steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                attempt(k1)
+                if use_graph and it == 0:
+                    # (the eager attempt above doubled as the warm-up: every lazy initialisation inside f is done)
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            attempt(k1)
+                        graph = g
+                    except Exception:   # noqa: BLE001 -- not capturable: stay eager
+                        graph = None
+                        use_graph = False
+                        torch.cuda.synchronize(dev)
+            host = torch.empty(5, dtype=torch.float32, pin_memory=True)
+            host.copy_(state[24:29], non_blocking=True)      # [0] finished, [4] next attempt may be the last
+            ev = torch.cuda.Event()
+            ev.record()
+            # flags of the PREVIOUS attempt (read one attempt late) say whether the attempt just enqueued may be the
+            # last one; if so -- or if that was known already -- wait for it now instead of queueing behind the end
+            wait_now = maybe_last
+            if not wait_now and flags:
+                prev, pev = flags.pop(0)
+                pev.synchronize()
+                if float(prev[0]) != 0.0:
+                    return y            # (the attempt enqueued after `prev` ran with h = 0: y is unchanged)
+                wait_now = float(prev[4]) != 0.0
+            if wait_now:
+                ev.synchronize()
+                if float(host[0]) != 0.0:
+                    return y
+                maybe_last = float(host[4]) != 0.0          # rejected (or not quite there): how about the next one
+                flags = []
+            else:
+                maybe_last = False
+                flags = [(host, ev)]
+    raise RuntimeError("odeint_dopri5: max_steps exceeded")
+
+
+def _odeint_host(f, y0: Tensor, t0: float, t1: float, atol: float, rtol: float, max_steps: int,
+                 first_step: float) -> Tensor:
     direction = 1.0 if t1 >= t0 else -1.0
     span = abs(t1 - t0)
-    if span == 0.0:
-        return y0.clone()
     y = y0.clone()
     t = float(t0)
     h = min(first_step, span)
@@ -70,7 +175,7 @@ def odeint_dopri5(f: Callable[[Tensor, Tensor], Tensor], y0: Tensor, t0: float, 
             if b5 != b4:
                 err.add_(k, alpha=hs * (b5 - b4))
         scale = atol + rtol * torch.maximum(y.abs(), y5.abs())
-        ratio = float(torch.sqrt(torch.mean((err / scale) ** 2)))   # the one host read of the step
+        ratio = float(torch.sqrt(torch.mean((err / scale) ** 2)))
         if ratio <= 1.0:
             t += hs
             y = y5
