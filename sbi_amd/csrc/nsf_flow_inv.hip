@@ -11,7 +11,7 @@ int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, const floa
   if (!cfg || !packed || !zstats || !in || !x || !out_main || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
   NsfPlan pl;
   int nw = 0;
-  int rc = nsf_plan_for_rows(cfg, n, &pl, &nw);
+  int rc = nsf_plan_for_rows(cfg, n, &pl, &nw, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   switch (cfg->K) {

@@ -13,7 +13,7 @@
 #include "debug_env.h"
 
 template <int K, int KSH, bool INV>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(768)
 nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
@@ -144,6 +144,18 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
         zs[zi] = y;
         ld_acc += (live && part == 0) ? ld : 0.f;
       };
+      if (pl.sc_pst2 == pl.sc_pst) {
+        // single staging buffer (12-wave workgroups): GEMM of chunk c, then its spline
+        for (int c = 0; c < nchunks; ++c) {
+          int nn = S.d_tr - c * pl.DCH;
+          nn = nn < pl.DCH ? nn : pl.DCH;
+          if (nn == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, c * pl.DCH);
+          else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, c * pl.DCH);
+          wave_lds_fence();
+          spline_chunk(c, NoYield());
+          wave_lds_fence();
+        }
+      } else {
       {
         const int n0 = S.d_tr < pl.DCH ? S.d_tr : pl.DCH;
         if (n0 == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 0);
@@ -171,6 +183,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
           spline_chunk(c, NoYield());
         }
         wave_lds_fence();
+      }
       }
     }
     TSF(20);

@@ -149,7 +149,14 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   pl->sc_cs = o;
   if (C > 16) o += 16 * pl->CW;   // C <= 16: the standardized context lives in 4 registers per lane
   pl->sc_pst = o; o += pst_sz;
-  pl->sc_pst2 = o; o += pst_sz;
+  // more than two waves per SIMD (nw > 8): ONE staging buffer per wave (4.9 instead of 9.1 KB at the defaults), the
+  // final-layer GEMM of a chunk then runs before that chunk's spline instead of under the previous one's; latency
+  // is covered by the third wave of the SIMD instead of by the second buffer
+  if (nw > 8) {
+    pl->sc_pst2 = pl->sc_pst;
+  } else {
+    pl->sc_pst2 = o; o += pst_sz;
+  }
   pl->sc_us = pl->sc_pst;
   pl->sc_cin = pl->sc_pst2;
   pl->sc_total = round_up(o, 4);
@@ -157,9 +164,14 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
   return 0;
 }
 
-int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out) {
-  // 16 rows per wave; aim for >= 256 workgroups (one per CU) before growing the
-  // workgroup, cap at 8 waves (2 per SIMD).
+int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out, bool wide) {
+  // 16 rows per wave; aim for >= 256 workgroups (one per CU) before growing the workgroup: 8, 4, 2, 1 waves.
+  // `wide` (the sampling direction): 12 waves (3 per SIMD, single staging buffer per wave) when there are enough rows
+  // and the image leaves room; SBI_AMD_ABLATE bit 4096 switches it off, bit 8192 switches it on for every direction.
+  const int abl = sbi_amd_dbg_ablate();
+  if ((wide || (abl & 8192)) && !(abl & (1024 | 4096)) && (n + 16 * 12 - 1) / (16 * 12) >= 256) {
+    if (nsf_build_plan(cfg, 12, pl) == 0) { *nw_out = 12; return 0; }
+  }
   int nw = 8;
   while (nw > 1 && (n + 16 * nw - 1) / (16 * nw) < 256) nw >>= 1;
   if ((sbi_amd_dbg_ablate() & 1024) && nw > 4) nw = 4;   // debug aid: forward kernel with one wave per SIMD

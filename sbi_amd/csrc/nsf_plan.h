@@ -68,7 +68,9 @@ struct NsfPlan {
 // Builds the plan for nw waves per workgroup; returns 0 or SBI_AMD_E_*.
 int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl);
 // Largest nw in {8,4,2,1} (<= nw_max) whose LDS footprint fits 160 KiB.
-int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out);
+// `wide`: allow 12-wave workgroups (3 per SIMD, one staging buffer per wave) when rows and LDS permit -- measured to
+// pay for the sampling direction only
+int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out, bool wide = false);
 // Packed weight image: T consecutive LDS images (img_floats each), written by
 // nsf_pack_kernel from the flat parameters; kernels stage a layer with a float4 copy.
 static inline int64_t nsf_packed_floats(const NsfPlan& pl) { return (int64_t)pl.T * pl.img_floats; }
