@@ -269,7 +269,18 @@ class PosteriorEstimatorTrainer:
         seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
         gen = torch.Generator(device=self._device)
         gen.manual_seed(seed)
-        return lambda n: torch.randperm(n, generator=gen, device=self._device)
+        # permutations are drawn EIGHT AT A TIME per length (argsort of 62-bit random keys, one batched sort): a
+        # `torch.randperm` is a dozen launches, two per epoch was a tenth of the host's enqueue time of an epoch
+        stock: Dict[int, list] = {}
+
+        def perm(n: int) -> Tensor:
+            have = stock.setdefault(n, [])
+            if not have:
+                keys = torch.randint(0, 2**62, (8, n), generator=gen, device=self._device, dtype=torch.int64)
+                have.extend(keys.argsort(dim=1).unbind(0))
+            return have.pop()
+
+        return perm
 
     # ------------------------------------------------------------------ training
     def train(self, num_atoms: int = 10, training_batch_size: int = 200, learning_rate: float = 5e-4,
@@ -378,7 +389,7 @@ class PosteriorEstimatorTrainer:
 
         def batch_losses(idx: Tensor, train: bool, global_batch: int) -> Tensor:
             th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)
-            mk = masks_d.index_select(0, idx)
+            mk = masks_d.index_select(0, idx) if atomic else None      # (only the atomic loss reads the prior masks)
             if fused:
                 if train:
                     if atomic:
@@ -423,7 +434,8 @@ class PosteriorEstimatorTrainer:
             if pipelined:
                 rec["snap"] = self._stepper.snapshot()      # weights + optimizer state after this epoch's steps
             net.eval()
-            val_epoch_idx = val_idx[perm_of(n_val)]
+            # (every validation row is used when the batches tile the split exactly: the order of a sum is immaterial)
+            val_epoch_idx = val_idx if n_val_batches * Bv == n_val else val_idx[perm_of(n_val)]
             for b in range(n_val_batches):
                 idx = my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv])
                 sums[1] += batch_losses(idx, False, Bv).sum()
