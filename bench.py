@@ -238,8 +238,8 @@ def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
 
 # ----------------------------------------------------------------------------------------- legs
 class TrainLeg:
-    """The NPE inner loop on resident simulations: per step a fresh device permutation, the batch gather and the
-    fused step (what `NPE.train` does per minibatch, npe.py)."""
+    """The NPE inner loop on resident simulations: per step a fresh device permutation (drawn eight at a time, as
+    `NPE._epoch_permutations` draws them), the batch gather and the fused step (what `NPE.train` does per minibatch)."""
 
     def __init__(self, est, theta_all, x_all, batch, distributed, global_batch):
         from sbi_amd.inference.trainers.fused import FusedTrainStep
@@ -248,9 +248,17 @@ class TrainLeg:
         self.global_batch = global_batch
         self.stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
         self.events = []          # (start, end) HIP events around the fused step alone (no permutation / gather)
+        self.perms = []           # drawn eight at a time, as NPE._epoch_permutations does (one batched argsort)
+
+    def _perm(self):
+        if not self.perms:
+            n, dev = self.theta_all.shape[0], self.theta_all.device
+            keys = torch.randint(0, 2**62, (8, n), device=dev, dtype=torch.int64)
+            self.perms.extend(keys.argsort(dim=1).unbind(0))
+        return self.perms.pop()
 
     def __call__(self):
-        idx = torch.randperm(self.theta_all.shape[0], device=self.theta_all.device)[: self.batch]
+        idx = self._perm()[: self.batch]
         th, xx = self.theta_all.index_select(0, idx), self.x_all.index_select(0, idx)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
