@@ -64,3 +64,33 @@ def test_unsupported_configs_are_refused_not_degraded():
         _lib.E_BADARG
     with pytest.raises(RuntimeError, match="unsupported|not supported"):
         _lib.check(_lib.E_UNSUPPORTED, "x")
+
+
+def test_training_envelope_and_refusals_are_host_side_decisions():
+    """`sbi_amd_nsf_train_workspace_floats` answers on the host (no device call) whether a shape trains: the
+    wave-specialised backward kernel's shapes, the generic training pass beyond them (theta-dim > 15, 3-4 blocks,
+    wide x), E_LDS once a transform's weight image plus the kernel's tiles no longer fit 160 KiB."""
+    lib = _lib.load()
+
+    def ws(**kw):
+        return lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(**kw).c_config(), 4096)
+
+    # the benchmark shape and the generic-pass shapes of tests/test_nsf_train_gpu.py
+    for kw in (dict(D=10, C=10), dict(D=1, C=3), dict(D=15, C=20, num_transforms=3),
+               dict(D=10, C=10, hidden_features=64, num_transforms=2),
+               dict(D=10, C=10, num_blocks=3, num_transforms=2), dict(D=20, C=10, num_transforms=2),
+               dict(D=32, C=6, num_transforms=3, num_bins=8), dict(D=16, C=40, num_transforms=2),
+               dict(D=12, C=70, num_transforms=2, hidden_features=48),
+               dict(D=6, C=60, num_transforms=2, num_blocks=4, hidden_features=32)):
+        assert ws(**kw) > 0, kw
+    # the envelope DESIGN.md section 1 quotes for sbi's default hyper-parameters (hidden 50, 10 bins, 2 blocks)
+    for D, cmax in ((2, 127), (5, 110), (10, 94), (16, 66), (20, 54), (24, 32)):
+        assert ws(D=D, C=cmax) > 0, (D, cmax)
+        assert ws(D=D, C=cmax + 1) == _lib.E_LDS, (D, cmax)
+    assert ws(D=32, C=4) == _lib.E_LDS
+    # a larger workspace for a larger batch, and the generic pass needs more of it than the fused one
+    small = lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10).c_config(), 1024)
+    big = lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10).c_config(), 65536)
+    assert 0 < small < big
+    assert lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10, hidden_features=128).c_config(), 1024) == \
+        _lib.E_UNSUPPORTED
