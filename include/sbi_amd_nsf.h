@@ -103,7 +103,13 @@ int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const
  * d theta_n (needed by MAP / gradient_ascent, base_posterior.py:216-323).  grad_x_out (n,C) optional, needs
  * x_rows == n: w_n * d loss_n / d x_n, the gradient a trainable embedding net in front of the flow
  * back-propagates (flow.py:1395-1416 puts `standardizing_net -> embedding_net` there).
- * `workspace` must hold sbi_amd_nsf_train_workspace_floats(cfg, n) floats. */
+ * `workspace` must hold sbi_amd_nsf_train_workspace_floats(cfg, n) floats.
+ * Which shapes train is decided on the HOST by sbi_amd_nsf_train_workspace_floats (a negative return is the
+ * refusal: no device call has happened): theta-dim <= 15, <= 2 blocks, identity features + x-dim <= 32 take the
+ * wave-specialised backward kernel; wider shapes (theta-dim up to 24 with x-dim 32, x-dim up to 94 at theta-dim 10
+ * with hidden 50 / 10 bins / 2 blocks; 3-4 blocks) take the generic pass (row-parallel backward kernel + split-K
+ * weight-gradient GEMMs, more workspace, no grad_x_out); SBI_AMD_E_LDS once one transform's weight image plus the
+ * kernel's tiles exceed 160 KiB of LDS. */
 int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n);
 int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const float* params, const float* packed,
                              const float* zstats,
