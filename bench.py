@@ -253,7 +253,7 @@ class TrainLeg:
     def _perm(self):
         if not self.perms:
             n, dev = self.theta_all.shape[0], self.theta_all.device
-            keys = torch.randint(0, 2**62, (8, n), device=dev, dtype=torch.int64)
+            keys = torch.randint(0, 2**31 - 1, (8, n), device=dev, dtype=torch.int32)
             self.perms.extend(keys.argsort(dim=1).unbind(0))
         return self.perms.pop()
 

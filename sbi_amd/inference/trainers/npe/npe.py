@@ -269,14 +269,15 @@ class PosteriorEstimatorTrainer:
         seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
         gen = torch.Generator(device=self._device)
         gen.manual_seed(seed)
-        # permutations are drawn EIGHT AT A TIME per length (argsort of 62-bit random keys, one batched sort): a
-        # `torch.randperm` is a dozen launches, two per epoch was a tenth of the host's enqueue time of an epoch
+        # permutations are drawn EIGHT AT A TIME per length: argsort of 31-bit random keys (four radix passes; the
+        # handful of ties among 1e5 keys fall back to index order), one batched sort -- a `torch.randperm` is a dozen
+        # launches, two per epoch was a tenth of the host's enqueue time of an epoch
         stock: Dict[int, list] = {}
 
         def perm(n: int) -> Tensor:
             have = stock.setdefault(n, [])
             if not have:
-                keys = torch.randint(0, 2**62, (8, n), generator=gen, device=self._device, dtype=torch.int64)
+                keys = torch.randint(0, 2**31 - 1, (8, n), generator=gen, device=self._device, dtype=torch.int32)
                 have.extend(keys.argsort(dim=1).unbind(0))
             return have.pop()
 
