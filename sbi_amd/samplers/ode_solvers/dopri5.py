@@ -89,7 +89,12 @@ def _odeint_device(f, y0: Tensor, t0: float, t1: float, atol: float, rtol: float
             kp = (c_void_p * 7)(*[_lib.ptr(k) for k in ks], *([None] * (7 - len(ks))))
             _lib.check(lib.sbi_amd_dopri5_stage(_lib.ptr(y), kp, i, _lib.ptr(state), _lib.ptr(yi), n, stream),
                        "dopri5_stage")
-            ks.append(own(f(time_slot(16 + i), yi)))
+            k = own(f(time_slot(16 + i), yi))
+            # (the seven stage derivatives are read together at the end of the attempt: a right-hand side that hands
+            # back its input or one persistent output buffer gets a private copy)
+            if k.data_ptr() == yi.data_ptr() or any(k.data_ptr() == o.data_ptr() for o in ks):
+                k = k.clone()
+            ks.append(k)
         kp = (c_void_p * 7)(*[_lib.ptr(k) for k in ks])
         _lib.check(lib.sbi_amd_dopri5_finish(_lib.ptr(y), _lib.ptr(yi), kp, _lib.ptr(state), _lib.ptr(scratch), n,
                                              stream), "dopri5_finish")
