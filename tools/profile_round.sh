@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/profile_round.sh <tag> [commit]
-#   -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc.txt,traffic.json}; copy what should be judged into profiles/
+#   -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc.txt,traffic.json,{maf,zuko}_bench.json,
+#      {maf,generic}_kernel_stats.csv}; copy what should be judged into profiles/
 tag=${1:-r2}
 commit=${2:-unknown}
 R=$GRAFT_REPO_ROOT
@@ -36,5 +37,13 @@ for f in sorted(glob.glob("$out/pmc_*/*/*counter_collection.csv")):
         if k.startswith("void at::") or k.startswith("__amd"): continue
         print(k, {c: round(v) for c, v in d.items()}, "launches", max(calls[(k, c)] for c in d))
 PY
-rm -rf $out/trace $out/pmc_*/ $out/hbm_*/
+# sibling flows and the generic training pass: bench lines + kernel traces (bounded: a hung profiler must not eat the box)
+for m in maf zuko; do
+  timeout -k 5 200 python $R/bench.py --mode $m --no-cpu-baseline > $out/${m}_bench.json 2> $out/${m}_bench.err < /dev/null
+done
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_maf -- python $R/bench.py --mode maf --steps 20 --warmup 5 --no-cpu-baseline > $out/trace_maf.log 2>&1 < /dev/null
+f=$(ls $out/trace_maf/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/maf_kernel_stats.csv
+SBI_AMD_ABLATE=2048 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_gen -- python $R/bench.py --mode train --steps 20 --warmup 5 --no-cpu-baseline > $out/trace_gen.log 2>&1 < /dev/null
+f=$(ls $out/trace_gen/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/generic_kernel_stats.csv
+rm -rf $out/trace $out/trace_maf $out/trace_gen $out/pmc_*/ $out/hbm_*/
 cat $out/bench.json | cut -c1-600
