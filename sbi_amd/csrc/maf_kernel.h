@@ -317,8 +317,8 @@ struct MafBwdArgs {
   float* gz_dn;            // (n, D) gradient wrt this transform's input (t > 0)
   float* grad_theta;       // optional (n, D), written by t == 0
   // gradient operands of the weight-gradient GEMMs are stored M-TILE MAJOR: column c of row r lives at
-  // plane (c >> 4) * npad * 16 + r * 16 + (c & 15), so that maf_dw_kernel streams a (256 rows x 16 columns) tile
-  // as one contiguous 16 KB block
+  // plane (c >> 4) * npad * 16 + r * 16 + (c & 15), so that maf_dw_kernel streams a (128 rows x 16 columns) tile
+  // as one contiguous 8 KB block (within a 16-block the hidden layers' planes are in fragment order, MafLin.gperm)
   float* GP;               // DP / 16 planes: gradient wrt the raw spline parameters, 16*PT columns per dim
   float* ACT;              // (n, (NB+1)*64) h_0 .. h_NB, row major (inputs of the GEMMs)
   float* G;                // (NB+2) x 4 planes; slot 0: d/d(a1), slot 1: d/d(context pre-activation), 2+b: block b

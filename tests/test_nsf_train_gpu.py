@@ -163,7 +163,7 @@ def test_training_reduces_loss_full_batch_65536():
 @pytest.mark.parametrize("cfg", [dict(D=4, C=7), GENERIC], ids=["fast", "generic"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 64, 65, 129, 257])
 def test_tiny_and_ragged_batches_match_autograd(n, cfg):
-    """Tile (64 rows), wave-tile (16 rows) and split-K chunk (256 rows) boundaries: a single row, one short of /
+    """Tile (64 rows), wave-tile (16 rows) and split-K sub-chunk (128 rows) boundaries: a single row, one short of /
     one past a boundary."""
     from sbi_amd.inference.trainers.fused import FusedTrainStep
 
