@@ -24,6 +24,7 @@ included), `fmpe_train` (configs[4] step).
 from __future__ import annotations
 
 import argparse
+import gc
 import glob
 import json
 import os
@@ -67,6 +68,34 @@ def launch_ranks(n: int, script: str, argv, require_gpus: bool = True, extra_env
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
     return subprocess.call(cmd, env=env)
+
+
+def rccl_one_rank_leg(args, plain):
+    """The train leg once more as rank 0 of a ONE-rank `nccl` (= RCCL) process group, self-launched through
+    torch.distributed.run exactly as the driver launches N > 1: communicator init, parameter broadcast, the
+    all-reduce of the flat gradient between backward and clip + Adam, barriers -- the data-parallel code path on the
+    one GPU a 1-GPU box has.  `plain` = this process's own train result (no process group) for the ratio."""
+    env = dict(os.environ)
+    env.update({"SBI_AMD_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                "OMP_NUM_THREADS": env.get("OMP_NUM_THREADS", "4")})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), "--gpus", "1", "--mode", "train",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--no-cpu-baseline",
+           "--no-rccl-leg"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = next(l for l in reversed(p.stdout.splitlines()) if l.startswith("{"))
+        j = json.loads(line)
+    except Exception as e:   # noqa: BLE001 -- the headline must not die with the side leg
+        return {"error": f"{type(e).__name__}: {e}"}
+    return {"metric": "NPE train (theta,x)-pairs/sec as rank 0 of a 1-rank RCCL group", "value": j["value"],
+            "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+            "fused_step_device_ms": j["roofline"]["device_ms_per_step"],
+            "rccl_ranks": j["config"]["rccl_ranks"],
+            "allreduce_us_98025_floats": j["config"]["rccl_allreduce_us_98025_floats"],
+            "ms_per_step_vs_no_process_group": j["ms_per_step"] / plain["ms_per_step"],
+            "launched_as": "python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 ... bench.py --gpus 1 "
+                           "--mode train (SBI_AMD_FORCE_DIST=1)"}
 
 
 # ----------------------------------------------------------------------------------------- data / model
@@ -174,25 +203,43 @@ def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
 
 
 # ----------------------------------------------------------------------------------------- timing / roofline
+LAST_TIMED: dict = {}     # host-side enqueue statistics of the most recent timed() call
+
+
 def timed(step, steps, warmup, device, dist=None):
     """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
     for _ in range(warmup):
         step()
+    # The cyclic garbage collector stays out of the timed region (as `timeit` does): a generation-2 pass over the
+    # objects earlier legs left behind is tens of milliseconds of HOST time that would be charged to K device steps
+    # (SBI_AMD_BENCH_KEEP_GC=1 keeps it on, for A/B).
+    gc_on = gc.isenabled()
+    if os.environ.get("SBI_AMD_BENCH_KEEP_GC") != "1":
+        gc.collect()
+        gc.disable()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    host = []
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
+        h0 = time.perf_counter()
         step()
+        host.append(time.perf_counter() - h0)
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if gc_on:
+        gc.enable()
+    LAST_TIMED.clear()
+    LAST_TIMED.update(host_enqueue_ms_max=max(host) * 1e3, host_enqueue_ms_argmax=host.index(max(host)),
+                      host_enqueue_ms_median=sorted(host)[len(host) // 2] * 1e3)
     dev_ms = ev0.elapsed_time(ev1)     # HIP events on the stream the kernels are launched on
     t = torch.tensor([wall], device=device, dtype=torch.float64)
     if dist is not None:
@@ -325,6 +372,7 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
     stepper = FusedFMPEStep(fm, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
     wall, dev_ms = timed(lambda: stepper.step(th_f, x_f, global_batch=global_batch), args.steps, args.warmup, device,
                          dist)
+    host_stats = dict(LAST_TIMED)
     h = fm.net.hyper
     H, L, E = h.hidden_features, h.num_layers, h.time_embedding_dim
     f_fwd = 2.0 * (DF * H + DF * H + 2 * H * H + E * H + L * H * H + H * DF)   # dense FLOP per row, forward
@@ -388,7 +436,7 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
         "config": {"workload": f"BASELINE configs[4] step: FMPE default vector-field MLP (hidden {H}, "
                                f"{L} layers, {h.param_count()} parameters), theta-dim {DF}, x-dim {DF}, "
                                f"batch {B} per GPU, synthetic linear-Gaussian", "parallelism": f"dp{world}"},
-        "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms, "fmpe"),
+        "roofline": roofline(3 * f_fwd, B, args.steps, dev_ms, "fmpe"), "host": host_stats,
         "_cpu_baseline_fn": lambda: fmpe_cpu_baseline(fm, th_f, x_f)}
 
 
@@ -407,6 +455,8 @@ def main(argv=None):
     ap.add_argument("--npe-epochs", type=int, default=200, help="epochs of the NPE.train() (M2) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-sampling", action="store_true", help="fmpe mode: no ODE-sampling leg (profiling passes)")
+    ap.add_argument("--no-rccl-leg", action="store_true",
+                    help="N = 1: skip the self-launched 1-rank RCCL run of the train leg (`rccl_1rank` object)")
     args = ap.parse_args(argv)
 
     if args.gpus < 1:
@@ -430,6 +480,7 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     dist = None
     rccl_world = 1
+    allreduce_us = None
     if distributed:
         import torch.distributed as dist
 
@@ -440,6 +491,18 @@ def main(argv=None):
         rccl_world = int(probe.item())          # the number of ranks RCCL actually reduced over
         if rccl_world != world:
             raise SystemExit(f"bench.py: RCCL all-reduce saw {rccl_world} ranks, expected {world}")
+        # the collective of one training step in isolation: all-reduce of a flat 98 025-float gradient buffer
+        gbuf = torch.zeros(98_025, device=device)
+        for _ in range(10):
+            dist.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(gbuf)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_us = e0.elapsed_time(e1) / 50 * 1e3
 
     if args.scaling == "strong":
         if args.batch % world:
@@ -632,6 +695,7 @@ def main(argv=None):
                             "ms_per_step": wall / args.steps * 1e3,
                             "roofline": roofline(F_TRAIN, B, args.steps, fused_ms, "train")}
         results["train"]["roofline"]["whole_step_device_ms"] = dev_ms / args.steps
+        results["train"]["host"] = dict(LAST_TIMED)
         if world > 1 and args.scaling == "weak" and args.batch % world == 0:
             # the same inner loop with the 65 536-pair global batch split over the ranks
             Bs = args.batch // world
@@ -662,11 +726,14 @@ def main(argv=None):
                                    f"step (pack, loss fwd+bwd, grad all-reduce, clip+Adam)"
                        if head == "train" else
                        f"NSF log_prob, theta-dim {D}, x-dim {C}, batch {args.batch} {per}",
-                       "parallelism": f"dp{world}", "rccl_ranks": rccl_world if distributed else 1},
+                       "parallelism": f"dp{world}", "rccl_ranks": rccl_world if distributed else 1,
+                       "rccl_allreduce_us_98025_floats": allreduce_us},
             # whole step (forward + T backward launches + reduce + clip/Adam) against dense fp32 MFMA;
             # per-kernel durations: profiles/*kernel_stats.csv
             "roofline": r["roofline"],
         }
+        if "host" in r:
+            out["host"] = r["host"]
         if strong_obj is not None:
             out["strong_scaling"] = strong_obj
         for key in ("log_prob", "log_prob_broadcast_x"):
@@ -681,11 +748,13 @@ def main(argv=None):
             out["posterior_sample"] = {"metric": "DirectPosterior.sample draws/sec", "value": sp["value"],
                                        "unit": sp["unit"], "draws_per_step": args.draws, "steps": sp["steps"],
                                        "ms_per_step": sp["ms_per_step"], "roofline": sp["roofline"]}
+        if world == 1 and not distributed and head == "train" and not args.no_rccl_leg:
+            out["rccl_1rank"] = rccl_one_rank_leg(args, r)
         if npe_obj is not None:
             out["npe_train"] = npe_obj
         if fm_out is not None:
             out["fmpe_train"] = {k: fm_out[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline",
-                                                        "posterior_sample")}
+                                                        "host", "posterior_sample")}
             out["fmpe_train"]["workload"] = fm_out["config"]["workload"]
             if world == 1 and not args.no_cpu_baseline:
                 out["fmpe_train"]["cpu_baseline"] = fm_out["_cpu_baseline_fn"]()

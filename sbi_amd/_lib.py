@@ -163,7 +163,17 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if not path.exists() and not build_if_missing:
         raise RuntimeError(f"{path} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
     if build_if_missing:
-        _build.build()      # no-op when the library matches the sources on disk (content hash, file-locked)
+        try:
+            _build.build()      # no-op when the library matches the sources on disk (content hash, file-locked)
+        except RuntimeError as e:
+            # a machine with a prebuilt library but no hipcc (or no `.srchash` next to it) must stay usable: fall back
+            # on the ABI-version check below instead of refusing to load
+            if not path.exists() or "hipcc not found" not in str(e):
+                raise
+            import warnings
+
+            warnings.warn(f"sbi_amd: {path.name} could not be checked against the sources ({e}); loading it as is "
+                          "(the ABI version is still verified)", stacklevel=2)
     elif _build.needs_build():
         raise RuntimeError(f"{path} is stale (built from different sources); rebuild it with "
                            "`python -c 'import __graft_entry__ as g; g.build()'`")

@@ -12,8 +12,10 @@
 #include "nsf_device.h"
 #include "debug_env.h"
 
+// Only the sampling direction ever launches 12-wave workgroups (nsf_plan_for_rows(..., wide)); the density direction
+// keeps the 512-thread bound so that its register allocation is not capped at three waves per SIMD.
 template <int K, int KSH, bool INV>
-__global__ void __launch_bounds__(768)
+__global__ void __launch_bounds__(INV ? 768 : 512)
 nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,

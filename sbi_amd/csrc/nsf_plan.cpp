@@ -167,9 +167,9 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
 int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out, bool wide) {
   // 16 rows per wave; aim for >= 256 workgroups (one per CU) before growing the workgroup: 8, 4, 2, 1 waves.
   // `wide` (the sampling direction): 12 waves (3 per SIMD, single staging buffer per wave) when there are enough rows
-  // and the image leaves room; SBI_AMD_ABLATE bit 4096 switches it off, bit 8192 switches it on for every direction.
+  // and the image leaves room; SBI_AMD_ABLATE bit 4096 switches it off (the density direction is compiled for <= 8 waves and never takes it).
   const int abl = sbi_amd_dbg_ablate();
-  if ((wide || (abl & 8192)) && !(abl & (1024 | 4096)) && (n + 16 * 12 - 1) / (16 * 12) >= 256) {
+  if (wide && !(abl & (1024 | 4096)) && (n + 16 * 12 - 1) / (16 * 12) >= 256) {
     if (nsf_build_plan(cfg, 12, pl) == 0) { *nw_out = 12; return 0; }
   }
   int nw = 8;

@@ -67,7 +67,10 @@ class MCMCPosterior:
     @property
     def theta_transform(self):
         """constrained -> unconstrained (what `mcmc_transform` returns)."""
-        return torch.distributions.transforms._InverseTransform(self._to_constrained)
+        # `.inv` of a plain transform builds its `_InverseTransform`; `.inv` of an `_InverseTransform` hands back the
+        # parent it wraps -- either way the transform the caller passed in (wrapping unconditionally double-inverted a
+        # plain transform and raised NotImplementedError in .sample())
+        return self._to_constrained.inv
 
     # -- x handling (base_posterior.py:170-214) ------------------------------------------
     @property

@@ -50,7 +50,10 @@ class RejectionPosterior:
     @property
     def theta_transform(self):
         """constrained -> unconstrained (what `mcmc_transform(prior)` returns)"""
-        return torch.distributions.transforms._InverseTransform(self._to_constrained)
+        # `.inv` of a plain transform builds its `_InverseTransform`; `.inv` of an `_InverseTransform` hands back the
+        # parent it wraps -- either way the transform the caller passed in (wrapping unconditionally double-inverted a
+        # plain transform and raised NotImplementedError in .sample())
+        return self._to_constrained.inv
 
     # -- x_o handling (base_posterior.py:170-214) ------------------------------------------------------
     @property

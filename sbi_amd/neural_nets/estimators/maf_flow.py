@@ -141,6 +141,12 @@ class MAFNet(nn.Module):
             sd[prefix + "_transform._transforms.0._scale"] = self.zstats[h.D : 2 * h.D].clone()
         for key, off, n, shape in self._slices():
             sd[prefix + key] = flat[off : off + n].reshape(shape).clone()
+        # nflows' MaskedLinear registers its `mask` and `degrees` as buffers (made.py): a strict load into a real
+        # nflows Flow needs them (round-2 advisor finding)
+        for t in range(h.num_transforms):
+            for key, mask, degrees in self._mask_buffers(t):
+                sd[prefix + key + "mask"] = mask
+                sd[prefix + key + "degrees"] = degrees
         for t in range(h.num_transforms):
             sd[prefix + f"_transform._transforms.{first + 2 * t + 1}._permutation"] = self.perms[t].to(torch.int64)
         if self.z_score_x:
@@ -148,10 +154,31 @@ class MAFNet(nn.Module):
             sd[prefix + "_embedding_net.0._std"] = self.zstats[2 * h.D + h.C :].clone()
         return sd
 
+    def _mask_buffers(self, t: int):
+        """(module key prefix, mask, degrees) of transform t's masked linears, as nflows' MADE builds them with
+        random_mask=False (the only form `build_maf_rqs` produces, flow.py:291-308)."""
+        h = self.hyper
+        first = 1 if self.z_score_theta else 0
+        pre = f"_transform._transforms.{first + 2 * t}.autoregressive_net."
+        hd = h.hidden_degrees()
+        od = torch.repeat_interleave(torch.arange(1, h.D + 1), 3 * h.num_bins - 1)
+        yield pre + "initial_layer.", h.mask(0), hd.clone()
+        for b in range(h.num_blocks):
+            yield pre + f"blocks.{b}.linear.", h.mask(2), hd.clone()
+        yield pre + "final_layer.", h.mask(3), od
+
     @torch.no_grad()
     def load_nflows_state_dict(self, sd: Dict[str, Tensor], prefix: str = "net.") -> None:
         h = self.hyper
         first = 1 if self.z_score_theta else 0
+        # a checkpoint whose masks differ from the degree rule the kernels evaluate (random_mask=True, a different
+        # nflows version) must not load silently
+        for t in range(h.num_transforms):
+            for key, mask, _ in self._mask_buffers(t):
+                got = sd.get(prefix + key + "mask")
+                if got is not None and not torch.equal(got.to(torch.float32).cpu(), mask):
+                    raise ValueError(f"{key}mask differs from the MADE degree masks the maf_rqs kernels apply "
+                                     "(random_mask=True checkpoints are not supported)")
         for key, off, n, shape in self._slices():
             src = sd[prefix + key]
             if tuple(src.shape) != tuple(shape):

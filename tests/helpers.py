@@ -42,3 +42,41 @@ def make_inputs(n, D, C, seed=3, spread=1.0):
     x = torch.randn(n, C, generator=g) * (0.2**0.5) * spread
     theta[::7] *= 6.0   # push some rows far into the tails
     return theta, x
+
+
+def spline_knot_distances(oracle, theta, x):
+    """For every row: the distance of each forward spline evaluation's input to its nearest INTERIOR knot, computed
+    in float64 through the oracle, in units of the float32 spacing at the tail bound (np.spacing(float32(B)): the
+    resolution at which an fp32 implementation can place a knot of a spline on [-B, B]).  Returns
+    (rows, num_transforms * d_tr) -- 25 evaluations per row at theta-dim 10 -- with +inf for inputs in the tails.
+
+    Used by the full-size gradient test to VERIFY that the rows it sets aside are knot-straddling rows (the RQ spline
+    is C1: at a knot log p is continuous but its parameter / input gradient is two-valued)."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    import oracle.nsf_oracle as mod
+
+    captured = []
+    real = mod.unconstrained_rational_quadratic_spline
+
+    def spy(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse=False,
+            tail_bound=1.0, min_bin_width=mod.DEFAULT_MIN_BIN_WIDTH, **kw):
+        K = unnormalized_widths.shape[-1]
+        w = min_bin_width + (1 - min_bin_width * K) * F.softmax(unnormalized_widths, dim=-1)
+        knots = 2 * tail_bound * torch.cumsum(w, dim=-1)[..., :-1] - tail_bound          # the K-1 interior knots
+        d = (inputs[..., None] - knots).abs().min(dim=-1).values
+        d = torch.where((inputs >= -tail_bound) & (inputs <= tail_bound), d, torch.full_like(d, float("inf")))
+        captured.append((d / float(np.spacing(np.float32(tail_bound)))).detach())
+        return real(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse=inverse,
+                    tail_bound=tail_bound, min_bin_width=min_bin_width, **kw)
+
+    mod.unconstrained_rational_quadratic_spline = spy
+    try:
+        oracle.double()
+        with torch.no_grad():
+            oracle.log_prob(theta.double(), x.double())
+    finally:
+        mod.unconstrained_rational_quadratic_spline = real
+        oracle.float()
+    return torch.cat([c.reshape(theta.shape[0], -1) for c in captured], dim=1)

@@ -61,3 +61,61 @@ def test_rejection_sample_timeout_and_m_warning():
         rejection_sample(lambda th: prop.log_prob(th), prop, num_samples=10, num_samples_to_find_max=50,
                          num_iter_to_find_max=2, m=0.9)
     assert any("m < 1.0" in str(x.message) for x in w)
+
+
+class _AnalyticPotential:
+    """Smallest object with the potential role (callable, set_x, device): a fixed Gaussian log-density."""
+
+    device = "cpu"
+
+    def __init__(self):
+        self.t = MultivariateNormal(torch.tensor([0.2, -0.1]), 0.04 * torch.eye(2))
+
+    def set_x(self, x):
+        self.x = x
+
+    def to(self, device):
+        return self
+
+    def __call__(self, theta, track_gradients=True):
+        return self.t.log_prob(theta)
+
+
+@pytest.mark.parametrize("tt", ["none", "affine", "mcmc_transform"])
+def test_rejection_posterior_constructed_directly_accepts_any_theta_transform(tt):
+    """rejection_posterior.py:44-60 of the reference: `theta_transform=None` (identity) and plain transforms are
+    legal constructor arguments, not only what `mcmc_transform` returns (round-2 advisor finding)."""
+    from torch.distributions.transforms import AffineTransform
+
+    from sbi_amd.inference.posteriors.rejection_posterior import RejectionPosterior
+    from sbi_amd.utils.sbiutils import mcmc_transform
+
+    prior = MultivariateNormal(torch.zeros(2), 0.5 * torch.eye(2))
+    transform = {"none": None, "affine": AffineTransform(torch.tensor([0.1, 0.0]), torch.tensor([2.0, 0.5])),
+                 "mcmc_transform": mcmc_transform(prior, device="cpu")}[tt]
+    post = RejectionPosterior(_AnalyticPotential(), prior, theta_transform=transform, device="cpu",
+                              num_samples_to_find_max=500, num_iter_to_find_max=20)
+    post.set_default_x(torch.zeros(1, 2))
+    torch.manual_seed(3)
+    s = post.sample((400,), show_progress_bars=False)
+    assert s.shape == (400, 2)
+    assert (s.mean(0) - torch.tensor([0.2, -0.1])).abs().max() < 0.06
+    # the property hands back the constrained -> unconstrained direction it was given
+    th = torch.tensor([[0.3, -0.2]])
+    want = th if transform is None else transform(th)
+    assert torch.allclose(post.theta_transform(th), want)
+    m = post.map(num_iter=50, num_to_optimize=10, num_init_samples=100)
+    assert (m.reshape(-1) - torch.tensor([0.2, -0.1])).abs().max() < 0.05
+
+
+def test_mcmc_posterior_theta_transform_property_round_trips_plain_transforms():
+    from torch.distributions.transforms import AffineTransform
+
+    from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+
+    prior = MultivariateNormal(torch.zeros(2), torch.eye(2))
+    th = torch.tensor([[0.3, -0.2]])
+    for transform in (None, AffineTransform(torch.tensor([0.1, 0.0]), torch.tensor([2.0, 0.5]))):
+        post = MCMCPosterior(_AnalyticPotential(), prior, theta_transform=transform, device="cpu")
+        want = th if transform is None else transform(th)
+        assert torch.allclose(post.theta_transform(th), want)

@@ -220,3 +220,44 @@ def test_npe_with_maf_rqs_recovers_the_linear_gaussian_posterior():
     assert 0.4 <= score <= 0.6
     lp = post.log_prob(samples[:5].cuda())
     assert torch.isfinite(lp).all()
+
+
+def test_kernels_implement_the_other_reading_of_the_sqrt_hidden_question():
+    """`scale_by_sqrt_hidden=True` (see tests/test_maf_oracle.py::test_both_readings_...): the HIP path with the
+    flag set matches the oracle with the flag set -- log_prob, sample and the flat gradient -- so flipping the
+    default, should a real nflows say so, needs no kernel work."""
+    import dataclasses
+
+    cfg = dict(D=5, C=4, hidden_features=32, num_transforms=3, num_bins=8)
+    theta, x = linear_gaussian_data(1000, cfg["D"], cfg["C"])
+    torch.manual_seed(1)
+    oracle = MAFRQSOracle(theta, x, scale_by_sqrt_hidden=True, **{k: v for k, v in cfg.items() if k not in "DC"})
+    g = torch.Generator().manual_seed(101)
+    with torch.no_grad():
+        for p in oracle.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    est = build_maf_rqs(theta, x, **{k: v for k, v in cfg.items() if k not in "DC"})
+    est.net.hyper = dataclasses.replace(est.net.hyper, scale_by_sqrt_hidden=True)
+    est.net.load_nflows_state_dict(oracle.state_dict())
+    est = est.cuda()
+    th, xx = theta[:600], x[:600]
+    with torch.no_grad():
+        ref = oracle.log_prob(th, xx)[0]
+        plain = MAFRQSOracle(theta, x, **{k: v for k, v in cfg.items() if k not in "DC"})
+        plain.load_state_dict(oracle.state_dict())
+        other = plain.log_prob(th, xx)[0]
+    got = est.log_prob(th.cuda(), xx.cuda())[0].cpu()
+    assert (got - ref).abs().max() <= 1e-5 * (1 + ref.abs().max())
+    assert (got - other).abs().max() > 1e-3                     # and it is NOT the unscaled reading
+    noise = torch.randn(256, cfg["D"], generator=g)
+    with torch.no_grad():
+        s_ref = oracle.sample_from_noise(noise, xx[:256])[0]
+    assert (est.sample_from_noise(noise.cuda(), xx[:256].cuda()).cpu() - s_ref).abs().max() < 1e-5
+    from sbi_amd.neural_nets.estimators.maf_flow import maf_loss_fwd_bwd
+
+    oracle.zero_grad()
+    oracle.loss(th, xx).mean().backward()
+    gref = oracle_flat_grad(oracle, est)
+    grad = torch.empty_like(est.net.flat_params.data)
+    maf_loss_fwd_bwd(est.net, th.cuda(), xx.cuda(), None, 1.0 / 600, grad)
+    assert (grad.cpu() - gref).abs().max() <= 2e-4 * gref.abs().max()

@@ -97,8 +97,8 @@ def test_builder_matches_the_oracles_construction_and_exchanges_weights():
     o = MAFRQSOracle(theta, x)
     assert isinstance(est, MAFRQSFlow) and est.net.hyper.param_count() == sum(p.numel() for p in o.parameters())
     mine, ref = est.net.nflows_state_dict(), o.state_dict()
-    assert set(mine) <= set(ref)                              # every exported key is an nflows key ...
-    assert {k for k in ref if k not in mine} == {k for k in ref if k.endswith((".mask", ".degrees"))}
+    assert set(mine) == set(ref)                              # exactly nflows' keys, mask / degrees buffers included
+    o.load_state_dict(mine, strict=True)                      # ... so a strict load into the nflows-shaped module works
     for k in mine:                                            # ... and the same seed gives the same init
         assert torch.equal(mine[k].to(ref[k].dtype), ref[k]), k
     with torch.no_grad():
@@ -107,6 +107,11 @@ def test_builder_matches_the_oracles_construction_and_exchanges_weights():
     est.net.load_nflows_state_dict(o.state_dict())
     back = est.net.nflows_state_dict()
     assert all(torch.equal(back[k].to(ref[k].dtype), o.state_dict()[k]) for k in back)
+    bad = dict(o.state_dict())                                # a checkpoint with other masks must not load silently
+    key = next(k for k in bad if k.endswith("initial_layer.mask"))
+    bad[key] = 1.0 - bad[key]
+    with pytest.raises(ValueError, match="degree masks"):
+        est.net.load_nflows_state_dict(bad)
 
 
 def test_config_and_factory_surface():
@@ -124,3 +129,45 @@ def test_config_and_factory_surface():
         build_maf_rqs(theta, x, z_score_x="transform_to_unconstrained")
     with pytest.raises(RuntimeError, match="ROCm device"):     # no CPU fallback
         est.log_prob(theta[:3].unsqueeze(0), x[:3])
+
+
+def test_both_readings_of_the_made_sqrt_hidden_question_are_evaluated():
+    """The one recalled nflows detail this path cannot check offline: nflows'
+    MaskedPiecewiseRationalQuadraticAutoregressiveTransform divides the width / height logits by sqrt(hidden_features)
+    `if hasattr(self.autoregressive_net, "hidden_features")`; the oracle assumes MADE defines no such attribute
+    (`scale_by_sqrt_hidden=False`).  Both readings exist in the oracle AND in the kernels' config; this pins what
+    each reading MEANS by a known answer, so that the day a real nflows is importable
+    (`tools/compare_with_nflows.py`, which evaluates both) the answer is a one-word change of a default:
+    reading True == reading False with the width / height rows of every final layer divided by sqrt(H)."""
+    import math
+
+    theta, x = _data()
+    H, K, D = 12, 5, 4
+    kw = dict(hidden_features=H, num_transforms=2, num_bins=K)
+    torch.manual_seed(3)
+    plain = MAFRQSOracle(theta, x, scale_by_sqrt_hidden=False, **kw).double()
+    with torch.no_grad():
+        for p in plain.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    scaled = MAFRQSOracle(theta, x, scale_by_sqrt_hidden=True, **kw).double()
+    scaled.load_state_dict(plain.state_dict())
+    th, xx = theta[:50].double(), x[:50].double()
+    lp_plain, lp_scaled = plain.log_prob(th, xx)[0], scaled.log_prob(th, xx)[0]
+    assert (lp_plain - lp_scaled).abs().max() > 1e-2          # the switch is live
+    # known answer: fold 1 / sqrt(H) into the final layers' width / height rows of the unscaled flow
+    folded = MAFRQSOracle(theta, x, scale_by_sqrt_hidden=False, **kw).double()
+    folded.load_state_dict(plain.state_dict())
+    P = 3 * K - 1
+    rows = torch.tensor([d * P + k for d in range(D) for k in range(2 * K)])
+    with torch.no_grad():
+        for name, p in folded.named_parameters():
+            if "final_layer" in name:
+                p[rows] /= math.sqrt(H)
+    assert torch.allclose(folded.log_prob(th, xx)[0], lp_scaled, atol=1e-10)
+    # the scaled reading is a proper flow too
+    noise = scaled.inverse_transform(th, xx)
+    back, _ = scaled.sample_from_noise(noise, xx)
+    assert (back - th).abs().max() < 1e-6
+    # and the product's config carries the same switch to the kernels (field 11 of sbi_amd_maf_config)
+    assert MAFHyper(D=4, C=3, scale_by_sqrt_hidden=True).c_config().scale_by_sqrt_hidden == 1
+    assert MAFHyper(D=4, C=3).c_config().scale_by_sqrt_hidden == 0

@@ -96,6 +96,9 @@ def test_sample_from_noise_65536_matches_oracle():
     assert frac > 0.999
 
 
+KNOT_ULPS = 8.0             # fp32 spacings at the tail bound within which a row counts as knot-straddling
+WORST_BLOCK_VS_O32 = 4.0    # per-block error budget in units of the eager fp32 oracle's own worst block
+
 GRAD_CONFIGS = {
     "D10-C10": dict(D=10, C=10),                                     # BASELINE configs[1]: wave-specialised backward
     "generic-D20-C12-T3": dict(D=20, C=12, num_transforms=3),        # generic pass (nsf_gtrain_kernel.h + dW GEMMs)
@@ -171,22 +174,53 @@ def test_training_gradient_65536_matches_autograd(name):
     print(f"grad 65536, all rows: hip vs f64 {e_all:.3e}, o32 vs f64 {e_o64:.3e}; rows off in d loss/d theta: "
           f"{outliers.tolist()} (err {row_err[outliers].tolist()}), every other row within {typical:.3e}")
     assert outliers.numel() <= 8, "more knot-straddling rows than one-ulp knot differences can explain"
+    # VERIFY that every row set aside really straddles a knot: in float64 through the oracle, at least one of its
+    # T x d_tr spline inputs must lie within KNOT_ULPS float32 spacings (at the tail bound: 2.4e-7) of an interior
+    # knot -- the distance within which two correct fp32 evaluations of softmax + cumsum can disagree about the bin.
+    # A row that is merely WRONG (far from every knot) fails here instead of being excused.
+    from tests.helpers import spline_knot_distances
+
+    near = torch.zeros(0)
+    if outliers.numel():
+        near = spline_knot_distances(oracle, theta[outliers], x[outliers]).min(dim=1).values
+        print(f"excluded rows: distance of the closest spline input to a knot, in fp32 spacings at B: {near.tolist()}")
+        assert (near <= KNOT_ULPS).all(), \
+            f"row(s) {outliers[near > KNOT_ULPS].tolist()} disagree with fp64 but sit {near.tolist()} spacings from a knot"
+    ctrl = spline_knot_distances(oracle, theta[:4096], x[:4096]).min(dim=1).values     # what ordinary rows look like
     keep = torch.ones(N)
     keep[outliers] = 0.0
     _, g64k, _ = oracle_pass(True, keep)
+    _, g32k, _ = oracle_pass(False, keep)
     _, g_hk, _ = hip_pass(keep)
     e_keep = (g_hk.double() - g64k).abs().max().item() / scale
-    worst_block = 0.0
+    # per parameter block, relative to the block's own largest entry (floored at 1e-3 of the global maximum): the
+    # eager fp32 oracle is held to the same yardstick, so a block whose entries are small next to their own
+    # rounding noise (near-zero-gradient biases) shows up as such instead of as a kernel error
+    worst_block, worst_name, worst_o32, worst_o32_name, worst_mag = 0.0, "", 0.0, "", 0.0
     for key, off, cnt, _ in est.net._slices():
-        a, b = g_hk[off : off + cnt].double(), g64k[off : off + cnt]
-        worst_block = max(worst_block, (a - b).abs().max().item() / max(b.abs().max().item(), 1e-3 * scale))
+        b = g64k[off : off + cnt]
+        den = max(b.abs().max().item(), 1e-3 * scale)
+        eh = (g_hk[off : off + cnt].double() - b).abs().max().item() / den
+        eo = (g32k[off : off + cnt].double() - b).abs().max().item() / den
+        if eh > worst_block:
+            worst_block, worst_name, worst_mag = eh, key, b.abs().max().item() / scale
+        if eo > worst_o32:
+            worst_o32, worst_o32_name = eo, key
     record("train_grad_65536", name, rows=N, max_abs_grad_ref=scale, max_abs_loss_err_vs_oracle32=e_l,
            rel_grad_err_hip_vs_f64_all_rows=e_all, rel_grad_err_oracle32_vs_f64_all_rows=e_o64,
            knot_straddling_rows=int(outliers.numel()), rel_grad_err_hip_vs_f64_without_those_rows=e_keep,
-           worst_block_rel_err_without_those_rows=worst_block, max_rel_row_grad_theta_err_other_rows=typical)
-    print(f"without those rows: hip vs f64 {e_keep:.3e}, worst block {worst_block:.3e}")
+           worst_block_rel_err_without_those_rows=worst_block, worst_block=worst_name,
+           worst_block_max_over_global_max=worst_mag, worst_block_rel_err_oracle32=worst_o32,
+           worst_block_oracle32=worst_o32_name, max_rel_row_grad_theta_err_other_rows=typical,
+           excluded_rows_min_knot_distance_fp32_spacings=[float(v) for v in near.tolist()],
+           control_rows_min_knot_distance_fp32_spacings_median=ctrl.median().item(),
+           control_rows_min_knot_distance_fp32_spacings_min=ctrl.min().item(), knot_ulps_bound=KNOT_ULPS)
+    print(f"without those rows: hip vs f64 {e_keep:.3e}, worst block {worst_name} {worst_block:.3e} (block max = "
+          f"{worst_mag:.2e} of the global max); fp32 oracle's worst block {worst_o32_name} {worst_o32:.3e}")
     assert e_keep <= 5e-5, f"flat gradient off by {e_keep} of max|grad| on rows away from knots"
-    assert worst_block <= 5e-4
+    # the kernels may be at most WORST_BLOCK_VS_O32 x as far from fp64 on their worst block as eager fp32 PyTorch is
+    # on its own worst block (+ an absolute 5e-5)
+    assert worst_block <= 5e-5 + WORST_BLOCK_VS_O32 * worst_o32
 
 
 def test_fmpe_loss_and_gradient_65536_match_pinned_oracle():

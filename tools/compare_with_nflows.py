@@ -12,7 +12,8 @@ its published algorithm ("PARITY UNPINNED at the nflows bou
 It builds sbi's own `build_nsf` estimator, copies its `state_dict` into the oracle / `NSFFlow`
 (`load_nflows_state_dict`: same key names), perturbs the weights so that no identity-at-init
 structure hides a discrepancy, and asserts |d log_prob| <= 1e-5 (norm-wise) and |d sample| <= 1e-5 on fixed seeds
-for several shapes, incl. theta-dim 1 (ContextSplineMap).  Exit code 0 = pinned.
+for several shapes, incl. theta-dim 1 (ContextSplineMap); then does the same for `maf_rqs` (both readings of the
+MADE sqrt(hidden) question, see compare_maf_rqs) and `zuko_nsf`.  Exit code 0 = all three pinned.
 """
 
 import argparse
@@ -78,8 +79,131 @@ def main() -> int:
         print(line)
         worst = max(worst, d_lp, d_s)
     ok = worst <= 1e-5
-    print("PINNED" if ok else f"MISMATCH (worst {worst:.2e})")
-    return 0 if ok else 1
+    print("nsf: PINNED" if ok else f"nsf: MISMATCH (worst {worst:.2e})")
+    ok_maf = compare_maf_rqs(args.device)
+    ok_zuko = compare_zuko_nsf(args.device)
+    return 0 if (ok and ok_maf and ok_zuko) else 1
+
+
+def _data(D, C, n=2000):
+    g = torch.Generator().manual_seed(0)
+    theta = torch.randn(n, D, generator=g) * 0.5
+    x = theta[:, :1].expand(-1, C) * 0.3 + torch.randn(n, C, generator=g)
+    return theta, x, g
+
+
+def compare_maf_rqs(device: str) -> bool:
+    """`maf_rqs` against the real nflows MADE / MaskedPiecewiseRationalQuadraticAutoregressiveTransform.
+    Settles the one recalled detail the oracle keeps switchable: whether the autoregressive transform divides the
+    width / height logits by sqrt(hidden_features) (it does `if hasattr(autoregressive_net, "hidden_features")`;
+    oracle/maf_oracle.py assumes MADE defines no such attribute).  BOTH readings are evaluated and reported."""
+    try:
+        from sbi.neural_nets.net_builders.flow import build_maf_rqs as ref_build
+    except Exception as e:   # noqa: BLE001
+        print(f"maf_rqs: real sbi/nflows not importable ({type(e).__name__}: {e}); nothing compared")
+        return False
+    from oracle.maf_oracle import MAFRQSOracle
+
+    worst = {False: 0.0, True: 0.0}
+    worst_hip = 0.0
+    for cfg in [dict(D=10, C=10), dict(D=3, C=2, num_bins=8), dict(D=6, C=4, hidden_features=32, num_transforms=3),
+                dict(D=1, C=3)]:
+        D, C = cfg.pop("D"), cfg.pop("C")
+        theta, x, g = _data(D, C)
+        torch.manual_seed(1)
+        ref = ref_build(theta, x, **cfg)
+        with torch.no_grad():
+            for p in ref.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        sd = ref.state_dict()
+        has_attr = hasattr(ref.net._transform._transforms[1].autoregressive_net, "hidden_features") \
+            if hasattr(ref, "net") else None
+        th, xx = theta[:512], x[:512]
+        with torch.no_grad():
+            lp_ref = ref.log_prob(th.unsqueeze(0), xx)[0]
+        line = f"maf_rqs D={D} C={C} {cfg}: MADE has hidden_features attr: {has_attr};"
+        for reading in (False, True):
+            o = MAFRQSOracle(theta, x, scale_by_sqrt_hidden=reading, **cfg)
+            o.load_state_dict(sd, strict=True)               # same keys, incl. mask / degrees / _permutation buffers
+            with torch.no_grad():
+                d = (lp_ref - o.log_prob(th, xx)[0]).abs().max().item() / (1 + lp_ref.abs().max().item())
+            worst[reading] = max(worst[reading], d)
+            line += f"  oracle(scale_by_sqrt_hidden={reading}) d_logp(norm)={d:.2e}"
+        if device != "cpu" and D <= 16:
+            from sbi_amd.neural_nets.net_builders.flow import build_maf_rqs
+
+            est = build_maf_rqs(theta, x, **cfg)
+            est.net.load_nflows_state_dict(sd)
+            est = est.to(device)
+            with torch.no_grad():
+                lp_hip = est.log_prob(th.to(device).unsqueeze(0), xx.to(device))[0].cpu()
+            d_hip = (lp_ref - lp_hip).abs().max().item() / (1 + lp_ref.abs().max().item())
+            worst_hip = max(worst_hip, d_hip)
+            line += f" | HIP (default reading) d_logp(norm)={d_hip:.2e}"
+        print(line)
+    if worst[False] <= 1e-5 and worst_hip <= 1e-5:
+        print("maf_rqs: PINNED (default reading scale_by_sqrt_hidden=False is nflows' behaviour)")
+        return True
+    if worst[True] <= 1e-5:
+        print("maf_rqs: nflows DOES scale by sqrt(hidden): flip the default of MAFHyper.scale_by_sqrt_hidden and of "
+              "oracle.maf_oracle.MAFRQSOracle(scale_by_sqrt_hidden=...) to True -- the kernels already implement it")
+        return False
+    print(f"maf_rqs: MISMATCH under both readings ({worst})")
+    return False
+
+
+def compare_zuko_nsf(device: str) -> bool:
+    """`zuko_nsf` against a real zuko install: weights are exchanged by ORDER and SHAPE (the hyper-network's
+    MaskedLinear weight / bias tensors of every transform, in module order), the adjacency masks by value."""
+    try:
+        from sbi.neural_nets.net_builders.flow import build_zuko_nsf as ref_build
+    except Exception as e:   # noqa: BLE001
+        print(f"zuko_nsf: real sbi/zuko not importable ({type(e).__name__}: {e}); nothing compared")
+        return False
+    from oracle.zuko_oracle import ZukoNSFOracle
+
+    worst = 0.0
+    for cfg in [dict(D=10, C=10), dict(D=3, C=2, num_bins=8), dict(D=6, C=4, hidden_features=32, num_transforms=3)]:
+        D, C = cfg.pop("D"), cfg.pop("C")
+        theta, x, g = _data(D, C)
+        torch.manual_seed(1)
+        ref = ref_build(theta, x, **cfg)
+        with torch.no_grad():
+            for p in ref.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        o = ZukoNSFOracle(theta, x, **cfg)
+        ref_w = [(k, v) for k, v in ref.state_dict().items() if ".hyper." in k and k.endswith((".weight", ".bias"))]
+        ref_m = [(k, v) for k, v in ref.state_dict().items() if ".hyper." in k and k.endswith(".mask")]
+        mine = [(k, p) for k, p in o.named_parameters()]
+        assert len(ref_w) == len(mine), (len(ref_w), len(mine))
+        with torch.no_grad():
+            for (kr, vr), (km, pm) in zip(ref_w, mine):
+                assert tuple(vr.shape) == tuple(pm.shape), (kr, km, vr.shape, pm.shape)
+                pm.copy_(vr)
+        mine_m = [b for k, b in o.named_buffers() if k.endswith(".mask")]
+        masks_ok = len(ref_m) == len(mine_m) and all(torch.equal(a[1].bool(), b.bool()) for a, b in zip(ref_m, mine_m))
+        th, xx = theta[:512], x[:512]
+        with torch.no_grad():
+            lp_ref = ref.log_prob(th.unsqueeze(0), xx)[0]
+            lp_or = o.log_prob(th.unsqueeze(0), xx)[0]
+        d = (lp_ref - lp_or).abs().max().item() / (1 + lp_ref.abs().max().item())
+        line = f"zuko_nsf D={D} C={C} {cfg}: masks equal: {masks_ok}; oracle d_logp(norm)={d:.2e}"
+        if device != "cpu" and D <= 16:
+            from sbi_amd.neural_nets.net_builders.flow import build_zuko_nsf
+
+            est = build_zuko_nsf(theta, x, **cfg)
+            est.net.load_zuko_state_dict(o.state_dict())
+            est = est.to(device)
+            with torch.no_grad():
+                lp_hip = est.log_prob(th.to(device).unsqueeze(0), xx.to(device))[0].cpu()
+            d_hip = (lp_ref - lp_hip).abs().max().item() / (1 + lp_ref.abs().max().item())
+            line += f" | HIP d_logp(norm)={d_hip:.2e}"
+            d = max(d, d_hip)
+        print(line)
+        worst = max(worst, d if masks_ok else 1.0)
+    ok = worst <= 1e-5
+    print("zuko_nsf: PINNED" if ok else f"zuko_nsf: MISMATCH (worst {worst:.2e})")
+    return ok
 
 
 if __name__ == "__main__":
