@@ -79,6 +79,22 @@ int64_t sbi_amd_nsf_lu_offset(const sbi_amd_nsf_config* cfg, int32_t t);
 int64_t sbi_amd_nsf_packed_floats(const sbi_amd_nsf_config* cfg);
 int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream);
 
+/* `packed` holds two images: the throughput kernels' (one LDS image per transform) and, for the shapes they take
+ * (theta-dim 2..16, x-dim <= 32), the fragment-ordered image of the latency-oriented kernels that calls of at most
+ * 12 288 rows are routed to (four cooperating wavefronts per 16-row tile, all transforms of the backward pass in one
+ * launch: csrc/nsf_coop.h; sbi's default training_batch_size = 200, npe_base.py:301-316, lives here).
+ * sbi_amd_nsf_image_kind says which image an n-row call reads (0 throughput, 1 cooperative; `training` != 0 for
+ * train_forward / train_backward / loss_fwd_bwd); sbi_amd_nsf_pack_images re-packs only the images named in the
+ * bit mask (1 throughput, 2 cooperative) -- a training loop at a fixed batch size needs one of them per step.
+ * sbi_amd_nsf_pack packs both. */
+int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, int32_t training);
+/* Tuning / test hook: calls of at most `rows` rows take the cooperative kernels (0: never; default 12 288 or the
+ * environment variable SBI_AMD_COOP_MAX_ROWS); returns the previous value.  Process-wide; images packed before a
+ * change stay valid (both images live in `packed`), but a training workspace belongs to the path that sized it. */
+int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows);
+int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const float* params, float* packed, int32_t images,
+                            void* stream);
+
 /* log p(theta | x) for n rows: replaces nflows Flow.log_prob behind
  * NFlowsFlow.log_prob (nflows_flow.py:77-97).  noise_out (n,D) is optional
  * (NULL) and receives transform(theta) = NFlowsFlow.inverse_transform
@@ -160,7 +176,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
                                 const float* u, float* theta_out, float* logabsdet_out, void* stream);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 105
+#define SBI_AMD_NSF_ABI_VERSION 106
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 105    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 106    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -64,6 +64,9 @@ _SIGNATURES = {
     "sbi_amd_nsf_lu_offset": (c_int64, [POINTER(NSFConfigC), c_int32]),
     "sbi_amd_nsf_packed_floats": (c_int64, [POINTER(NSFConfigC)]),
     "sbi_amd_nsf_pack": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p]),
+    "sbi_amd_nsf_image_kind": (c_int, [POINTER(NSFConfigC), c_int64, c_int32]),
+    "sbi_amd_nsf_set_coop_max_rows": (c_int64, [c_int64]),
+    "sbi_amd_nsf_pack_images": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_int32, c_void_p]),
     "sbi_amd_nsf_log_prob": (
         c_int,
         [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,

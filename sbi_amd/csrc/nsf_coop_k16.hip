@@ -1,0 +1,8 @@
+// nsf_coop_k16.hip -- num_bins = 16 instantiations of the cooperative (small-batch) kernels.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "nsf_train_kernel.h"
+#include "nsf_coop_kernel.h"
+
+template int co_fwd_k<16>(const NsfPlan&, const CoopPlan&, const CoFwdArgs&, hipStream_t);
+template int co_bwd_k<16>(const NsfPlan&, const CoopPlan&, const CoBwdArgs&, hipStream_t);

@@ -1,0 +1,128 @@
+// nsf_coop_plan.cpp -- host-side plan of the cooperative (small-batch) NSF kernels, see nsf_coop.h.
+#include "nsf_coop.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
+
+static int64_t g_coop_max_rows = -1;
+int64_t coop_max_rows() {
+  if (g_coop_max_rows < 0) {
+    const char* a = getenv("SBI_AMD_COOP_MAX_ROWS");
+    g_coop_max_rows = a ? atoll(a) : 12288;   // measured cross-over against the throughput kernels: DESIGN.md section 4
+  }
+  return g_coop_max_rows;
+}
+// tuning / test hook: route calls of <= `rows` rows to the cooperative kernels (0: never); returns the previous value
+extern "C" int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows) {
+  const int64_t prev = coop_max_rows();
+  g_coop_max_rows = rows < 0 ? 0 : rows;
+  return prev;
+}
+
+static void add_mat(CoMat* m, int* off, int mtiles, int quads, int kind, int lin) {
+  m->off = *off;
+  m->mtiles = mtiles;
+  m->quads = quads;
+  m->kind = kind;
+  m->lin = lin;
+  *off += mtiles * quads * 256;
+}
+static void add_bias(CoBias* b, int* off, int mtiles, int kind, int lin) {
+  b->off = *off;
+  b->mtiles = mtiles;
+  b->kind = kind;
+  b->lin = lin;
+  *off += 16 * mtiles;
+}
+
+int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, CoopPlan* cp) {
+  memset(cp, 0, sizeof(*cp));
+  // shapes: residual-net conditioner (theta-dim >= 2), LULinear as one 16 x 16 MFMA tile, context K-steps in registers
+  if (pl.ctx_mlp || pl.D < 2 || pl.D > 16 || pl.C > 32 || pl.H > 64 || pl.NB < 1 || pl.NB > NSF_MAX_NB)
+    return SBI_AMD_E_UNSUPPORTED;
+  const int HQ = (pl.KSH + 3) / 4;     // K-quads of a hidden-K layer (13 or 16 K-steps)
+  int img = 0;
+  for (int par = 0; par < 2; ++par) {
+    const ShapeDesc& S = pl.shape[par];
+    CoShape& c = cp->sh[par];
+    c.KC = (pl.C + 3) / 4;
+    c.KZ = (S.d_id + 3) / 4;
+    c.nft = S.d_tr * pl.PT;
+    int o = 0;
+    add_mat(&c.W0, &o, NSF_HT, (c.KC + c.KZ + 3) / 4, CO_K_W0, 0);
+    for (int b = 0; b < pl.NB; ++b) {
+      add_mat(&c.WC[b], &o, NSF_HT, (c.KC + 3) / 4, CO_K_PLAIN, 1 + 3 * b);
+      add_mat(&c.W1[b], &o, NSF_HT, HQ, CO_K_PLAIN, 2 + 3 * b);
+      add_mat(&c.W2[b], &o, NSF_HT, HQ, CO_K_PLAIN, 3 + 3 * b);
+    }
+    add_mat(&c.WF, &o, c.nft, HQ, CO_K_WF, S.fin);
+    add_mat(&c.U, &o, 1, 1, CO_K_U, -1);
+    add_mat(&c.L, &o, 1, 1, CO_K_L, -1);
+    add_mat(&c.WFT, &o, NSF_HT, S.d_tr * pl.PT, CO_K_WFT, S.fin);
+    for (int b = 0; b < pl.NB; ++b) {
+      add_mat(&c.W1T[b], &o, NSF_HT, HQ, CO_K_PLAIN_T, 2 + 3 * b);
+      add_mat(&c.W2T[b], &o, NSF_HT, HQ, CO_K_PLAIN_T, 3 + 3 * b);
+    }
+    add_mat(&c.W0T, &o, 1, HQ, CO_K_W0T, 0);
+    add_mat(&c.UT, &o, 1, 1, CO_K_UT, -1);
+    add_mat(&c.LT, &o, 1, 1, CO_K_LT, -1);
+    for (int b = 0; b < pl.NB; ++b) add_mat(&c.WCT[b], &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 1 + 3 * b);
+    add_mat(&c.W0CT, &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 0);
+    add_bias(&c.b0, &o, NSF_HT, 0, 0);
+    for (int b = 0; b < pl.NB; ++b) {
+      add_bias(&c.bc[b], &o, NSF_HT, 0, 1 + 3 * b);
+      add_bias(&c.b1[b], &o, NSF_HT, 0, 2 + 3 * b);
+      add_bias(&c.b2[b], &o, NSF_HT, 0, 3 + 3 * b);
+    }
+    add_bias(&c.bf, &o, c.nft, 1, S.fin);
+    add_bias(&c.blu, &o, 1, 2, -1);
+    c.o_ld = o;
+    o += 4;
+    o = round_up_i(o, 256);
+    if (o > img) img = o;
+  }
+  cp->img_floats = img;
+
+  // rows per workgroup: one 16-row tile while that still gives every CU at most two workgroups' worth of partial
+  // slabs; two tiles per workgroup beyond (the A operands are then shared by both, the slabs halve)
+  int NT = nt_force > 0 ? nt_force : (n > 4096 ? 2 : 1);
+  if (NT > CO_MAX_NT) NT = CO_MAX_NT;
+  cp->NT = NT;
+  cp->R = 16 * NT;
+  cp->RS = cp->R + 4;
+  cp->ZS = 17;
+  cp->PSW = 16 * pl.PT + 1;
+  const int d_tr_max = pl.shape[0].d_tr;
+  cp->DSTR = d_tr_max * cp->PSW;
+  if ((cp->DSTR & 1) == 0) cp->DSTR += 1;
+  cp->s_blk = NSF_HT;
+  cp->s_par = NSF_HT + 4 * NSF_HT * pl.NB;
+  cp->slots = cp->s_par + d_tr_max * pl.PT;
+  // conditioner-input tile [z_id ; context ; 1 ; 0 ...]^T: rows cover d W0's n-tiles and, from row d_id, d Wc's
+  const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
+  const int nt0 = (d_id_max + pl.C + 1 + 15) / 16, ntc = (pl.C + 1 + 15) / 16;
+  cp->ct_rows = 16 * nt0 > d_id_max + 16 * ntc ? 16 * nt0 : d_id_max + 16 * ntc;
+  int o = 0;
+  cp->o_zs = o;  o += round_up_i(cp->R * cp->ZS + 16, 4);
+  cp->o_gys = o; o += round_up_i(cp->R * cp->ZS + 16, 4);
+  cp->o_gzs = o; o += round_up_i(cp->R * cp->ZS + 16, 4);
+  cp->o_w = o;   o += cp->R;
+  cp->o_pst = o; o += round_up_i(cp->R * cp->DSTR, 4);
+  cp->o_ex = o;  o += 2 * CO_WAVES * NT * 256;
+  cp->o_ldp = o; o += 8 * cp->R;
+  if (training) {
+    cp->o_gt = o;  o += 2 * 64 * cp->RS;
+    cp->o_at = o;  o += 2 * 65 * cp->RS;
+    cp->o_ct = o;  o += cp->ct_rows * cp->RS;
+    cp->o_lut = o; o += 4 * 17 * cp->RS;
+    cp->o_ctx = o; o += 32 * cp->R;
+  }
+  cp->lds_floats = round_up_i(o, 4);
+  if (4ll * cp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
+  cp->grid = (int)((n + cp->R - 1) / cp->R);
+  int pmax = pl.shape[0].n_params > pl.shape[1].n_params ? pl.shape[0].n_params : pl.shape[1].n_params;
+  cp->PLP = (pmax + 1 + 3) / 4 * 4;
+  return 0;
+}

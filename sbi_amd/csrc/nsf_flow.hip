@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "nsf_flow_kernel.h"
+#include "nsf_coop_host.h"
 
 // one workgroup per transform: flat parameters -> packed MFMA weight image
 __global__ void __launch_bounds__(512)
@@ -54,25 +55,54 @@ int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const
   return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, astash, stream);
 }
 
+// The packed buffer holds TWO images: [throughput image: T LDS images | cooperative image: fragment-ordered, forward
+// and transposed matrices (nsf_coop.h); absent for shapes the cooperative kernels do not take].
 extern "C" int64_t sbi_amd_nsf_packed_floats(const sbi_amd_nsf_config* cfg) {
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, 1, &pl);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
-  return nsf_packed_floats(pl);
+  return nsf_packed_floats(pl) + coop_packed_floats(cfg);
 }
 
-extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream) {
+// which image does an n-row call read?  0: the throughput image, 1: the cooperative image
+extern "C" int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, int32_t training) {
+  if (!cfg) return SBI_AMD_E_BADARG;
+  NsfPlan pl;
+  CoopPlan cp;
+  return coop_applies(cfg, n, training != 0, &pl, &cp) ? 1 : 0;
+}
+
+// images: bit 0 the throughput image, bit 1 the cooperative image (a training loop at a fixed batch size only ever
+// needs one of them re-packed per step)
+extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const float* params, float* packed,
+                                       int32_t images, void* stream) {
   if (!cfg || !params || !packed) return SBI_AMD_E_BADARG;
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, 1, &pl);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
-  hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
+  if (images & 1)
+    hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
+  if (images & 2) {
+    rc = coop_pack(cfg, params, packed + nsf_packed_floats(pl), stream);
+    if (rc) return rc;
+  }
   return (int)hipGetLastError();
+}
+
+extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream) {
+  return sbi_amd_nsf_pack_images(cfg, params, packed, 3, stream);
 }
 
 extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                     const float* theta, const float* x, int64_t n, int64_t x_rows,
                                     float* logp_out, float* noise_out, void* stream) {
+  if (n == 0) return 0;
+  if (!cfg || !packed || !zstats || !theta || !x || !logp_out || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
+  NsfPlan pl;
+  CoopPlan cp;
+  if (coop_applies(cfg, n, false, &pl, &cp))   // small batches: four cooperating waves per 16-row tile (nsf_coop.h)
+    return coop_log_prob(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, theta, x, n, x_rows, logp_out,
+                         noise_out, stream);
   return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, nullptr, stream);
 }
 

@@ -2,8 +2,10 @@
 // backward kernel (other bin counts: nsf_train_k5.hip / nsf_train_k8.hip, separate TUs for a parallel build).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "nsf_train_kernel.h"
 #include "debug_env.h"
+#include "nsf_coop_host.h"
 
 // grad[p] = sum over workgroups of the partial slabs (fixed association => deterministic);
 // finishes LULinear's diagonal: d/d(unconstrained_upper_diag_i) =
@@ -102,6 +104,11 @@ static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int6
 }
 
 extern "C" int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* cfg, int64_t n) {
+  {
+    NsfPlan cpl;
+    CoopPlan cp;
+    if (coop_applies(cfg, n > 0 ? n : 1, true, &cpl, &cp)) return coop_workspace_floats(cpl, cp, n > 0 ? n : 1);
+  }
   NsfPlan pl;
   // (an E_LDS here speaks about the FORWARD kernel's 4-wave layout; the backward kernel has its own budget, checked
   // by build_train_plan, and the training forward picks its workgroup size in nsf_plan_for_rows)
@@ -140,6 +147,12 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
                                          float* logp_out, float* workspace, void* stream) {
   if (!cfg || !packed || !zstats || !theta || !x || !workspace || n < 1 || x_rows < 1) return SBI_AMD_E_BADARG;
   NsfPlan pl;
+  {
+    CoopPlan cp;
+    if (coop_applies(cfg, n, true, &pl, &cp))
+      return coop_train_forward(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, theta, x, n, x_rows, logp_out,
+                                workspace, stream);
+  }
   // (an E_LDS here speaks about the FORWARD kernel's 4-wave layout; the backward kernel has its own budget, checked
   // by build_train_plan, and the training forward picks its workgroup size in nsf_plan_for_rows)
   int rc = nsf_build_plan(cfg, TR_NW, &pl);
@@ -174,6 +187,24 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
     return SBI_AMD_E_BADARG;
   if (grad_x_out && x_rows != n) return SBI_AMD_E_BADARG;   // one context row per theta row (no reduction here)
   NsfPlan pl;
+  {
+    // small batches: ONE cooperative backward launch over all transforms, then the same fixed-order slab reduction.
+    // (The workspace was laid out by the cooperative forward: both halves take the same decision from (cfg, n).)
+    CoopPlan cp;
+    if (coop_applies(cfg, n, true, &pl, &cp)) {
+      const float *partial = nullptr, *logp = nullptr;
+      int rc = coop_train_backward(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, x, n, x_rows, row_weight,
+                                   uniform_weight, grad_theta_out, grad_x_out, workspace, &partial, &logp, stream);
+      if (rc) return rc;
+      TrainPlan tpc;
+      memset(&tpc, 0, sizeof(tpc));
+      tpc.grid = cp.grid;
+      tpc.PLP = cp.PLP;
+      hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64 * RED_GROUPS), 0,
+                         (hipStream_t)stream, pl, tpc, params, partial, grad_out, logp, loss_out, (long long)n);
+      return (int)hipGetLastError();
+    }
+  }
   // (an E_LDS here speaks about the FORWARD kernel's 4-wave layout; the backward kernel has its own budget, checked
   // by build_train_plan, and the training forward picks its workgroup size in nsf_plan_for_rows)
   int rc = nsf_build_plan(cfg, TR_NW, &pl);

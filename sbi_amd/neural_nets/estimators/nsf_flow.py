@@ -225,26 +225,33 @@ class NSFNet(nn.Module):
 
 
 # --------------------------------------------------------------------- kernel calls
-def packed_weights(net: NSFNet) -> Tensor:
-    """Kernel-side weight image of ``net.flat_params`` (re-packed lazily when the
-    parameter tensor was modified or moved; tracked through its version counter)."""
+def packed_weights(net: NSFNet, rows: Optional[int] = None, training: bool = False) -> Tensor:
+    """Kernel-side weight images of ``net.flat_params`` (re-packed lazily when the parameter tensor was modified or
+    moved; tracked through its version counter).  The buffer holds two images (include/sbi_amd_nsf.h): the throughput
+    kernels' and the cooperative small-batch kernels'; a call that knows its row count (`rows`) only re-packs the one
+    its kernels read -- a training loop at a fixed batch size pays for one image per step, not two."""
     fp = net.flat_params
     key = (fp.data_ptr(), fp._version, str(fp.device))
     cache = net.__dict__.get("_packed_cache")
-    if cache is not None and cache[0] == key:
-        return cache[1]
-    dev = _lib.require_device(fp)
     lib = _lib.load()
     cfg = net.hyper.c_config()
+    want = 3 if rows is None else (2 if lib.sbi_amd_nsf_image_kind(cfg, int(rows), int(training)) == 1 else 1)
+    have = 0
+    if cache is not None and cache[0] == key:
+        have = net.__dict__.get("_packed_images", 0)
+        if have & want == want:
+            return cache[1]
+    dev = _lib.require_device(fp)
     n = lib.sbi_amd_nsf_packed_floats(cfg)
     if n < 0:
         _lib.check(int(n), "nsf_packed_floats")
     packed = cache[1] if (cache is not None and cache[1].device == dev and cache[1].numel() == n) else \
         torch.zeros(int(n), dtype=torch.float32, device=dev)   # alignment gaps of the image are never written
     with torch.cuda.device(dev):
-        rc = lib.sbi_amd_nsf_pack(cfg, _lib.ptr(fp), _lib.ptr(packed), _lib.current_stream(dev))
+        rc = lib.sbi_amd_nsf_pack_images(cfg, _lib.ptr(fp), _lib.ptr(packed), want & ~have, _lib.current_stream(dev))
     _lib.check(rc, "nsf_pack")
     net.__dict__["_packed_cache"] = (key, packed)
+    net.__dict__["_packed_images"] = have | want
     return packed
 
 
@@ -257,7 +264,7 @@ def _log_prob_call(net: NSFNet, theta: Tensor, x: Tensor, want_noise: bool) -> T
     noise = torch.empty_like(theta) if want_noise else None
     if n == 0:
         return logp, noise
-    packed = packed_weights(net)
+    packed = packed_weights(net, rows=n)
     cfg = net.hyper.c_config()
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_log_prob(
@@ -277,7 +284,7 @@ def _sample_call(net: NSFNet, noise: Tensor, x: Tensor, want_ld: bool) -> Tuple[
     if n == 0:
         return theta, ld
     cfg = net.hyper.c_config()
-    packed = packed_weights(net)
+    packed = packed_weights(net, rows=0)    # the sampling direction always runs on the throughput kernels
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_sample(
             cfg, _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(noise), _lib.ptr(x), n, x.shape[0],
@@ -303,7 +310,7 @@ def loss_fwd_bwd(net: NSFNet, theta: Tensor, x: Tensor, row_weight: Optional[Ten
         workspace = torch.empty(max(int(need), 1), dtype=torch.float32, device=dev)
     loss = torch.empty(n, dtype=torch.float32, device=dev)
     gtheta = torch.empty_like(theta) if want_grad_theta else None
-    packed = packed_weights(net)
+    packed = packed_weights(net, rows=n, training=True)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_loss_fwd_bwd(
             cfg, _lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
@@ -332,7 +339,7 @@ def train_forward(net: NSFNet, theta: Tensor, x: Tensor, workspace: Tensor) -> T
     lib = _lib.load()
     n = theta.shape[0]
     logp = torch.empty(n, dtype=torch.float32, device=dev)
-    packed = packed_weights(net)
+    packed = packed_weights(net, rows=n, training=True)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_train_forward(
             net.hyper.c_config(), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(theta), _lib.ptr(x), n, x.shape[0],
@@ -348,7 +355,7 @@ def train_backward(net: NSFNet, x: Tensor, n: int, row_weight: Tensor, grad_out:
     dev = _lib.require_device(x, net.flat_params, net.zstats, grad_out, row_weight, workspace)
     lib = _lib.load()
     gtheta = torch.empty(n, net.hyper.D, dtype=torch.float32, device=dev) if want_grad_theta else None
-    packed = packed_weights(net)
+    packed = packed_weights(net, rows=n, training=True)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_train_backward(
             net.hyper.c_config(), _lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(x), n,

@@ -44,11 +44,12 @@ def make_inputs(n, D, C, seed=3, spread=1.0):
     return theta, x
 
 
-def spline_knot_distances(oracle, theta, x):
+def spline_knot_distances(oracle, theta, x, include_bounds=True):
     """For every row: the distance of each forward spline evaluation's input to its nearest INTERIOR knot, computed
     in float64 through the oracle, in units of the float32 spacing at the tail bound (np.spacing(float32(B)): the
     resolution at which an fp32 implementation can place a knot of a spline on [-B, B]).  Returns
-    (rows, num_transforms * d_tr) -- 25 evaluations per row at theta-dim 10 -- with +inf for inputs in the tails.
+    (rows, num_transforms * d_tr) -- 25 evaluations per row at theta-dim 10.  The tail bounds +-B count as knots
+    (`include_bounds`; otherwise inputs in the tails get +inf).
 
     Used by the full-size gradient test to VERIFY that the rows it sets aside are knot-straddling rows (the RQ spline
     is C1: at a knot log p is continuous but its parameter / input gradient is two-valued)."""
@@ -66,7 +67,10 @@ def spline_knot_distances(oracle, theta, x):
         w = min_bin_width + (1 - min_bin_width * K) * F.softmax(unnormalized_widths, dim=-1)
         knots = 2 * tail_bound * torch.cumsum(w, dim=-1)[..., :-1] - tail_bound          # the K-1 interior knots
         d = (inputs[..., None] - knots).abs().min(dim=-1).values
-        d = torch.where((inputs >= -tail_bound) & (inputs <= tail_bound), d, torch.full_like(d, float("inf")))
+        if include_bounds:     # the spline meets its linear tails C1 at +-B: the same two-valued second derivative
+            d = torch.minimum(d, (inputs.abs() - tail_bound).abs())
+        else:
+            d = torch.where((inputs >= -tail_bound) & (inputs <= tail_bound), d, torch.full_like(d, float("inf")))
         captured.append((d / float(np.spacing(np.float32(tail_bound)))).detach())
         return real(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse=inverse,
                     tail_bound=tail_bound, min_bin_width=min_bin_width, **kw)

@@ -15,6 +15,18 @@ from tests.parity_log import record
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["cooperative", "throughput"])
+def kernel_family(request):
+    """Every test of this file runs on BOTH kernel families: calls of <= 12 288 rows normally take the cooperative
+    small-batch kernels (csrc/nsf_coop.h); `throughput` switches them off so that the wave-per-tile kernels stay
+    covered at the same sizes."""
+    from sbi_amd import _lib
+
+    prev = _lib.load().sbi_amd_nsf_set_coop_max_rows(12288 if request.param == "cooperative" else 0)
+    yield request.param
+    _lib.load().sbi_amd_nsf_set_coop_max_rows(prev)
+
 ATOL, RTOL = 1e-5, 1e-5
 
 CONFIGS = [

@@ -96,7 +96,7 @@ def test_sample_from_noise_65536_matches_oracle():
     assert frac > 0.999
 
 
-KNOT_ULPS = 8.0             # fp32 spacings at the tail bound within which a row counts as knot-straddling
+KNOT_ULPS = 2.0             # fp32 spacings at the tail bound within which a row counts as knot-straddling
 WORST_BLOCK_VS_O32 = 4.0    # per-block error budget in units of the eager fp32 oracle's own worst block
 
 GRAD_CONFIGS = {

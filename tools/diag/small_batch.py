@@ -18,6 +18,14 @@ theta = torch.randn(N, 10)
 x = theta + 0.3 * torch.randn(N, 10)
 est = build_nsf(theta, x).cuda()
 theta, x = theta.cuda(), x.cuda()
+from sbi_amd import _lib
+
+# SB_FAMILY=throughput switches the cooperative small-batch kernels (csrc/nsf_coop.h) off for an A/B run
+if os.environ.get("SB_FAMILY") == "throughput":
+    _lib.load().sbi_amd_nsf_set_coop_max_rows(0)
+elif os.environ.get("SB_FAMILY") == "cooperative":
+    _lib.load().sbi_amd_nsf_set_coop_max_rows(1 << 40)
+print("family:", os.environ.get("SB_FAMILY", "default"), flush=True)
 for B in batches:
     st = FusedTrainStep(est)
     idx = torch.randint(0, N, (B,), device="cuda")
