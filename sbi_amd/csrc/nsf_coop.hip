@@ -23,9 +23,9 @@ bool coop_applies(const sbi_amd_nsf_config* cfg, int64_t n, bool training, NsfPl
   if (rc && rc != SBI_AMD_E_LDS) return false;   // (E_LDS speaks about the throughput kernels' weight image)
   return coop_build_plan(*pl, n, 0, training, cp) == 0;
 }
-// Is there a cooperative image for this configuration at all (any n)?
+// Is there a cooperative image for this configuration at all (any n)?  Deliberately independent of the row
+// threshold / ablation switches: the size of the packed buffer must not change when those are toggled at run time.
 bool coop_shape_ok(const sbi_amd_nsf_config* cfg, NsfPlan* pl, CoopPlan* cp) {
-  if (coop_max_rows() < 1 || (sbi_amd_dbg_ablate() & 16384)) return false;
   int rc = nsf_build_plan(cfg, 1, pl);
   if (rc && rc != SBI_AMD_E_LDS) return false;
   return coop_build_plan(*pl, 1, 0, true, cp) == 0;

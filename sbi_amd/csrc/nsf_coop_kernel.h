@@ -818,11 +818,11 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) co_write_tile(part, S.lin[3 + 3 * b], 16 * wave, nt, id, acc[nt]);
         if (hb64) co_write_bias(part, S.lin[3 + 3 * b], 16 * wave, id, accb);
-        f4 accc[2];
+        f4 accc[3];       // x-dim <= 32 plus the bias column: up to three n-tiles
         const int ntc = (C + 1 + 15) / 16;
-        co_dw<NT, 2>(GT1, CT, RS, 16 * wave, S.d_id, ntc, id, accc, nullptr);
+        co_dw<NT, 3>(GT1, CT, RS, 16 * wave, S.d_id, ntc, id, accc, nullptr);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 3; ++nt)
           if (nt < ntc) co_write_tile(part, S.lin[1 + 3 * b], 16 * wave, nt, id, accc[nt]);
       }
       wave_lds_fence();

@@ -87,6 +87,9 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
 
   // rows per workgroup: one 16-row tile while that still gives every CU at most two workgroups' worth of partial
   // slabs; two tiles per workgroup beyond (the A operands are then shared by both, the slabs halve)
+  static int nt_env = -1;   // debug aid: SBI_AMD_COOP_NT=1|2 forces the workgroup shape
+  if (nt_env < 0) { const char* a = getenv("SBI_AMD_COOP_NT"); nt_env = a ? atoi(a) : 0; }
+  if (nt_force <= 0) nt_force = nt_env;
   int NT = nt_force > 0 ? nt_force : (n > 4096 ? 2 : 1);
   if (NT > CO_MAX_NT) NT = CO_MAX_NT;
   cp->NT = NT;

@@ -245,8 +245,10 @@ def packed_weights(net: NSFNet, rows: Optional[int] = None, training: bool = Fal
     n = lib.sbi_amd_nsf_packed_floats(cfg)
     if n < 0:
         _lib.check(int(n), "nsf_packed_floats")
-    packed = cache[1] if (cache is not None and cache[1].device == dev and cache[1].numel() == n) else \
-        torch.zeros(int(n), dtype=torch.float32, device=dev)   # alignment gaps of the image are never written
+    if cache is not None and cache[1].device == dev and cache[1].numel() == n:
+        packed = cache[1]
+    else:
+        packed, have = torch.zeros(int(n), dtype=torch.float32, device=dev), 0   # (gaps of the images are never written)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_pack_images(cfg, _lib.ptr(fp), _lib.ptr(packed), want & ~have, _lib.current_stream(dev))
     _lib.check(rc, "nsf_pack")
