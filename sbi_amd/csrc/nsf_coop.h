@@ -35,7 +35,7 @@ struct CoMat {
   int lin;       // index into ShapeDesc::lin (or -1)
 };
 enum {
-  CO_K_W0 = 0,     // initial layer, K order [context (4 KC) ; identity features (4 KZ)]
+  CO_K_W0 = 0,     // initial layer, K order [context: KCQ quads ; identity features: one quad (<= 8 used)]
   CO_K_PLAIN,      // W[m][k]
   CO_K_WF,         // final layer: m-tile = (dim, 16-param tile), K = hidden
   CO_K_WFT,        // final layer transposed: m = hidden, k = (dim, param padded to 16 PT)
@@ -53,8 +53,9 @@ struct CoShape {    // per mask parity
   CoMat WFT, W1T[NSF_MAX_NB], W2T[NSF_MAX_NB], W0T, UT, LT;                      // backward
   CoMat WCT[NSF_MAX_NB], W0CT;                                                   // backward, d loss / d context
   CoBias b0, bc[NSF_MAX_NB], b1[NSF_MAX_NB], b2[NSF_MAX_NB], bf, blu;
-  int o_ld;         // slot holding sum_i log U_ii
-  int KC, KZ;       // K-steps of the context / identity part of the initial layer
+  int o_bias;       // first float behind the matrices (256-aligned): bias blocks, then
+  int o_ld;         // the slot holding sum_i log U_ii
+  int KCQ;          // K-quads (16 context features each) of the context part of the initial / gate layers (1 or 2)
   int nft;          // final-layer m-tiles = d_tr * PT
 };
 

@@ -41,7 +41,8 @@ int coop_pack(const sbi_amd_nsf_config* cfg, const float* params, float* cimg, v
   NsfPlan pl;
   CoopPlan cp;
   if (!coop_shape_ok(cfg, &pl, &cp)) return 0;
-  hipLaunchKernelGGL(nsf_coop_pack_kernel, dim3(pl.T, 48), dim3(256), 0, (hipStream_t)stream, pl, cp, params, cimg);
+  hipLaunchKernelGGL(nsf_coop_pack_kernel, dim3(pl.T, cp.img_floats >> 8), dim3(256), 0, (hipStream_t)stream, pl, cp,
+                     params, cimg);
   return (int)hipGetLastError();
 }
 
@@ -89,7 +90,7 @@ int64_t coop_workspace_floats(const NsfPlan& pl, const CoopPlan& cp, int64_t n) 
 int coop_log_prob(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
                   const float* zstats, const float* theta, const float* x, int64_t n, int64_t x_rows, float* logp,
                   float* noise, void* stream) {
-  CoFwdArgs a = {cimg, zstats, theta, x, (long long)n, (long long)x_rows, logp, noise, nullptr, nullptr};
+  CoFwdArgs a = {cimg, zstats, theta, x, (long long)n, (long long)x_rows, logp, noise, nullptr, nullptr, nullptr};
   return co_dispatch_fwd(cfg, pl, cp, a, (hipStream_t)stream);
 }
 
@@ -98,10 +99,28 @@ int coop_train_forward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const C
                        float* logp_out, float* workspace, void* stream) {
   int64_t o_zst, o_noise, o_logp, o_part, o_ast;
   co_ws_layout(pl, cp, n, &o_zst, &o_noise, &o_logp, &o_part, &o_ast);
+  // debug timeline (SBI_AMD_TIMELINE): the stamps land in the (not yet used) partial-slab region and are printed here
+  long long* dbg = sbi_amd_dbg_timeline() ? (long long*)(workspace + o_part) : nullptr;
+  if (dbg) hipMemsetAsync(dbg, 0, 256 * sizeof(long long), (hipStream_t)stream);
   CoFwdArgs a = {cimg, zstats, theta, x, (long long)n, (long long)x_rows, workspace + o_logp, workspace + o_noise,
-                 workspace + o_zst, workspace + o_ast};
+                 workspace + o_zst, workspace + o_ast, dbg};
   int rc = co_dispatch_fwd(cfg, pl, cp, a, (hipStream_t)stream);
   if (rc) return rc;
+  if (dbg) {
+    static int printed = 0;
+    long long h[256];
+    hipStreamSynchronize((hipStream_t)stream);
+    hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    if (printed++ == 20) {      // a warm call
+      fprintf(stderr, "coop fwd timeline (cycles since stamp 0 of wave 0), n = %lld, NT = %d\n", (long long)n, cp.NT);
+      for (int i = 0; i < 64; ++i) {
+        if (!h[i] && !h[64 + i]) continue;
+        fprintf(stderr, "  stamp %2d:", i);
+        for (int w = 0; w < 4; ++w) fprintf(stderr, " %8lld", h[64 * w + i] ? h[64 * w + i] - h[0] : -1);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   if (logp_out) {
     hipError_t e = hipMemcpyAsync(logp_out, workspace + o_logp, sizeof(float) * n, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);

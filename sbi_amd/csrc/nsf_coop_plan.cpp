@@ -47,13 +47,12 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   for (int par = 0; par < 2; ++par) {
     const ShapeDesc& S = pl.shape[par];
     CoShape& c = cp->sh[par];
-    c.KC = (pl.C + 3) / 4;
-    c.KZ = (S.d_id + 3) / 4;
+    c.KCQ = (pl.C + 15) / 16;
     c.nft = S.d_tr * pl.PT;
     int o = 0;
-    add_mat(&c.W0, &o, NSF_HT, (c.KC + c.KZ + 3) / 4, CO_K_W0, 0);
+    add_mat(&c.W0, &o, NSF_HT, c.KCQ + 1, CO_K_W0, 0);
     for (int b = 0; b < pl.NB; ++b) {
-      add_mat(&c.WC[b], &o, NSF_HT, (c.KC + 3) / 4, CO_K_PLAIN, 1 + 3 * b);
+      add_mat(&c.WC[b], &o, NSF_HT, c.KCQ, CO_K_PLAIN, 1 + 3 * b);
       add_mat(&c.W1[b], &o, NSF_HT, HQ, CO_K_PLAIN, 2 + 3 * b);
       add_mat(&c.W2[b], &o, NSF_HT, HQ, CO_K_PLAIN, 3 + 3 * b);
     }
@@ -70,6 +69,7 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
     add_mat(&c.LT, &o, 1, 1, CO_K_LT, -1);
     for (int b = 0; b < pl.NB; ++b) add_mat(&c.WCT[b], &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 1 + 3 * b);
     add_mat(&c.W0CT, &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 0);
+    c.o_bias = o;        // (256-aligned: every matrix block is 256 floats) the bias blocks and the log-det slot follow
     add_bias(&c.b0, &o, NSF_HT, 0, 0);
     for (int b = 0; b < pl.NB; ++b) {
       add_bias(&c.bc[b], &o, NSF_HT, 0, 1 + 3 * b);
