@@ -57,6 +57,11 @@ struct CoShape {    // per mask parity
   int o_ld;         // the slot holding sum_i log U_ii
   int KCQ;          // K-quads (16 context features each) of the context part of the initial / gate layers (1 or 2)
   int nft;          // final-layer m-tiles = d_tr * PT
+  // partial weight-gradient slab of one (workgroup, transform): 256-float tiles in D-fragment order (lane l holds four
+  // consecutive inputs 16 nt + 4 (l >> 4) + r of output 16 mt + (l & 15); the bias is input index L.in), one
+  // 16-byte store per lane and tile; linear k's tile (mt, nt) is dw_tb[k] + mt * dw_nnt[k] + nt
+  int dw_tb[NSF_MAX_LIN], dw_nnt[NSF_MAX_LIN];
+  int dw_tail;      // float offset of the LULinear block (natural order: lower, upper, diag, bias, sum d/d logabsdet)
 };
 
 struct CoopPlan {
@@ -71,8 +76,33 @@ struct CoopPlan {
   int o_zs, o_gys, o_gzs, o_w, o_pst, o_ex, o_ldp, o_gt, o_at, o_ct, o_lut, o_ctx, lds_floats;
   int ct_rows;              // rows of the static conditioner-input tile
   int grid;                 // workgroups
-  int PLP;                  // floats per (workgroup, transform) partial-gradient slab (natural parameter order)
+  int PLP;                  // floats per (workgroup, transform) partial-gradient slab (tile order, see CoShape)
 };
+
+// Compact kernel constants of the forward / backward kernels (~0.5 KB of kernarg instead of the 3.5 KB of both plans):
+// everything those kernels read, as plain scalars the compiler keeps in SGPRs.  A kernel that walks the plan structs
+// pays one scalar-cache round trip (~200 cycles, and an lgkmcnt wait that also drains its LDS reads) per field it
+// touches -- measured at a third of the backward kernel's time.
+struct CoKP {      // per mask parity
+  int d_id, d_tr, in0, nft;
+  int nnt0;        // n-tiles of d W0 (conditioner input + bias column)
+  int dw_tail;     // slab offset of the LULinear block
+  int w0, wc0, w10, w20, wf, u, l, wft, w1t0, w2t0, w0t, ut, lt, wct0, w0ct;   // image offsets (block b: + b * stride)
+  int b0, bc0, b10, b20, bf, blu, ld;
+};
+struct CoK {
+  int D, C, H, NB, T, P, KCQ;
+  int sA, sT, sC, sB;          // per-block strides of [WC W1 W2], [W1T W2T], [WCT] and of the bias blocks [bc b1 b2]
+  int img_floats;
+  int ZS, RS, PSW, DSTR;
+  int o_zs, o_gys, o_gzs, o_w, o_pst, o_ex, o_ldp, o_gt, o_at, o_ct, o_lut, o_ctx, ct_rows;
+  int slots, s_blk, s_par;
+  int PLP, ntc, nnh;           // slab: floats per (workgroup, transform); n-tiles of d Wc and of the hidden-input layers
+  int ablate;
+  float B, min_w, min_h, min_d, inv_sqrt_h, one_minus_kw, one_minus_kh, d_const, log_z;
+  CoKP p[2];
+};
+void coop_make_consts(const NsfPlan& pl, const CoopPlan& cp, CoK* k);
 
 // 0 or SBI_AMD_E_*: which shapes the cooperative kernels take (everything else keeps the throughput kernels)
 int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, CoopPlan* cp);

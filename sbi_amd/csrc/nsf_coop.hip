@@ -80,6 +80,7 @@ static int64_t co_ws_layout(const NsfPlan& pl, const CoopPlan& cp, int64_t n, in
   *o_part = o; o += (int64_t)pl.T * cp.grid * cp.PLP;
   o = (o + 63) / 64 * 64;
   *o_ast = o; o += (int64_t)pl.T * ((n + 15) / 16) * cp.slots * 256;
+  o += 1024;   // debug timelines (SBI_AMD_TIMELINE): the last 512 int64 of the workspace
   return o;
 }
 int64_t coop_workspace_floats(const NsfPlan& pl, const CoopPlan& cp, int64_t n) {
@@ -129,18 +130,37 @@ int coop_train_forward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const C
   return 0;
 }
 
-// backward launch; the caller (nsf_train.hip) follows it with nsf_grad_reduce_kernel over `*partial_out`
-// (grid = cp.grid slabs of cp.PLP floats per transform: the throughput path's layout)
-int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
-                        const float* zstats, const float* x, int64_t n, int64_t x_rows, const float* row_weight,
-                        float uniform_weight, float* grad_theta_out, float* grad_x_out, float* workspace,
-                        const float** partial_out,
-                        const float** logp_out, void* stream) {
+// backward launch + the fixed-order reduction of its partial slabs (grid = cp.grid slabs of cp.PLP floats per transform)
+int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* params,
+                        const float* cimg, const float* zstats, const float* x, int64_t n, int64_t x_rows,
+                        const float* row_weight, float uniform_weight, float* grad_out, float* grad_theta_out,
+                        float* grad_x_out, float* loss_out, float* workspace, void* stream) {
   int64_t o_zst, o_noise, o_logp, o_part, o_ast;
   co_ws_layout(pl, cp, n, &o_zst, &o_noise, &o_logp, &o_part, &o_ast);
+  const int64_t ws_total = coop_workspace_floats(pl, cp, n);
+  long long* dbg = sbi_amd_dbg_timeline() ? (long long*)(workspace + ws_total - 1024) : nullptr;
+  if (dbg) hipMemsetAsync(dbg, 0, 256 * sizeof(long long), (hipStream_t)stream);
   CoBwdArgs a = {cimg, zstats, x, (long long)n, (long long)x_rows, row_weight, uniform_weight, workspace + o_noise,
-                 workspace + o_zst, workspace + o_ast, workspace + o_part, grad_theta_out, grad_x_out};
-  *partial_out = workspace + o_part;
-  *logp_out = workspace + o_logp;
-  return co_dispatch_bwd(cfg, pl, cp, a, (hipStream_t)stream);
+                 workspace + o_zst, workspace + o_ast, workspace + o_part, grad_theta_out, grad_x_out, dbg};
+  int rc = co_dispatch_bwd(cfg, pl, cp, a, (hipStream_t)stream);
+  if (rc) return rc;
+  if (dbg) {
+    static int printed = 0;
+    long long h[256];
+    hipStreamSynchronize((hipStream_t)stream);
+    hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    if (printed++ == 20) {
+      fprintf(stderr, "coop bwd timeline (cycles since stamp 0 of wave 0), n = %lld, NT = %d\n", (long long)n, cp.NT);
+      for (int i = 0; i < 64; ++i) {
+        if (!h[i] && !h[64 + i]) continue;
+        fprintf(stderr, "  stamp %2d:", i);
+        for (int w = 0; w < 4; ++w) fprintf(stderr, " %8lld", h[64 * w + i] ? h[64 * w + i] - h[0] : -1);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  hipLaunchKernelGGL(nsf_coop_reduce_kernel, dim3((cp.PLP + 63) / 64, pl.T), dim3(64 * CO_RED_GROUPS), 0,
+                     (hipStream_t)stream, pl, cp, params, (const float*)(workspace + o_part), grad_out,
+                     (const float*)(workspace + o_logp), loss_out, (long long)n);
+  return (int)hipGetLastError();
 }

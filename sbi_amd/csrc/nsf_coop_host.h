@@ -14,8 +14,7 @@ int coop_log_prob(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPl
 int coop_train_forward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
                        const float* zstats, const float* theta, const float* x, int64_t n, int64_t x_rows,
                        float* logp_out, float* workspace, void* stream);
-int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
-                        const float* zstats, const float* x, int64_t n, int64_t x_rows, const float* row_weight,
-                        float uniform_weight, float* grad_theta_out, float* grad_x_out, float* workspace,
-                        const float** partial_out,
-                        const float** logp_out, void* stream);
+int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* params,
+                        const float* cimg, const float* zstats, const float* x, int64_t n, int64_t x_rows,
+                        const float* row_weight, float uniform_weight, float* grad_out, float* grad_theta_out,
+                        float* grad_x_out, float* loss_out, float* workspace, void* stream);

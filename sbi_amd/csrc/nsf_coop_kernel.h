@@ -143,20 +143,96 @@ nsf_coop_pack_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restric
     img[idx] = v;
   }
 }
+
+// grad[p] = sum over workgroups of the partial slabs in a fixed association (deterministic, no atomics).  The kernel
+// walks the slab in ITS order (one thread per slab word: the loads of a wave are contiguous) and scatters each sum to
+// the parameter the word belongs to (CoShape::dw_tb); padding words are skipped.  Finishes LULinear's diagonal as the
+// throughput path's nsf_grad_reduce_kernel does:  d/d(unconstrained_upper_diag_i) =
+//   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i).   Rider: loss_out = -log p.
+#define CO_RED_GROUPS 8
+__global__ void __launch_bounds__(64 * CO_RED_GROUPS)
+nsf_coop_reduce_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict__ params,
+                       const float* __restrict__ partial, float* __restrict__ grad, const float* __restrict__ logp,
+                       float* __restrict__ loss_out, long long n_rows) {
+  if (loss_out)
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_rows;
+         i += (long long)gridDim.x * gridDim.y * blockDim.x)
+      loss_out[i] = -logp[i];
+  __shared__ float red[CO_RED_GROUPS][64];
+  __shared__ float red_sgl[CO_RED_GROUPS][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int t = blockIdx.y;
+  const ShapeDesc& S = pl.shape[t & 1];
+  const CoShape& c = cp.sh[t & 1];
+  const int pos = blockIdx.x * 64 + lane;       // word of the slab
+  const int D = pl.D, ntri = D * (D - 1) / 2;
+  int li = -1;                                  // parameter (relative to the transform's block) this word belongs to
+  if (pos < c.dw_tail) {
+    const int tile = pos >> 8, l = (pos >> 2) & 63, r = pos & 3;
+    int k = 0;
+    for (int kk = 1; kk <= S.fin; ++kk) k = tile >= c.dw_tb[kk] ? kk : k;
+    const LinDesc& L = S.lin[k];
+    const int rel = tile - c.dw_tb[k];
+    const int mt = rel / c.dw_nnt[k], nt = rel - mt * c.dw_nnt[k];
+    const int j = l & 15, g = l >> 4;
+    int out = 16 * mt + j;
+    if (k == S.fin) {
+      const int dd = mt / pl.PT, p = 16 * (mt - dd * pl.PT) + j;
+      out = p < pl.P ? dd * pl.P + p : L.out;
+    }
+    const int in = 16 * nt + 4 * g + r;
+    if (out < L.out && in <= L.in) li = in < L.in ? L.g_w + out * L.in + in : L.g_b + out;
+  } else if (pos - c.dw_tail < 2 * ntri + 2 * D) {
+    li = S.g_lu + (pos - c.dw_tail);
+  }
+  const bool live = li >= 0;
+  const bool is_diag = live && li >= S.g_lu + 2 * ntri && li < S.g_lu + 2 * ntri + D;
+  const float* base = partial + (long long)t * cp.grid * cp.PLP;
+  float a = 0.f, sgl = 0.f;
+  if (live) {
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    int w = grp;
+    for (; w + 3 * CO_RED_GROUPS < cp.grid; w += 4 * CO_RED_GROUPS) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] += base[(long long)(w + u * CO_RED_GROUPS) * cp.PLP + pos];
+    }
+    for (; w < cp.grid; w += CO_RED_GROUPS) acc4[0] += base[(long long)w * cp.PLP + pos];
+    a = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    if (is_diag)
+      for (int w2 = grp; w2 < cp.grid; w2 += CO_RED_GROUPS) sgl += base[(long long)w2 * cp.PLP + c.dw_tail + 2 * ntri + 2 * D];
+  }
+  red[grp][lane] = a;
+  red_sgl[grp][lane] = sgl;
+  __syncthreads();
+  if (grp == 0 && live) {
+    float tot = 0.f, tsg = 0.f;
+#pragma unroll
+    for (int g = 0; g < CO_RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g][lane]; }
+    const int idx = pl.g_layer[t] + li;
+    if (is_diag) {
+      const float ud = params[idx];
+      const float uii = softplus_f(ud) + pl.lu_eps;
+      tot = (tot + tsg / uii) * (1.f / (1.f + expf(-ud)));
+    }
+    grad[idx] = tot;
+  }
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------ device helpers
-// A fragments of one m-tile of a matrix: NQ 16-byte words per lane (block stride 256 floats)
+// The forward / backward kernels read nothing but the compact constant block CoK (nsf_coop.h): image offsets are
+// plain integers (block b of a per-block matrix: offset + b * stride), every matrix block is 256 floats (64 lanes x 4
+// K-steps), an m-tile of a matrix with Q K-quads is Q consecutive blocks.
 template <int NQ>
-__device__ __forceinline__ void co_load_a(const float* __restrict__ img, const CoMat& m, int mt, int lane, f4 (&a)[NQ]) {
-  // NQ words are read unconditionally (branch-free): a matrix with fewer quads is followed by other readable image
-  // data, and the K-steps of those words are never issued
-  const f4* p = reinterpret_cast<const f4*>(img + m.off + mt * m.quads * 256) + lane;
+__device__ __forceinline__ void co_load_a(const float* __restrict__ p, int lane, f4 (&a)[NQ]) {
+  // NQ 16-byte words per lane, read unconditionally (branch-free): a matrix with fewer quads is followed by other
+  // readable image data, and the K-steps of those words are never issued
+  const f4* q = reinterpret_cast<const f4*>(p) + lane;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) a[q] = p[q * 64];
+  for (int i = 0; i < NQ; ++i) a[i] = q[i * 64];
 }
-__device__ __forceinline__ f4 co_load_bias(const float* __restrict__ img, const CoBias& b, int mt, int g) {
-  return *reinterpret_cast<const f4*>(img + b.off + 16 * mt + 4 * g);
+__device__ __forceinline__ f4 co_load_bias(const float* __restrict__ p, int mt, int g) {
+  return *reinterpret_cast<const f4*>(p + 16 * mt + 4 * g);
 }
 
 // all-gather of the waves' D fragments: out[u][mt] = fragment of wave mt (lane for lane); one barrier
@@ -183,11 +259,8 @@ __device__ __forceinline__ void co_gemm_h(const f4 (&a)[4], const f4 (&b)[NT][CO
     for (int u = 0; u < NT; ++u) acc[u] = MFMA16(a[s >> 2][s & 3], b[u][s >> 2][s & 3], acc[u]);
 }
 
-// stash slot address of (transform t, 16-row tile, slot): 256 floats, lane-major 16-byte words
-__device__ __forceinline__ f4* co_slot(float* __restrict__ ast, const CoopPlan& cp, long long nt16, int t,
-                                       long long tile16, int slot, int lane) {
-  return reinterpret_cast<f4*>(ast + (((long long)t * nt16 + tile16) * cp.slots + slot) * 256) + lane;
-}
+template <int K_>
+struct CoIdx { static constexpr int value = K_; };
 
 // ------------------------------------------------------------------------------------------------ forward
 // Every weight a wave needs is requested from L2 well before its use (the image is written by another XCD's pack
@@ -201,41 +274,38 @@ struct CoSet {
   f4 ac[2];       // W1 stages: A fragments of the block's context layer (gate)
   f4 bias, biasc;
 };
-template <int K_>
-struct CoIdx { static constexpr int value = K_; };
-
 template <int KS>   // stage index: even = W1_b (+ gate), odd = W2_b
-__device__ __forceinline__ void co_load_set(const float* __restrict__ img, const CoShape& c, int wave,
+__device__ __forceinline__ void co_load_set(const float* __restrict__ img, const CoK& k, const CoKP& kp, int wave,
                                             const LaneId& id, CoSet& s) {
   constexpr int b = KS >> 1;
   if ((KS & 1) == 0) {
-    co_load_a<4>(img, c.W1[b], wave, id.lane, s.a);
-    co_load_a<2>(img, c.WC[b], wave, id.lane, s.ac);
-    s.bias = co_load_bias(img, c.b1[b], wave, id.g);
-    s.biasc = co_load_bias(img, c.bc[b], wave, id.g);
+    co_load_a<4>(img + kp.w10 + b * k.sA + wave * 1024, id.lane, s.a);
+    co_load_a<2>(img + kp.wc0 + b * k.sA + wave * k.KCQ * 256, id.lane, s.ac);
+    s.bias = co_load_bias(img + kp.b10 + b * k.sB, wave, id.g);
+    s.biasc = co_load_bias(img + kp.bc0 + b * k.sB, wave, id.g);
   } else {
-    co_load_a<4>(img, c.W2[b], wave, id.lane, s.a);
-    s.bias = co_load_bias(img, c.b2[b], wave, id.g);
+    co_load_a<4>(img + kp.w20 + b * k.sA + wave * 1024, id.lane, s.a);
+    s.bias = co_load_bias(img + kp.b20 + b * k.sB, wave, id.g);
   }
 }
 struct CoW0 {
   f4 a[3];
   f4 bias;
 };
-__device__ __forceinline__ void co_load_w0(const float* __restrict__ img, const CoShape& c, int wave, const LaneId& id,
-                                           CoW0& w) {
-  co_load_a<3>(img, c.W0, wave, id.lane, w.a);
-  w.bias = co_load_bias(img, c.b0, wave, id.g);
+__device__ __forceinline__ void co_load_w0(const float* __restrict__ img, const CoK& k, const CoKP& kp, int wave,
+                                           const LaneId& id, CoW0& w) {
+  co_load_a<3>(img + kp.w0 + wave * (k.KCQ + 1) * 256, id.lane, w.a);
+  w.bias = co_load_bias(img + kp.b0, wave, id.g);
 }
 struct CoWf {
   f4 a[4];
   f4 bias;
 };
-__device__ __forceinline__ void co_load_wf(const float* __restrict__ img, const CoShape& c, int mt, const LaneId& id,
+__device__ __forceinline__ void co_load_wf(const float* __restrict__ img, const CoKP& kp, int mt, const LaneId& id,
                                            CoWf& w) {
-  const int m = mt < c.nft ? mt : c.nft - 1;     // clamped instead of predicated: straight-line code
-  co_load_a<4>(img, c.WF, m, id.lane, w.a);
-  w.bias = co_load_bias(img, c.bf, m, id.g);
+  const int m = mt < kp.nft ? mt : kp.nft - 1;     // clamped instead of predicated: straight-line code
+  co_load_a<4>(img + kp.wf + m * 1024, id.lane, w.a);
+  w.bias = co_load_bias(img + kp.bf, m, id.g);
 }
 // acc[u] += A(context quads) * standardized context (K-steps of the context live in registers)
 template <int NT>
@@ -252,10 +322,10 @@ __device__ __forceinline__ void co_gemm_ctx(const f4 (&a)[2], int kcq, const flo
 
 template <int K, int KSH, int NT>
 __global__ void __launch_bounds__(64 * CO_WAVES, 1)
-nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict__ cimg,
-                    const float* __restrict__ zstats, const float* __restrict__ theta, const float* __restrict__ x,
-                    long long n, long long x_rows, float* __restrict__ logp, float* __restrict__ noise_out,
-                    float* __restrict__ zst, float* __restrict__ ast, long long* __restrict__ dbg) {
+nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __restrict__ zstats,
+                    const float* __restrict__ theta, const float* __restrict__ x, long long n, long long x_rows,
+                    float* __restrict__ logp, float* __restrict__ noise_out, float* __restrict__ zst,
+                    float* __restrict__ ast, long long* __restrict__ dbg) {
   // debug timeline (SBI_AMD_TIMELINE): cycle stamps of workgroup 0's waves while they walk transform 1
 #define TSC(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 1) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -264,26 +334,26 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6;
   const LaneId id = make_lane();
-  const int D = pl.D, C = pl.C, ZS = cp.ZS;
-  float* zs = lds + cp.o_zs;
-  float* pst = lds + cp.o_pst;
-  float* ex = lds + cp.o_ex;
-  float* ldp = lds + cp.o_ldp;
+  const int D = k.D, C = k.C, ZS = k.ZS;
+  float* zs = lds + k.o_zs;
+  float* pst = lds + k.o_pst;
+  float* ex = lds + k.o_ex;
+  float* ldp = lds + k.o_ldp;
   const long long row0 = (long long)blockIdx.x * R;
   const long long nt16 = (n + 15) / 16;
   const float* th_shift = zstats;
   const float* th_scale = zstats + D;
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
-  const int nstages = 2 * pl.NB;
-  const int kcq = cp.sh[0].KCQ;
+  const int nstages = 2 * k.NB;
+  const int kcq = k.KCQ;
 
   // ---- weights of the first transform: requested before anything else
   CoW0 w0;
   CoSet S[3];
-  co_load_w0(cimg, cp.sh[0], wave, id, w0);
-  co_load_set<0>(cimg, cp.sh[0], wave, id, S[0]);
-  co_load_set<1>(cimg, cp.sh[0], wave, id, S[1]);
+  co_load_w0(cimg, k, k.p[0], wave, id, w0);
+  co_load_set<0>(cimg, k, k.p[0], wave, id, S[0]);
+  co_load_set<1>(cimg, k, k.p[0], wave, id, S[1]);
 
   // ---- prologue: z-scored theta rows -> LDS; standardized context as B fragments (K-step s <-> c = 4 s + g)
   for (int i = tid; i < R * ZS + 16; i += 64 * CO_WAVES) zs[i] = 0.f;
@@ -318,20 +388,25 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
   float ld_const = 0.f;
   for (int d = 0; d < D; ++d) ld_const += logf(fabsf(th_scale[d]));
   int buf = 0;
+  // stash addresses of this wave's fragments: slot s of transform t, row tile u is (abase[u] + t * astride + s * 256)
+  float* abase[NT];
+  const long long astride = nt16 * k.slots * 256;
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+    abase[u] = (ast && (row0 >> 4) + u < nt16) ? ast + ((row0 >> 4) + u) * k.slots * 256 + 4 * id.lane : nullptr;
   __syncthreads();
 
-  for (int t = 0; t < pl.T; ++t) {
+  for (int t = 0; t < k.T; ++t) {
     const int par = t & 1;
-    const ShapeDesc& S_ = pl.shape[par];
-    const CoShape& c = cp.sh[par];
-    const float* img = cimg + (long long)t * cp.img_floats;
+    const CoKP& kp = k.p[par];
+    const float* img = cimg + (long long)t * k.img_floats;
     if (zst)
       for (int i = tid; i < R * D; i += 64 * CO_WAVES) {
         const int r = i / D, d = i - r * D;
         if (row0 + r < n) zst[((long long)t * n + row0 + r) * D + d] = zs[r * ZS + d];
       }
     TSC(0);
-    if (2 < nstages) co_load_set<2>(img, c, wave, id, S[2]);
+    if (2 < nstages) co_load_set<2>(img, k, kp, wave, id, S[2]);
     // ---- initial layer: h = W0 [context ; z_id] + b0   (m-tile = wave)
     f4 h[NT];
     {
@@ -343,11 +418,11 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
 #pragma unroll
       for (int sz = 0; sz < 2; ++sz) {
         const int kz = 4 * sz + id.g;
-        const int kzc = kz < S_.d_id ? kz : 0;
+        const int kzc = kz < kp.d_id ? kz : 0;
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           const float zv = zs[(16 * u + id.j) * ZS + 2 * kzc + (1 - par)];
-          h[u] = MFMA16(az[sz], kz < S_.d_id ? zv : 0.f, h[u]);
+          h[u] = MFMA16(az[sz], kz < kp.d_id ? zv : 0.f, h[u]);
         }
       }
     }
@@ -362,16 +437,15 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
     CoWf wf0, wf1;
     f4 gate[NT], tt[NT];
     auto stage = [&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      constexpr int b = k >> 1;
-      CoSet& cur = S[k % 3];
+      constexpr int ks = decltype(kc)::value;
+      CoSet& cur = S[ks % 3];
       f4 u1[NT], bg[NT][CO_WAVES];
-      if (k + 2 < nstages) co_load_set<(k + 2 < 2 * NSF_MAX_NB ? k + 2 : 0)>(img, c, wave, id, S[(k + 2) % 3]);
-      if (k == nstages - 2) {   // the wave's first two final-layer tiles, two stages ahead
-        co_load_wf(img, c, wave, id, wf0);
-        co_load_wf(img, c, wave + CO_WAVES, id, wf1);
+      if (ks + 2 < nstages) co_load_set<(ks + 2 < 2 * NSF_MAX_NB ? ks + 2 : 0)>(img, k, kp, wave, id, S[(ks + 2) % 3]);
+      if (ks == nstages - 2) {   // the wave's first two final-layer tiles, two stages ahead
+        co_load_wf(img, kp, wave, id, wf0);
+        co_load_wf(img, kp, wave + CO_WAVES, id, wf1);
       }
-      if ((k & 1) == 0) {
+      if ((ks & 1) == 0) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           gate[u] = cur.biasc;
@@ -381,11 +455,11 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         co_gemm_ctx<NT>(cur.ac, kcq, cb, gate);
       }
       co_gather<NT>(ex, buf, wave, id.lane, tt, bg);
-      TSC(2 + 2 * k);
+      TSC(2 + 2 * ks);
 #pragma unroll
       for (int u = 0; u < NT; ++u) u1[u] = cur.bias;
       co_gemm_h<NT, KSH>(cur.a, bg, u1);
-      if ((k & 1) == 0) {
+      if ((ks & 1) == 0) {
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -394,16 +468,16 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
             tt[u][r] = fmaxf(u1[u][r], 0.f);
           }
 #pragma unroll
-        for (int u = 0; u < NT; ++u) { sv[k][0][u] = u1[u]; sv[k][1][u] = gate[u]; }    // t1 (pre-relu), sigmoid(gate)
+        for (int u = 0; u < NT; ++u) { sv[ks][0][u] = u1[u]; sv[ks][1][u] = gate[u]; }    // t1 (pre-relu), sigmoid(gate)
       } else {
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[u][r] += u1[u][r] * gate[u][r];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) { sv[k][0][u] = u1[u]; sv[k][1][u] = h[u]; }       // t2, h_{b+1}
+        for (int u = 0; u < NT; ++u) { sv[ks][0][u] = u1[u]; sv[ks][1][u] = h[u]; }       // t2, h_{b+1}
       }
-      TSC(3 + 2 * k);
+      TSC(3 + 2 * ks);
     };
     stage(CoIdx<0>{});
     stage(CoIdx<1>{});
@@ -418,19 +492,19 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int mt = wave + CO_WAVES * i;
-        if (mt < c.nft) {
+        if (mt < kp.nft) {
           CoWf& w = (i & 1) ? wf1 : wf0;
           f4 acc[NT];
 #pragma unroll
           for (int u = 0; u < NT; ++u) acc[u] = w.bias;
           co_gemm_h<NT, KSH>(w.a, hb, acc);
-          if (i < 2) co_load_wf(img, c, mt + 2 * CO_WAVES, id, w);     // two tiles ahead
+          if (i < 2) co_load_wf(img, kp, mt + 2 * CO_WAVES, id, w);     // two tiles ahead
           const int dd = mt / PT, pt = mt - dd * PT;
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              pst[(16 * u + id.j) * cp.DSTR + dd * cp.PSW + 16 * pt + 4 * r + id.g] = acc[u][r];
+              pst[(16 * u + id.j) * k.DSTR + dd * k.PSW + 16 * pt + 4 * r + id.g] = acc[u][r];
             pv[i][u] = acc[u];
           }
         }
@@ -440,34 +514,35 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
     if (ast) {      // the stash burst (plain stores: the backward workgroup of the same index runs on the same XCD)
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
-        const long long t16 = (row0 >> 4) + u;
-        if (t16 < nt16) {
-          *co_slot(ast, cp, nt16, t, t16, wave, id.lane) = sv0[u];
+        float* ab = abase[u] ? abase[u] + t * astride : nullptr;
+        if (ab) {
+          *reinterpret_cast<f4*>(ab + wave * 256) = sv0[u];
 #pragma unroll
-          for (int k = 0; k < 2 * NSF_MAX_NB; ++k)
-            if (k < nstages) {
-              const int b = k >> 1, o = (k & 1) ? 4 : 0;      // even stage: t1 | gate, odd stage: t2 | h_{b+1}
-              *co_slot(ast, cp, nt16, t, t16, cp.s_blk + 16 * b + o + wave, id.lane) = sv[k][0][u];
-              *co_slot(ast, cp, nt16, t, t16, cp.s_blk + 16 * b + o + 8 + wave, id.lane) = sv[k][1][u];
+          for (int ks = 0; ks < 2 * NSF_MAX_NB; ++ks)
+            if (ks < nstages) {
+              const int b = ks >> 1, o = (ks & 1) ? 4 : 0;      // even stage: t1 | gate, odd stage: t2 | h_{b+1}
+              *reinterpret_cast<f4*>(ab + (k.s_blk + 16 * b + o + wave) * 256) = sv[ks][0][u];
+              *reinterpret_cast<f4*>(ab + (k.s_blk + 16 * b + o + 8 + wave) * 256) = sv[ks][1][u];
             }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (wave + CO_WAVES * i < c.nft) *co_slot(ast, cp, nt16, t, t16, cp.s_par + wave + CO_WAVES * i, id.lane) = pv[i][u];
+            if (wave + CO_WAVES * i < kp.nft)
+              *reinterpret_cast<f4*>(ab + (k.s_par + wave + CO_WAVES * i) * 256) = pv[i][u];
         }
       }
     }
     // LULinear's factors and the next transform's first weights: requested before the spline, landed after it
-    const f4 au = *(reinterpret_cast<const f4*>(img + c.U.off) + id.lane);
-    const f4 al = *(reinterpret_cast<const f4*>(img + c.L.off) + id.lane);
-    const f4 blu = co_load_bias(img, c.blu, 0, id.g);
-    const float ld_lu = img[c.o_ld];
+    const f4 au = *(reinterpret_cast<const f4*>(img + kp.u) + id.lane);
+    const f4 al = *(reinterpret_cast<const f4*>(img + kp.l) + id.lane);
+    const f4 blu = co_load_bias(img + kp.blu, 0, id.g);
+    const float ld_lu = img[kp.ld];
     {
-      const int tn = t + 1 < pl.T ? t + 1 : t;           // (the last transform re-requests itself: harmless)
-      const float* imgn = cimg + (long long)tn * cp.img_floats;
-      const CoShape& cn = cp.sh[tn & 1];
-      co_load_w0(imgn, cn, wave, id, w0);
-      co_load_set<0>(imgn, cn, wave, id, S[0]);
-      co_load_set<1>(imgn, cn, wave, id, S[1]);
+      const int tn = t + 1 < k.T ? t + 1 : t;           // (the last transform re-requests itself: harmless)
+      const float* imgn = cimg + (long long)tn * k.img_floats;
+      const CoKP& kn = k.p[tn & 1];
+      co_load_w0(imgn, k, kn, wave, id, w0);
+      co_load_set<0>(imgn, k, kn, wave, id, S[0]);
+      co_load_set<1>(imgn, k, kn, wave, id, S[1]);
     }
     __syncthreads();
     TSC(22);
@@ -475,14 +550,14 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
     {
       const int slot = id.g & 1, part = id.g >> 1;
       const int dd_raw = 2 * wave + slot;
-      const bool live = dd_raw < S_.d_tr;
+      const bool live = dd_raw < kp.d_tr;
       const int dd = live ? dd_raw : 0;
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
         const int r = 16 * u + id.j;
         const int zi = r * ZS + 2 * dd + par;
         float y, ld;
-        rq_spline_pair<K, false>(pst + r * cp.DSTR + dd * cp.PSW, zs[zi], pl, part, y, ld);
+        rq_spline_pair<K, false>(pst + r * k.DSTR + dd * k.PSW, zs[zi], k, part, y, ld);
         if (live && part == 0) zs[zi] = y;
         ld_acc[u] += (live && part == 0) ? ld : 0.f;
       }
@@ -531,7 +606,7 @@ nsf_coop_fwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         ss += z * z;
         if (noise_out) noise_out[row * D + d] = z;
       }
-      logp[row] = -0.5f * ss + ld + ld_const - pl.log_z;
+      logp[row] = -0.5f * ss + ld + ld_const - k.log_z;
     }
   }
 }
@@ -552,14 +627,10 @@ __device__ __forceinline__ void co_store_T(float* __restrict__ T, int RS, int f0
     }
 }
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte store to a 4-byte-aligned address
-
 // Weight-gradient tiles of one 16-wide slice of OUTPUT features, all from transposed LDS tiles (one ds_read_b128 per
 // operand, row tile and n-tile):  acc[nt][r] of lane (g, j) = d W[out0 + j][16 nt + 4 g + r]
 //   = sum over the workgroup's rows of Gt[out0 + j][row] * At[in_off + 16 nt + 4 g + r][row].
-// The INPUT index runs along the registers, so a lane owns four consecutive entries of one row of the (row-major)
-// weight gradient: one 16-byte store per tile instead of four scattered 4-byte ones (the partial slabs are the
-// kernel's largest output: 78 KB per 16 * NT rows and transform).
+// The INPUT index runs along the registers, so a lane owns four consecutive entries of one row of the weight gradient.
 template <int NT, int NNT>
 __device__ __forceinline__ void co_dw(const float* __restrict__ Gt, const float* __restrict__ At, int RS, int out0,
                                       int in_off, int nnt, const LaneId& id, f4 (&acc)[NNT], f4* accb) {
@@ -587,90 +658,76 @@ __device__ __forceinline__ void co_dw(const float* __restrict__ Gt, const float*
   }
 }
 
-// partial-gradient write-out of one tile of co_dw; column `in == L.in` of the activation tile is the ones row
-__device__ __forceinline__ void co_write_tile(float* __restrict__ part, const LinDesc& L, int out0, int nt,
+// partial-gradient write-out of one tile of co_dw (slab layout: CoShape::dw_tb): ONE aligned 16-byte store per lane,
+// 1 KiB contiguous per wave.  `tile` = the linear's tile base + mt * nnt + nt; lanes whose four inputs all lie behind
+// the bias column (16 nt + 4 g > in_dim), or whose output does not exist, store nothing (the reduction skips them).
+__device__ __forceinline__ void co_write_tile(float* __restrict__ part, int tile, bool out_ok, int nt, int in_dim,
                                               const LaneId& id, const f4& acc) {
-  const int out = out0 + id.j;
-  const int in = 16 * nt + 4 * id.g;
-  if (out >= L.out) return;
-  float* w = part + L.g_w + out * L.in + in;
-  if (in + 3 < L.in) {
-    *reinterpret_cast<f4u*>(w) = f4u{acc[0], acc[1], acc[2], acc[3]};
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (in + r < L.in) w[r] = acc[r];
-      else if (in + r == L.in) part[L.g_b + out] = acc[r];
-    }
-  }
-}
-__device__ __forceinline__ void co_write_bias(float* __restrict__ part, const LinDesc& L, int out0, const LaneId& id,
-                                              const f4& accb) {
-  const int out = out0 + id.j;
-  if (id.g == 0 && out < L.out) part[L.g_b + out] = accb[0];
-}
-
-// transposed hidden-K matrix of backward stage k (execution order: k even W2^T of block NB-1-k/2, k odd its W1^T)
-template <int KS>
-__device__ __forceinline__ void co_load_tset(const float* __restrict__ img, const CoShape& c, int NB, int wave,
-                                             int lane, f4 (&a)[4]) {
-  const int b = NB - 1 - (KS >> 1) > 0 ? NB - 1 - (KS >> 1) : 0;     // (clamped: a stage past the last re-reads block 0)
-  co_load_a<4>(img, (KS & 1) ? c.W1T[b] : c.W2T[b], wave, lane, a);
+  if (part && out_ok && 16 * nt + 4 * id.g <= in_dim)      // (part == null: SBI_AMD_ABLATE bit 32768, timing only)
+    *reinterpret_cast<f4*>(part + tile * 256 + 4 * id.lane) = acc;
 }
 
 template <int K, int KSH, int NT>
 __global__ void __launch_bounds__(64 * CO_WAVES, 1)
-nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict__ cimg,
-                    const float* __restrict__ zstats, const float* __restrict__ x, long long n, long long x_rows,
-                    const float* __restrict__ row_w, const float uni_w, const float* __restrict__ z_last,
-                    const float* __restrict__ zst, const float* __restrict__ ast, float* __restrict__ partial,
-                    float* __restrict__ grad_theta, float* __restrict__ grad_x) {
+nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __restrict__ zstats,
+                    const float* __restrict__ x, long long n, long long x_rows, const float* __restrict__ row_w,
+                    const float uni_w, const float* __restrict__ z_last, const float* __restrict__ zst,
+                    const float* __restrict__ ast, float* __restrict__ partial, float* __restrict__ grad_theta,
+                    float* __restrict__ grad_x, long long* __restrict__ dbg) {
+  // debug timeline (SBI_AMD_TIMELINE): cycle stamps of workgroup 0's waves while they walk transform T - 2
+#define TSB(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == k.T - 2) \
+    dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
   constexpr int R = 16 * NT;
   constexpr int NZ = (R * 16 + 64 * CO_WAVES - 1) / (64 * CO_WAVES);   // state values per thread (theta-dim <= 16)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6;
   const LaneId id = make_lane();
-  const int D = pl.D, C = pl.C, ZS = cp.ZS, RS = cp.RS, NB = pl.NB;
-  float* zs = lds + cp.o_zs;
-  float* gys = lds + cp.o_gys;
-  float* gzs = lds + cp.o_gzs;
-  float* wrow = lds + cp.o_w;
-  float* pst = lds + cp.o_pst;
-  float* ex = lds + cp.o_ex;
-  float* GT0 = lds + cp.o_gt;
+  const int D = k.D, C = k.C, H = k.H, ZS = k.ZS, RS = k.RS, NB = k.NB;
+  float* zs = lds + k.o_zs;
+  float* gys = lds + k.o_gys;
+  float* gzs = lds + k.o_gzs;
+  float* wrow = lds + k.o_w;
+  float* pst = lds + k.o_pst;
+  float* ex = lds + k.o_ex;
+  float* GT0 = lds + k.o_gt;
   float* GT1 = GT0 + 64 * RS;
-  float* AT0 = lds + cp.o_at;
+  float* AT0 = lds + k.o_at;
   float* AT1 = AT0 + 65 * RS;
-  float* CT = lds + cp.o_ct;
-  float* GUT = lds + cp.o_lut;
+  float* CT = lds + k.o_ct;
+  float* GUT = lds + k.o_lut;
   float* GZT = GUT + 17 * RS;
   float* YT = GZT + 17 * RS;
   float* UTt = YT + 17 * RS;
-  float* ctx = lds + cp.o_ctx;
+  float* ctx = lds + k.o_ctx;
   const long long row0 = (long long)blockIdx.x * R;
   const long long nt16 = (n + 15) / 16;
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
-  const bool hb64 = pl.H == 64;
-  const int ones_h = hb64 ? -1 : pl.H;
+  const bool hb64 = H == 64;
+  const int ones_h = hb64 ? -1 : H;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const bool want_gx = grad_x != nullptr;
-  // clamped stash tiles: wave-tiles past the last row were never written by the forward pass
-  long long t16c[NT];
+  const int ntc = k.ntc, nnh = k.nnh;
+  const int blk_tiles = 4 * ntc + 8 * nnh;          // slab tiles of one residual block: d Wc | d W1 | d W2
+  const bool out_ok = 16 * wave + id.j < H;         // this lane's output feature of a hidden-width layer exists
+  // stash addresses of this wave's fragments (clamped tiles: wave-tiles past the last row were never written by the
+  // forward pass): slot s of transform t, row tile u is abase[u] + t * astride + s * 256
+  const float* abase[NT];
+  const long long astride = nt16 * k.slots * 256;
 #pragma unroll
-  for (int u = 0; u < NT; ++u) t16c[u] = (row0 >> 4) + u < nt16 ? (row0 >> 4) + u : nt16 - 1;
-  auto slot_at = [&](int t, int u, int sl) -> f4 {
-    return *(reinterpret_cast<const f4*>(ast + (((long long)t * nt16 + t16c[u]) * cp.slots + sl) * 256) + id.lane);
-  };
+  for (int u = 0; u < NT; ++u) {
+    const long long t16 = (row0 >> 4) + u < nt16 ? (row0 >> 4) + u : nt16 - 1;
+    abase[u] = ast + t16 * k.slots * 256 + 4 * id.lane;
+  }
   // What a transform needs FIRST is requested a transform ahead (for t = T - 1: before the prologue touches LDS):
   // its input state rows, its spline-parameter tiles, LULinear's factors.
   float zin[NZ];
   f4 ptile[4][NT];
   f4 a_lt, a_ut, a_u;
   auto request_entry = [&](int t) {
-    const CoShape& c = cp.sh[t & 1];
-    const float* img = cimg + (long long)t * cp.img_floats;
+    const CoKP& kq = k.p[t & 1];
+    const float* img = cimg + (long long)t * k.img_floats;
 #pragma unroll
     for (int q = 0; q < NZ; ++q) {
       const int i = tid + 64 * CO_WAVES * q;
@@ -680,19 +737,18 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int mt = wave + CO_WAVES * i;
-      if (mt < c.nft) {
+      const int mt = wave + CO_WAVES * i < kq.nft ? wave + CO_WAVES * i : kq.nft - 1;    // clamped: straight-line
 #pragma unroll
-        for (int u = 0; u < NT; ++u) ptile[i][u] = slot_at(t, u, cp.s_par + mt);
-      }
+      for (int u = 0; u < NT; ++u)
+        ptile[i][u] = *reinterpret_cast<const f4*>(abase[u] + t * astride + (k.s_par + mt) * 256);
     }
-    a_lt = *(reinterpret_cast<const f4*>(img + c.LT.off) + id.lane);
-    a_ut = *(reinterpret_cast<const f4*>(img + c.UT.off) + id.lane);
-    a_u = *(reinterpret_cast<const f4*>(img + c.U.off) + id.lane);
+    a_lt = *(reinterpret_cast<const f4*>(img + kq.lt) + id.lane);
+    a_ut = *(reinterpret_cast<const f4*>(img + kq.ut) + id.lane);
+    a_u = *(reinterpret_cast<const f4*>(img + kq.u) + id.lane);
   };
-  request_entry(pl.T - 1);
+  request_entry(k.T - 1);
 
-  for (int i = tid; i < cp.o_w - cp.o_zs; i += 64 * CO_WAVES) lds[cp.o_zs + i] = 0.f;   // state rows incl. padding
+  for (int i = tid; i < k.o_w - k.o_zs; i += 64 * CO_WAVES) lds[k.o_zs + i] = 0.f;   // state rows incl. padding
   if (tid < R) {
     const long long row = row0 + tid;
     wrow[tid] = row < n ? (row_w ? row_w[row] : uni_w) : 0.f;
@@ -718,25 +774,30 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
   for (int u = 0; u < NT; ++u) gxacc[u] = zero4;
   __syncthreads();
 
-  for (int t = pl.T - 1; t >= 0; --t) {
+  for (int t = k.T - 1; t >= 0; --t) {
     const int par = t & 1;
-    const ShapeDesc& S = pl.shape[par];
-    const CoShape& c = cp.sh[par];
-    const float* img = cimg + (long long)t * cp.img_floats;
-    float* part = partial + ((long long)t * gridDim.x + blockIdx.x) * cp.PLP;
-    const LinDesc& LF = S.lin[S.fin];
+    const CoKP& kp = k.p[par];
+    const float* img = cimg + (long long)t * k.img_floats;
+    float* part = (k.ablate & 32768) ? nullptr : partial + ((long long)t * gridDim.x + blockIdx.x) * k.PLP;
+    const int tb_blk0 = 4 * kp.nnt0;                 // slab tile bases: d W0 | blocks | d Wf | LULinear tail
+    const int tb_wf = tb_blk0 + NB * blk_tiles;
+    TSB(0);
     // ---- requests whose results are needed after the spline: h_last, Wf^T, the last block's stash, the first two
     //      transposed hidden matrices
     struct BSt { f4 t1[NT], t2[NT], sg[NT], hb[NT]; };   // a block's stash: t1 (pre-relu), t2, sigmoid(gate), input
     f4 hl[NT], wft[8][PT], T[3][4];
     BSt B[2];
+    const float* at[NT];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) hl[u] = slot_at(t, u, cp.s_blk + 16 * (NB - 1) + 12 + wave);
+    for (int u = 0; u < NT; ++u) {
+      at[u] = abase[u] + t * astride + wave * 256;
+      hl[u] = *reinterpret_cast<const f4*>(at[u] + (k.s_blk + 16 * (NB - 1) + 12) * 256);
+    }
     {
-      const f4* ap = reinterpret_cast<const f4*>(img + c.WFT.off + wave * c.WFT.quads * 256) + id.lane;
+      const f4* ap = reinterpret_cast<const f4*>(img + kp.wft + wave * kp.d_tr * PT * 256) + id.lane;
 #pragma unroll
       for (int dd = 0; dd < 8; ++dd)
-        if (dd < S.d_tr) {
+        if (dd < kp.d_tr) {
 #pragma unroll
           for (int q = 0; q < PT; ++q) wft[dd][q] = ap[(dd * PT + q) * 64];
         }
@@ -744,15 +805,22 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
     auto request_block = [&](int b, BSt& st) {
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
-        st.t1[u] = slot_at(t, u, cp.s_blk + 16 * b + wave);
-        st.t2[u] = slot_at(t, u, cp.s_blk + 16 * b + 4 + wave);
-        st.sg[u] = slot_at(t, u, cp.s_blk + 16 * b + 8 + wave);
-        st.hb[u] = slot_at(t, u, b == 0 ? wave : cp.s_blk + 16 * (b - 1) + 12 + wave);
+        const float* a = at[u] + (k.s_blk + 16 * b) * 256;
+        st.t1[u] = *reinterpret_cast<const f4*>(a);
+        st.t2[u] = *reinterpret_cast<const f4*>(a + 4 * 256);
+        st.sg[u] = *reinterpret_cast<const f4*>(a + 8 * 256);
+        st.hb[u] = *reinterpret_cast<const f4*>(b == 0 ? at[u] : a - 4 * 256);     // h_0 (slot 0) or h_b of block b - 1
       }
     };
+    auto load_tset = [&](auto kc, f4 (&a)[4]) {      // transposed hidden matrix of backward stage ks (clamped)
+      constexpr int ks = decltype(kc)::value;
+      const int b = NB - 1 - (ks >> 1) > 0 ? NB - 1 - (ks >> 1) : 0;
+      co_load_a<4>(img + ((ks & 1) ? kp.w1t0 : kp.w2t0) + b * k.sT + wave * 1024, id.lane, a);
+    };
     request_block(NB - 1, B[0]);
-    co_load_tset<0>(img, c, NB, wave, id.lane, T[0]);
-    co_load_tset<1>(img, c, NB, wave, id.lane, T[1]);
+    load_tset(CoIdx<0>{}, T[0]);
+    load_tset(CoIdx<1>{}, T[1]);
+    TSB(1);
     // ---- P0: state rows + conditioner-input tile (from the registers requested a transform ago), spline
     //      parameters -> LDS; LULinear backward
 #pragma unroll
@@ -764,20 +832,20 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         if ((d & 1) == (1 - par)) CT[(d >> 1) * RS + r] = zin[q];     // identity feature k = (d - (1 - par)) / 2
       }
     }
-    for (int i = tid; i < (cp.ct_rows - S.d_id) * R; i += 64 * CO_WAVES) {
-      const int k = S.d_id + i / R, r = i % R;
-      CT[k * RS + r] = k < S.in0 ? ctx[(k - S.d_id) * R + r] : (k == S.in0 ? 1.f : 0.f);
+    for (int i = tid; i < (k.ct_rows - kp.d_id) * R; i += 64 * CO_WAVES) {
+      const int kk = kp.d_id + i / R, r = i % R;
+      CT[kk * RS + r] = kk < kp.in0 ? ctx[(kk - kp.d_id) * R + r] : (kk == kp.in0 ? 1.f : 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mt = wave + CO_WAVES * i;
-      if (mt < c.nft) {
+      if (mt < kp.nft) {
         const int dd = mt / PT, pt = mt - dd * PT;
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            pst[(16 * u + id.j) * cp.DSTR + dd * cp.PSW + 16 * pt + 4 * r + id.g] = ptile[i][u][r];
+            pst[(16 * u + id.j) * k.DSTR + dd * k.PSW + 16 * pt + 4 * r + id.g] = ptile[i][u][r];
       }
     }
     if (wave < NT) {   // g_u = L^T g_z, g_y = U^T g_u for row tile `wave`
@@ -799,18 +867,20 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         GZT[d * RS + 16 * u + id.j] = gz[r];
       }
     }
+    TSB(2);
     __syncthreads();
+    TSB(3);
     // ---- P1: spline forward + reverse mode; the parameter rows become d loss / d(raw conditioner outputs)
     {
       const int slt = id.g & 1, sp = id.g >> 1;
       const int dd = 2 * wave + slt;
-      if (dd < S.d_tr) {
+      if (dd < kp.d_tr) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           const int r = 16 * u + id.j;
           const int zi = r * ZS + 2 * dd + par;
           float yv, gxv;
-          rq_spline_pair_bwd<K>(pst + r * cp.DSTR + dd * cp.PSW, 16 * PT, zs[zi], gys[zi], -wrow[r], pl, sp, yv, gxv);
+          rq_spline_pair_bwd<K>(pst + r * k.DSTR + dd * k.PSW, 16 * PT, zs[zi], gys[zi], -wrow[r], k, sp, yv, gxv);
           if (sp == 0) {
             zs[zi] = yv;
             gys[zi] = gxv;
@@ -818,7 +888,9 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         }
       }
     }
+    TSB(4);
     __syncthreads();
+    TSB(5);
     // ---- P2: u = U y (LU parameter gradients), h_last -> activation tile, g_h = Wf^T g_p (m-tile = wave)
     if (wave < NT) {
       const int u = wave;
@@ -840,14 +912,14 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
       for (int u = 0; u < NT; ++u) { acc0[u] = zero4; acc1[u] = zero4; }
 #pragma unroll
       for (int dd = 0; dd < 8; ++dd) {
-        if (dd < S.d_tr) {
+        if (dd < kp.d_tr) {
 #pragma unroll
           for (int q = 0; q < PT; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
               for (int u = 0; u < NT; ++u) {
-                const float bv = pst[(16 * u + id.j) * cp.DSTR + dd * cp.PSW + 16 * q + 4 * r + id.g];
+                const float bv = pst[(16 * u + id.j) * k.DSTR + dd * k.PSW + 16 * q + 4 * r + id.g];
                 if ((dd * PT + q) & 1) acc1[u] = MFMA16(wft[dd][q][r], bv, acc1[u]);
                 else acc0[u] = MFMA16(wft[dd][q][r], bv, acc0[u]);
               }
@@ -858,53 +930,43 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) gh[u][r] = acc0[u][r] + acc1[u][r];
     }
+    TSB(6);
     __syncthreads();
+    TSB(7);
     // ---- d Wf (parameter tiles wave, wave + 4, ...), LULinear parameter gradients
-#pragma unroll 1
-    for (int mt = wave; mt < c.nft; mt += CO_WAVES) {
-      const int dd = mt / PT, pt = mt - dd * PT;
-      f4 acc[4], accb = zero4;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = zero4;
+    for (int i = 0; i < 4; ++i) {
+      const int mt = wave + CO_WAVES * i;
+      if (mt < kp.nft) {
+        const int dd = mt / PT, pt = mt - dd * PT;
+        f4 acc[4], accb = zero4;
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        float bv[4];    // B side = g_p: parameter 16 pt + j of rows 16 u + 4 g + s
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = zero4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[s] = pst[(16 * u + 4 * id.g + s) * cp.DSTR + dd * cp.PSW + 16 * pt + id.j];
+        for (int u = 0; u < NT; ++u) {
+          float bv[4];    // B side = g_p: parameter 16 pt + j of rows 16 u + 4 g + s
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const f4 a = *reinterpret_cast<const f4*>(AT0 + (16 * nt + id.j) * RS + 16 * u + 4 * id.g);
+          for (int s = 0; s < 4; ++s) bv[s] = pst[(16 * u + 4 * id.g + s) * k.DSTR + dd * k.PSW + 16 * pt + id.j];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[nt] = MFMA16(a[s], bv[s], acc[nt]);
-        }
-        if (hb64) {
+          for (int nt = 0; nt < 4; ++nt) {
+            const f4 a = *reinterpret_cast<const f4*>(AT0 + (16 * nt + id.j) * RS + 16 * u + 4 * id.g);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) accb = MFMA16(1.f, bv[s], accb);
-        }
-      }
-      const int p = 16 * pt + id.j;
-      if (p < pl.P) {
-        const int out = dd * pl.P + p;
-        float* w = part + LF.g_w + out * LF.in;
+            for (int s = 0; s < 4; ++s) acc[nt] = MFMA16(a[s], bv[s], acc[nt]);
+          }
+          if (hb64) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int in = 16 * nt + 4 * id.g;
-          if (in + 3 < LF.in) {
-            *reinterpret_cast<f4u*>(w + in) = f4u{acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (in + r < LF.in) w[in + r] = acc[nt][r];
-              else if (in + r == LF.in) part[LF.g_b + out] = acc[nt][r];
-            }
+            for (int s = 0; s < 4; ++s) accb = MFMA16(1.f, bv[s], accb);
           }
         }
-        if (hb64 && id.g == 0) part[LF.g_b + out] = accb[0];
+        const bool p_ok = 16 * pt + id.j < k.P;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) co_write_tile(part, tb_wf + mt * nnh + nt, p_ok, nt, H, id, acc[nt]);
+        if (hb64) co_write_tile(part, tb_wf + mt * nnh + 4, p_ok, 4, H, id, accb);
       }
     }
-    {
+    if (part) {
       const int ntri = D * (D - 1) / 2;
-      float* plow = part + S.g_lu;
+      float* plow = part + kp.dw_tail;
       float* pup = plow + ntri;
       float* pdiag = pup + ntri;
       float* pbias = pdiag + D;
@@ -913,13 +975,13 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         co_dw<NT, 1>(wave == 0 ? GUT : GZT, wave == 0 ? YT : UTt, RS, 0, 0, 1, id, acc, nullptr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = id.j, k = 4 * id.g + r;
-          if (i < D && k < D) {
+          const int i = id.j, kk = 4 * id.g + r;
+          if (i < D && kk < D) {
             if (wave == 0) {
-              if (k > i) pup[i * D - i * (i + 1) / 2 + (k - i - 1)] = acc[0][r];
-              else if (k == i) pdiag[i] = acc[0][r];     // dL/dU_ii; chain rule finished in the reduction
-            } else if (k < i) {
-              plow[i * (i - 1) / 2 + k] = acc[0][r];
+              if (kk > i) pup[i * D - i * (i + 1) / 2 + (kk - i - 1)] = acc[0][r];
+              else if (kk == i) pdiag[i] = acc[0][r];     // dL/dU_ii; chain rule finished in the reduction
+            } else if (kk < i) {
+              plow[i * (i - 1) / 2 + kk] = acc[0][r];
             }
           }
         }
@@ -931,18 +993,21 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         } else if (id.lane == 63) {   // sum_n d loss / d logabsdet_n = - sum_n w_n
           float a = 0.f;
           for (int r = 0; r < R; ++r) a -= wrow[r];
-          part[S.n_params] = a;
+          plow[D * (D - 1) + 2 * D] = a;
         }
       }
     }
+    TSB(8);
     // the transform below: its state rows, parameter tiles and LU factors land under this transform's block phase
     if (t > 0) request_entry(t - 1);
+    TSB(9);
     // ---- residual blocks, last -> first, unrolled at compile time over the execution ordinal i (block b = NB-1-i):
     //      stage 2 i is W2_b^T, stage 2 i + 1 is W1_b^T; transposed matrices two stages ahead, the stash one block ahead
     f4 a0t[4];     // W0^T (identity columns), wave 0
     auto block = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int b = NB - 1 - i;
+      const int tb_c = tb_blk0 + b * blk_tiles, tb_1 = tb_c + 4 * ntc, tb_2 = tb_1 + 4 * nnh;
       BSt& cur = B[i & 1];
       f4 ga[NT], gc[NT];
 #pragma unroll
@@ -953,9 +1018,9 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
           ga[u][r] = gh[u][r] * sg;                                     // d t2
           gc[u][r] = gh[u][r] * cur.t2[u][r] * sg * (1.f - sg);         // d (Wc c + bc)
         }
-      co_load_tset<2 * i + 2>(img, c, NB, wave, id.lane, T[(2 * i + 2) % 3]);
+      load_tset(CoIdx<2 * i + 2>{}, T[(2 * i + 2) % 3]);
       request_block(b > 0 ? b - 1 : 0, B[(i + 1) & 1]);
-      if (b == 0) co_load_a<4>(img, c.W0T, 0, id.lane, a0t);
+      if (b == 0) co_load_a<4>(img + kp.w0t, id.lane, a0t);
       co_store_T<NT>(GT0, RS, 16 * wave, id, ga, false, -1);
       co_store_T<NT>(GT1, RS, 16 * wave, id, gc, false, -1);
       co_store_T<NT>(AT1, RS, 16 * wave, id, cur.t1, true, ones_h);
@@ -964,39 +1029,44 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         co_gather<NT>(ex, buf, wave, id.lane, gc, bg);
         if (wave * 16 < C) {
           f4 act[4];
-          co_load_a<4>(img, c.WCT[b], wave, id.lane, act);
+          co_load_a<4>(img + kp.wct0 + b * k.sC + wave * 1024, id.lane, act);
           co_gemm_h<NT, KSH>(act, bg, gxacc);
         }
       }
+      TSB(10 + 8 * i);
       co_gather<NT>(ex, buf, wave, id.lane, ga, bg);
+      TSB(11 + 8 * i);
 #pragma unroll
       for (int u = 0; u < NT; ++u) gr[u] = zero4;
       co_gemm_h<NT, KSH>(T[(2 * i) % 3], bg, gr);
+      TSB(12 + 8 * i);
 #pragma unroll
       for (int u = 0; u < NT; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ga[u][r] = cur.t1[u][r] > 0.f ? gr[u][r] : 0.f;     // d t1
-      co_load_tset<2 * i + 3>(img, c, NB, wave, id.lane, T[(2 * i + 3) % 3]);
+      load_tset(CoIdx<2 * i + 3>{}, T[(2 * i + 3) % 3]);
       {
         f4 acc[4], accb;
         co_dw<NT, 4>(GT0, AT1, RS, 16 * wave, 0, 4, id, acc, hb64 ? &accb : nullptr);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) co_write_tile(part, S.lin[3 + 3 * b], 16 * wave, nt, id, acc[nt]);
-        if (hb64) co_write_bias(part, S.lin[3 + 3 * b], 16 * wave, id, accb);
+        for (int nt = 0; nt < 4; ++nt) co_write_tile(part, tb_2 + wave * nnh + nt, out_ok, nt, H, id, acc[nt]);
+        if (hb64) co_write_tile(part, tb_2 + wave * nnh + 4, out_ok, 4, H, id, accb);
         f4 accc[3];       // x-dim <= 32 plus the bias column: up to three n-tiles
-        const int ntc = (C + 1 + 15) / 16;
-        co_dw<NT, 3>(GT1, CT, RS, 16 * wave, S.d_id, ntc, id, accc, nullptr);
+        co_dw<NT, 3>(GT1, CT, RS, 16 * wave, kp.d_id, ntc, id, accc, nullptr);
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
-          if (nt < ntc) co_write_tile(part, S.lin[1 + 3 * b], 16 * wave, nt, id, accc[nt]);
+          if (nt < ntc) co_write_tile(part, tb_c + wave * ntc + nt, out_ok, nt, C, id, accc[nt]);
       }
       wave_lds_fence();
+      TSB(13 + 8 * i);
       co_store_T<NT>(GT0, RS, 16 * wave, id, ga, false, -1);
       co_store_T<NT>(AT0, RS, 16 * wave, id, cur.hb, true, ones_h);
       co_gather<NT>(ex, buf, wave, id.lane, ga, bg);
+      TSB(14 + 8 * i);
 #pragma unroll
       for (int u = 0; u < NT; ++u) gr[u] = zero4;
       co_gemm_h<NT, KSH>(T[(2 * i + 1) % 3], bg, gr);
+      TSB(15 + 8 * i);
 #pragma unroll
       for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -1005,10 +1075,11 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         f4 acc[4], accb;
         co_dw<NT, 4>(GT0, AT0, RS, 16 * wave, 0, 4, id, acc, hb64 ? &accb : nullptr);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) co_write_tile(part, S.lin[2 + 3 * b], 16 * wave, nt, id, acc[nt]);
-        if (hb64) co_write_bias(part, S.lin[2 + 3 * b], 16 * wave, id, accb);
+        for (int nt = 0; nt < 4; ++nt) co_write_tile(part, tb_1 + wave * nnh + nt, out_ok, nt, H, id, acc[nt]);
+        if (hb64) co_write_tile(part, tb_1 + wave * nnh + 4, out_ok, 4, H, id, accb);
       }
       wave_lds_fence();
+      TSB(16 + 8 * i);
       // (AT0 / AT1 are re-written only after the next barrier: no reader of this block is still on them)
     };
     block(CoIdx<0>{});
@@ -1020,6 +1091,7 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
       co_store_T<NT>(GT0, RS, 16 * wave, id, gh, false, -1);
       f4 bg[NT][CO_WAVES];
       co_gather<NT>(ex, buf, wave, id.lane, gh, bg);
+      TSB(50);
       if (wave == 0) {      // identity features receive W0[:, :d_id]^T g_h0
         f4 gin[NT];
 #pragma unroll
@@ -1029,23 +1101,24 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
         for (int u = 0; u < NT; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = 4 * r + id.g;
-            if (k < S.d_id) gys[(16 * u + id.j) * ZS + 2 * k + (1 - par)] += gin[u][r];
+            const int kk = 4 * r + id.g;
+            if (kk < kp.d_id) gys[(16 * u + id.j) * ZS + 2 * kk + (1 - par)] += gin[u][r];
           }
       }
       if (want_gx && wave * 16 < C) {
         f4 act[4];
-        co_load_a<4>(img, c.W0CT, wave, id.lane, act);
+        co_load_a<4>(img + kp.w0ct + wave * 1024, id.lane, act);
         co_gemm_h<NT, KSH>(act, bg, gxacc);
       }
       f4 acc[3];
-      const int nt0 = (S.in0 + 1 + 15) / 16;
-      co_dw<NT, 3>(GT0, CT, RS, 16 * wave, 0, nt0, id, acc, nullptr);
+      co_dw<NT, 3>(GT0, CT, RS, 16 * wave, 0, kp.nnt0, id, acc, nullptr);
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt)
-        if (nt < nt0) co_write_tile(part, S.lin[0], 16 * wave, nt, id, acc[nt]);
+        if (nt < kp.nnt0) co_write_tile(part, wave * kp.nnt0 + nt, out_ok, nt, kp.in0, id, acc[nt]);
     }
+    TSB(51);
     __syncthreads();
+    TSB(52);
     // gradient wrt this transform's input becomes the upstream gradient of the transform below
     if (t > 0) {
       float* tmp = gzs;
@@ -1058,6 +1131,7 @@ nsf_coop_bwd_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict
       }
     }
   }
+#undef TSB
   if (want_gx && wave * 16 < C) {      // through the kernel's own z-scoring: d c / d x = 1 / std
 #pragma unroll
     for (int u = 0; u < NT; ++u)
@@ -1084,37 +1158,42 @@ struct CoBwdArgs {
   float uni_w;
   const float *z_last, *zst, *ast;
   float *partial, *grad_theta, *grad_x;
+  long long* dbg;
 };
 
 template <int K, int KSH, int NT>
-static int co_launch_fwd(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
+static int co_launch_fwd(const CoK& k, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
   auto kern = nsf_coop_fwd_kernel<K, KSH, NT>;
   const int lds_bytes = 4 * cp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(cp.grid), dim3(64 * CO_WAVES), (size_t)lds_bytes, st, pl, cp, a.cimg, a.zstats, a.theta,
-                     a.x, a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast, a.dbg);
+  hipLaunchKernelGGL(kern, dim3(cp.grid), dim3(64 * CO_WAVES), (size_t)lds_bytes, st, k, a.cimg, a.zstats, a.theta, a.x,
+                     a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast, a.dbg);
   return (int)hipGetLastError();
 }
 template <int K, int KSH, int NT>
-static int co_launch_bwd(const NsfPlan& pl, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {
+static int co_launch_bwd(const CoK& k, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {
   auto kern = nsf_coop_bwd_kernel<K, KSH, NT>;
   const int lds_bytes = 4 * cp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(cp.grid), dim3(64 * CO_WAVES), (size_t)lds_bytes, st, pl, cp, a.cimg, a.zstats, a.x, a.n,
-                     a.x_rows, a.row_w, a.uni_w, a.z_last, a.zst, a.ast, a.partial, a.grad_theta, a.grad_x);
+  hipLaunchKernelGGL(kern, dim3(cp.grid), dim3(64 * CO_WAVES), (size_t)lds_bytes, st, k, a.cimg, a.zstats, a.x, a.n,
+                     a.x_rows, a.row_w, a.uni_w, a.z_last, a.zst, a.ast, a.partial, a.grad_theta, a.grad_x, a.dbg);
   return (int)hipGetLastError();
 }
 
 // one translation unit per bin count (parallel build): nsf_coop.hip holds K = 10, nsf_coop_k{4,5,8,16}.hip the rest
 template <int K>
 int co_fwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
-  if (pl.KSH == 13) return cp.NT == 2 ? co_launch_fwd<K, 13, 2>(pl, cp, a, st) : co_launch_fwd<K, 13, 1>(pl, cp, a, st);
-  return cp.NT == 2 ? co_launch_fwd<K, 16, 2>(pl, cp, a, st) : co_launch_fwd<K, 16, 1>(pl, cp, a, st);
+  CoK k;
+  coop_make_consts(pl, cp, &k);
+  if (pl.KSH == 13) return cp.NT == 2 ? co_launch_fwd<K, 13, 2>(k, cp, a, st) : co_launch_fwd<K, 13, 1>(k, cp, a, st);
+  return cp.NT == 2 ? co_launch_fwd<K, 16, 2>(k, cp, a, st) : co_launch_fwd<K, 16, 1>(k, cp, a, st);
 }
 template <int K>
 int co_bwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {
-  if (pl.KSH == 13) return cp.NT == 2 ? co_launch_bwd<K, 13, 2>(pl, cp, a, st) : co_launch_bwd<K, 13, 1>(pl, cp, a, st);
-  return cp.NT == 2 ? co_launch_bwd<K, 16, 2>(pl, cp, a, st) : co_launch_bwd<K, 16, 1>(pl, cp, a, st);
+  CoK k;
+  coop_make_consts(pl, cp, &k);
+  if (pl.KSH == 13) return cp.NT == 2 ? co_launch_bwd<K, 13, 2>(k, cp, a, st) : co_launch_bwd<K, 13, 1>(k, cp, a, st);
+  return cp.NT == 2 ? co_launch_bwd<K, 16, 2>(k, cp, a, st) : co_launch_bwd<K, 16, 1>(k, cp, a, st);
 }

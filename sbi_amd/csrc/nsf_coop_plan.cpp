@@ -43,7 +43,7 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   if (pl.ctx_mlp || pl.D < 2 || pl.D > 16 || pl.C > 32 || pl.H > 64 || pl.NB < 1 || pl.NB > NSF_MAX_NB)
     return SBI_AMD_E_UNSUPPORTED;
   const int HQ = (pl.KSH + 3) / 4;     // K-quads of a hidden-K layer (13 or 16 K-steps)
-  int img = 0;
+  int img = 0, plp = 0;
   for (int par = 0; par < 2; ++par) {
     const ShapeDesc& S = pl.shape[par];
     CoShape& c = cp->sh[par];
@@ -82,8 +82,21 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
     o += 4;
     o = round_up_i(o, 256);
     if (o > img) img = o;
+    // partial-slab tiles: every linear with ceil((in + 1) / 16) n-tiles per m-tile (the bias is input index `in`)
+    int tb = 0;
+    for (int k = 0; k <= S.fin; ++k) {
+      const LinDesc& L = S.lin[k];
+      const int mts = k == S.fin ? c.nft : NSF_HT;
+      c.dw_tb[k] = tb;
+      c.dw_nnt[k] = (L.in + 1 + 15) / 16;
+      tb += mts * c.dw_nnt[k];
+    }
+    c.dw_tail = tb * 256;
+    const int slab = round_up_i(c.dw_tail + pl.D * (pl.D - 1) + 2 * pl.D + 1, 64);
+    if (slab > plp) plp = slab;
   }
   cp->img_floats = img;
+  cp->PLP = plp;
 
   // rows per workgroup: one 16-row tile while that still gives every CU at most two workgroups' worth of partial
   // slabs; two tiles per workgroup beyond (the A operands are then shared by both, the slabs halve)
@@ -125,7 +138,41 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   cp->lds_floats = round_up_i(o, 4);
   if (4ll * cp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
   cp->grid = (int)((n + cp->R - 1) / cp->R);
-  int pmax = pl.shape[0].n_params > pl.shape[1].n_params ? pl.shape[0].n_params : pl.shape[1].n_params;
-  cp->PLP = (pmax + 1 + 3) / 4 * 4;
   return 0;
+}
+
+void coop_make_consts(const NsfPlan& pl, const CoopPlan& cp, CoK* k) {
+  memset(k, 0, sizeof(*k));
+  k->D = pl.D; k->C = pl.C; k->H = pl.H; k->NB = pl.NB; k->T = pl.T; k->P = pl.P;
+  k->KCQ = cp.sh[0].KCQ;
+  const CoShape& c0 = cp.sh[0];
+  k->sA = pl.NB > 1 ? c0.W1[1].off - c0.W1[0].off : 0;
+  k->sT = pl.NB > 1 ? c0.W1T[1].off - c0.W1T[0].off : 0;
+  k->sC = pl.NB > 1 ? c0.WCT[1].off - c0.WCT[0].off : 0;
+  k->sB = pl.NB > 1 ? c0.b1[1].off - c0.b1[0].off : 0;
+  k->img_floats = cp.img_floats;
+  k->ZS = cp.ZS; k->RS = cp.RS; k->PSW = cp.PSW; k->DSTR = cp.DSTR;
+  k->o_zs = cp.o_zs; k->o_gys = cp.o_gys; k->o_gzs = cp.o_gzs; k->o_w = cp.o_w; k->o_pst = cp.o_pst;
+  k->o_ex = cp.o_ex; k->o_ldp = cp.o_ldp; k->o_gt = cp.o_gt; k->o_at = cp.o_at; k->o_ct = cp.o_ct;
+  k->o_lut = cp.o_lut; k->o_ctx = cp.o_ctx; k->ct_rows = cp.ct_rows;
+  k->slots = cp.slots; k->s_blk = cp.s_blk; k->s_par = cp.s_par;
+  k->PLP = cp.PLP;
+  k->ntc = (pl.C + 1 + 15) / 16;
+  k->nnh = (pl.H + 1 + 15) / 16;
+  k->ablate = pl.ablate;
+  k->B = pl.B; k->min_w = pl.min_w; k->min_h = pl.min_h; k->min_d = pl.min_d; k->inv_sqrt_h = pl.inv_sqrt_h;
+  k->one_minus_kw = pl.one_minus_kw; k->one_minus_kh = pl.one_minus_kh; k->d_const = pl.d_const; k->log_z = pl.log_z;
+  for (int par = 0; par < 2; ++par) {
+    const ShapeDesc& S = pl.shape[par];
+    const CoShape& c = cp.sh[par];
+    CoKP& q = k->p[par];
+    q.d_id = S.d_id; q.d_tr = S.d_tr; q.in0 = S.in0; q.nft = c.nft;
+    q.nnt0 = (S.in0 + 1 + 15) / 16;
+    q.dw_tail = c.dw_tail;
+    q.w0 = c.W0.off; q.wc0 = c.WC[0].off; q.w10 = c.W1[0].off; q.w20 = c.W2[0].off; q.wf = c.WF.off;
+    q.u = c.U.off; q.l = c.L.off; q.wft = c.WFT.off; q.w1t0 = c.W1T[0].off; q.w2t0 = c.W2T[0].off;
+    q.w0t = c.W0T.off; q.ut = c.UT.off; q.lt = c.LT.off; q.wct0 = c.WCT[0].off; q.w0ct = c.W0CT.off;
+    q.b0 = c.b0.off; q.bc0 = c.bc[0].off; q.b10 = c.b1[0].off; q.b20 = c.b2[0].off; q.bf = c.bf.off;
+    q.blu = c.blu.off; q.ld = c.o_ld;
+  }
 }

@@ -483,20 +483,22 @@ struct NoYield {
 // The rational-quadratic map, its inverse and its log-derivative are the same function of (knots, slopes).
 #define ZUKO_CW 0.28952965460216784f   /* 2 / |ln 1e-3| */
 #define ZUKO_CD 0.14476482730108392f   /* 1 / |ln 1e-3| */
-template <int VAR>
-__device__ __forceinline__ float spline_logit(float q, const NsfPlan& pl) {
+// (PL: any struct with the spline constants B, min_w, min_h, min_d, inv_sqrt_h, one_minus_kw, one_minus_kh, d_const --
+//  NsfPlan, or the compact kernel-constant block of the cooperative kernels)
+template <int VAR, class PL>
+__device__ __forceinline__ float spline_logit(float q, const PL& pl) {
   return VAR == 0 ? q * pl.inv_sqrt_h : q * rcp_f(1.f + fabsf(q) * ZUKO_CW);
 }
 // d logit' / d logit
-template <int VAR>
-__device__ __forceinline__ float spline_logit_grad(float q, const NsfPlan& pl) {
+template <int VAR, class PL>
+__device__ __forceinline__ float spline_logit_grad(float q, const PL& pl) {
   if (VAR == 0) return pl.inv_sqrt_h;
   const float r = rcp_f(1.f + fabsf(q) * ZUKO_CW);
   return r * r;
 }
 
-template <int K, class Y = NoYield, int VAR = 0>
-__device__ __forceinline__ void spline_side(const float* __restrict__ q, const NsfPlan& pl, int part,
+template <int K, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
+__device__ __forceinline__ void spline_side(const float* __restrict__ q, const PL& pl, int part,
                                             SplineSide<K>& S, Y&& y = Y()) {
   const float B = pl.B;
   float m = -INFINITY;
@@ -534,8 +536,8 @@ struct SplineSel {   // per-task scalars both lanes hold after the exchange
   float cw_i, cw_n, ch_i, ch_n, d_i, d_n, ud_mine;
 };
 
-template <int K, bool INV, class Y = NoYield, int VAR = 0>
-__device__ __forceinline__ void spline_select(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
+template <int K, bool INV, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
+__device__ __forceinline__ void spline_select(const float* __restrict__ p, float x, const PL& pl, int part,
                                               const SplineSide<K>& S, SplineSel& o, Y&& y = Y()) {
   const float B = pl.B;
   // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6; done by the
@@ -590,8 +592,8 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
 
 // forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
 // receive y and ld.
-template <int K, bool INV, class Y = NoYield, int VAR = 0>
-__device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const NsfPlan& pl, int part,
+template <int K, bool INV, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
+__device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const PL& pl, int part,
                                                float& y, float& ld, Y&& yield = Y()) {
   SplineSide<K> S;
   spline_side<K, Y, VAR>(p + part * K, pl, part, S, static_cast<Y&&>(yield));

@@ -191,19 +191,9 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
     // small batches: ONE cooperative backward launch over all transforms, then the same fixed-order slab reduction.
     // (The workspace was laid out by the cooperative forward: both halves take the same decision from (cfg, n).)
     CoopPlan cp;
-    if (coop_applies(cfg, n, true, &pl, &cp)) {
-      const float *partial = nullptr, *logp = nullptr;
-      int rc = coop_train_backward(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, x, n, x_rows, row_weight,
-                                   uniform_weight, grad_theta_out, grad_x_out, workspace, &partial, &logp, stream);
-      if (rc) return rc;
-      TrainPlan tpc;
-      memset(&tpc, 0, sizeof(tpc));
-      tpc.grid = cp.grid;
-      tpc.PLP = cp.PLP;
-      hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64 * RED_GROUPS), 0,
-                         (hipStream_t)stream, pl, tpc, params, partial, grad_out, logp, loss_out, (long long)n);
-      return (int)hipGetLastError();
-    }
+    if (coop_applies(cfg, n, true, &pl, &cp))
+      return coop_train_backward(cfg, pl, cp, params, packed + nsf_packed_floats(pl), zstats, x, n, x_rows, row_weight,
+                                 uniform_weight, grad_out, grad_theta_out, grad_x_out, loss_out, workspace, stream);
   }
   // (an E_LDS here speaks about the FORWARD kernel's 4-wave layout; the backward kernel has its own budget, checked
   // by build_train_plan, and the training forward picks its workgroup size in nsf_plan_for_rows)

@@ -395,9 +395,9 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
 // d(gy*y + gl*logabsdet)/d(raw outputs) on exit (entries [3K-1, plen) zeroed): part 0 writes the
 // width logits and all derivative slots but one, part 1 the height logits, its own derivative
 // slot and the padding.  Formulas: DESIGN.md "spline backward".
-template <int K, int VAR = 0>
+template <int K, int VAR = 0, class PL = NsfPlan>
 __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int plen, float x, float gy, float gl,
-                                                   const NsfPlan& pl, int part, float& y, float& gx) {
+                                                   const PL& pl, int part, float& y, float& gx) {
   const float B = pl.B;
   SplineSide<K> S;
   spline_side<K, NoYield, VAR>(p + part * K, pl, part, S);
