@@ -159,7 +159,7 @@ int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const 
       }
     }
   }
-  hipLaunchKernelGGL(nsf_coop_reduce_kernel, dim3((cp.PLP + 63) / 64, pl.T), dim3(64 * CO_RED_GROUPS), 0,
+  hipLaunchKernelGGL(nsf_coop_reduce_kernel, dim3((cp.PLP / 4 + 63) / 64, pl.T), dim3(64 * CO_RED_GROUPS), 0,
                      (hipStream_t)stream, pl, cp, params, (const float*)(workspace + o_part), grad_out,
                      (const float*)(workspace + o_logp), loss_out, (long long)n);
   return (int)hipGetLastError();

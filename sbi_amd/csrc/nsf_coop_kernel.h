@@ -158,17 +158,17 @@ nsf_coop_reduce_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restr
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_rows;
          i += (long long)gridDim.x * gridDim.y * blockDim.x)
       loss_out[i] = -logp[i];
-  __shared__ float red[CO_RED_GROUPS][64];
-  __shared__ float red_sgl[CO_RED_GROUPS][64];
+  __shared__ f4 red[CO_RED_GROUPS][64];
+  __shared__ float red_sgl[CO_RED_GROUPS];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int t = blockIdx.y;
   const ShapeDesc& S = pl.shape[t & 1];
   const CoShape& c = cp.sh[t & 1];
-  const int pos = blockIdx.x * 64 + lane;       // word of the slab
+  const int pos = 4 * (blockIdx.x * 64 + lane);       // four consecutive words of the slab: one lane's 16-byte store
   const int D = pl.D, ntri = D * (D - 1) / 2;
-  int li = -1;                                  // parameter (relative to the transform's block) this word belongs to
+  int li[4] = {-1, -1, -1, -1};                       // parameter (relative to the transform's block) of each word
   if (pos < c.dw_tail) {
-    const int tile = pos >> 8, l = (pos >> 2) & 63, r = pos & 3;
+    const int tile = pos >> 8, l = (pos >> 2) & 63;
     int k = 0;
     for (int kk = 1; kk <= S.fin; ++kk) k = tile >= c.dw_tb[kk] ? kk : k;
     const LinDesc& L = S.lin[k];
@@ -180,41 +180,55 @@ nsf_coop_reduce_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restr
       const int dd = mt / pl.PT, p = 16 * (mt - dd * pl.PT) + j;
       out = p < pl.P ? dd * pl.P + p : L.out;
     }
-    const int in = 16 * nt + 4 * g + r;
-    if (out < L.out && in <= L.in) li = in < L.in ? L.g_w + out * L.in + in : L.g_b + out;
-  } else if (pos - c.dw_tail < 2 * ntri + 2 * D) {
-    li = S.g_lu + (pos - c.dw_tail);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int in = 16 * nt + 4 * g + r;
+      if (out < L.out && in <= L.in) li[r] = in < L.in ? L.g_w + out * L.in + in : L.g_b + out;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (pos + r - c.dw_tail < 2 * ntri + 2 * D) li[r] = S.g_lu + (pos + r - c.dw_tail);
   }
-  const bool live = li >= 0;
-  const bool is_diag = live && li >= S.g_lu + 2 * ntri && li < S.g_lu + 2 * ntri + D;
+  const bool live = (li[0] & li[1] & li[2] & li[3]) >= 0 || li[0] >= 0 || li[1] >= 0 || li[2] >= 0 || li[3] >= 0;
   const float* base = partial + (long long)t * cp.grid * cp.PLP;
-  float a = 0.f, sgl = 0.f;
+  f4 a = {0.f, 0.f, 0.f, 0.f};
   if (live) {
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    f4 acc4[4] = {a, a, a, a};
     int w = grp;
     for (; w + 3 * CO_RED_GROUPS < cp.grid; w += 4 * CO_RED_GROUPS) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc4[u] += base[(long long)(w + u * CO_RED_GROUPS) * cp.PLP + pos];
+      for (int u = 0; u < 4; ++u) acc4[u] += *reinterpret_cast<const f4*>(base + (long long)(w + u * CO_RED_GROUPS) * cp.PLP + pos);
     }
-    for (; w < cp.grid; w += CO_RED_GROUPS) acc4[0] += base[(long long)w * cp.PLP + pos];
+    for (; w < cp.grid; w += CO_RED_GROUPS) acc4[0] += *reinterpret_cast<const f4*>(base + (long long)w * cp.PLP + pos);
     a = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-    if (is_diag)
-      for (int w2 = grp; w2 < cp.grid; w2 += CO_RED_GROUPS) sgl += base[(long long)w2 * cp.PLP + c.dw_tail + 2 * ntri + 2 * D];
   }
   red[grp][lane] = a;
-  red_sgl[grp][lane] = sgl;
+  // sum_n d loss / d logabsdet_n (one word per slab): every block needs it only if it holds LU-diagonal words; cheap
+  {
+    float sgl = 0.f;
+    for (int w2 = grp * 64 + lane; w2 < cp.grid; w2 += 64 * CO_RED_GROUPS) sgl += base[(long long)w2 * cp.PLP + c.dw_tail + 2 * ntri + 2 * D];
+    for (int off = 32; off > 0; off >>= 1) sgl += __shfl_xor(sgl, off);
+    if (lane == 0) red_sgl[grp] = sgl;
+  }
   __syncthreads();
   if (grp == 0 && live) {
-    float tot = 0.f, tsg = 0.f;
+    f4 tot = {0.f, 0.f, 0.f, 0.f};
+    float tsg = 0.f;
 #pragma unroll
-    for (int g = 0; g < CO_RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g][lane]; }
-    const int idx = pl.g_layer[t] + li;
-    if (is_diag) {
-      const float ud = params[idx];
-      const float uii = softplus_f(ud) + pl.lu_eps;
-      tot = (tot + tsg / uii) * (1.f / (1.f + expf(-ud)));
+    for (int g = 0; g < CO_RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (li[r] < 0) continue;
+      const int idx = pl.g_layer[t] + li[r];
+      float v = tot[r];
+      if (li[r] >= S.g_lu + 2 * ntri && li[r] < S.g_lu + 2 * ntri + D) {
+        const float ud = params[idx];
+        const float uii = softplus_f(ud) + pl.lu_eps;
+        v = (v + tsg / uii) * (1.f / (1.f + expf(-ud)));
+      }
+      grad[idx] = v;
     }
-    grad[idx] = tot;
   }
 }
 #endif
@@ -511,6 +525,20 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
       }
     }
     TSC(21);
+    // LULinear's factors and the next transform's first weights: requested before the spline (and before the stash
+    // burst enters the in-order memory queue), landed after it
+    const f4 au = *(reinterpret_cast<const f4*>(img + kp.u) + id.lane);
+    const f4 al = *(reinterpret_cast<const f4*>(img + kp.l) + id.lane);
+    const f4 blu = co_load_bias(img + kp.blu, 0, id.g);
+    const float ld_lu = img[kp.ld];
+    {
+      const int tn = t + 1 < k.T ? t + 1 : t;           // (the last transform re-requests itself: harmless)
+      const float* imgn = cimg + (long long)tn * k.img_floats;
+      const CoKP& kn = k.p[tn & 1];
+      co_load_w0(imgn, k, kn, wave, id, w0);
+      co_load_set<0>(imgn, k, kn, wave, id, S[0]);
+      co_load_set<1>(imgn, k, kn, wave, id, S[1]);
+    }
     if (ast) {      // the stash burst (plain stores: the backward workgroup of the same index runs on the same XCD)
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
@@ -530,19 +558,6 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
               *reinterpret_cast<f4*>(ab + (k.s_par + wave + CO_WAVES * i) * 256) = pv[i][u];
         }
       }
-    }
-    // LULinear's factors and the next transform's first weights: requested before the spline, landed after it
-    const f4 au = *(reinterpret_cast<const f4*>(img + kp.u) + id.lane);
-    const f4 al = *(reinterpret_cast<const f4*>(img + kp.l) + id.lane);
-    const f4 blu = co_load_bias(img + kp.blu, 0, id.g);
-    const float ld_lu = img[kp.ld];
-    {
-      const int tn = t + 1 < k.T ? t + 1 : t;           // (the last transform re-requests itself: harmless)
-      const float* imgn = cimg + (long long)tn * k.img_floats;
-      const CoKP& kn = k.p[tn & 1];
-      co_load_w0(imgn, k, kn, wave, id, w0);
-      co_load_set<0>(imgn, k, kn, wave, id, S[0]);
-      co_load_set<1>(imgn, k, kn, wave, id, S[1]);
     }
     __syncthreads();
     TSC(22);
@@ -931,6 +946,9 @@ nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
         for (int r = 0; r < 4; ++r) gh[u][r] = acc0[u][r] + acc1[u][r];
     }
     TSB(6);
+    // the transform below: its state rows, parameter tiles and LU factors are requested BEFORE this transform's
+    // partial-slab stores enter the (in-order) memory queue; they land under the block phase
+    if (t > 0) request_entry(t - 1);
     __syncthreads();
     TSB(7);
     // ---- d Wf (parameter tiles wave, wave + 4, ...), LULinear parameter gradients
@@ -970,14 +988,15 @@ nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
       float* pup = plow + ntri;
       float* pdiag = pup + ntri;
       float* pbias = pdiag + D;
-      if (wave == 0 || wave == 1) {   // d U = g_u (x) y (wave 0), d L = g_z (x) u (wave 1): one 16 x 16 tile each
+      // (on the waves with the fewest final-layer tiles: 10 tiles over four waves is 3, 3, 2, 2)
+      if (wave == 3 || wave == 2) {   // d U = g_u (x) y (wave 3), d L = g_z (x) u (wave 2): one 16 x 16 tile each
         f4 acc[1];
-        co_dw<NT, 1>(wave == 0 ? GUT : GZT, wave == 0 ? YT : UTt, RS, 0, 0, 1, id, acc, nullptr);
+        co_dw<NT, 1>(wave == 3 ? GUT : GZT, wave == 3 ? YT : UTt, RS, 0, 0, 1, id, acc, nullptr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = id.j, kk = 4 * id.g + r;
           if (i < D && kk < D) {
-            if (wave == 0) {
+            if (wave == 3) {
               if (kk > i) pup[i * D - i * (i + 1) / 2 + (kk - i - 1)] = acc[0][r];
               else if (kk == i) pdiag[i] = acc[0][r];     // dL/dU_ii; chain rule finished in the reduction
             } else if (kk < i) {
@@ -985,7 +1004,7 @@ nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
             }
           }
         }
-      } else if (wave == 2) {
+      } else if (wave == 1) {
         if (id.lane < D) {            // d bias = sum_n g_z
           float a = 0.f;
           for (int r = 0; r < R; ++r) a += gzs[r * ZS + id.lane];
@@ -998,9 +1017,6 @@ nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
       }
     }
     TSB(8);
-    // the transform below: its state rows, parameter tiles and LU factors land under this transform's block phase
-    if (t > 0) request_entry(t - 1);
-    TSB(9);
     // ---- residual blocks, last -> first, unrolled at compile time over the execution ordinal i (block b = NB-1-i):
     //      stage 2 i is W2_b^T, stage 2 i + 1 is W1_b^T; transposed matrices two stages ahead, the stash one block ahead
     f4 a0t[4];     // W0^T (identity columns), wave 0
