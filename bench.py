@@ -706,6 +706,26 @@ def main(argv=None):
                           "ms_per_step": wall_s / args.steps * 1e3,
                           "roofline": roofline(F_TRAIN, Bs, args.steps, leg_s.fused_ms(args.steps))}
 
+    small_obj = None
+    if args.mode in ("both", "train") and world == 1 and not distributed:
+        # The latency regime (cooperative kernels, csrc/nsf_coop.h): sbi's default training_batch_size = 200
+        # (npe_base.py:301-316) and the per-GPU share of SURVEY 8(e)'s partitioning -- the 65 536-pair batch split over
+        # 8 GPUs = 8 192 pairs per GPU per step.  Same inner loop as the headline leg (permutation, gather, fused step).
+        small_obj = {}
+        for b in (200, 8192):
+            leg_b = TrainLeg(est, th_all, x_all, b, False, b)
+            ks = 200
+            wall_b, _ = timed(leg_b, ks, 20, device)
+            small_obj[f"batch_{b}"] = {"ms_per_step": wall_b / ks * 1e3, "fused_step_device_ms": leg_b.fused_ms(ks) / ks,
+                                       "value": b * ks / wall_b, "unit": "pairs/s"}
+        small_obj["strong_scaling_8_gpus"] = {
+            "rows_per_gpu": 8192, "fused_step_ms_at_65536_rows": results["train"]["roofline"]["device_ms_per_step"],
+            "fused_step_ms_at_8192_rows": small_obj["batch_8192"]["fused_step_device_ms"],
+            "speedup_bound_before_allreduce": results["train"]["roofline"]["device_ms_per_step"]
+            / small_obj["batch_8192"]["fused_step_device_ms"],
+            "note": "one 65 536-pair step on 1 GPU vs the same step's 8 192-pair share on each of 8 GPUs; the RCCL "
+                    "all-reduce of the 392 KB gradient comes on top (rccl_1rank.allreduce_us_98025_floats)"}
+
     npe_obj = npe_train_leg(device, rank, world, args.npe_epochs) if args.mode == "both" else None
     fm_out = fmpe_leg(args, B, rank, world, device, dist, distributed, GB) if args.mode == "both" else None
     if rank == 0:
@@ -748,6 +768,8 @@ def main(argv=None):
             out["posterior_sample"] = {"metric": "DirectPosterior.sample draws/sec", "value": sp["value"],
                                        "unit": sp["unit"], "draws_per_step": args.draws, "steps": sp["steps"],
                                        "ms_per_step": sp["ms_per_step"], "roofline": sp["roofline"]}
+        if small_obj is not None:
+            out["small_batch"] = small_obj
         if world == 1 and not distributed and head == "train" and not args.no_rccl_leg:
             out["rccl_1rank"] = rccl_one_rank_leg(args, r)
         if npe_obj is not None:
