@@ -9,20 +9,50 @@
 // (SURVEY.md 3.2, Appendix A).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "nsf_device.h"
+#include "nsf_plan_layout.h"
 #include "debug_env.h"
+
+// ---- the benchmark configuration's layout as compile-time constants (see nsf_train_kernel.h, kStaticPl, for why): the
+// SP instantiations take every offset / stride / count from these and only the floating-point constants and debug
+// switches from the kernel argument.  One static plan per workgroup shape: 8 waves (density direction at >= 32 768
+// rows), 12 waves (sampling direction at >= 49 152 rows).
+constexpr sbi_amd_nsf_config kFlowDefaultCfg = {10, 10, 50, 10, 5, 2, 3.0f, 1e-3f, 1e-3f, 1e-3f, 1e-3f};
+constexpr NsfPlan nsf_make_static_flow_plan(int nw) {
+  NsfPlan p{};
+  nsf_build_layout(&kFlowDefaultCfg, nw, &p);
+  return p;
+}
+constexpr NsfPlan kStaticFlow8 = nsf_make_static_flow_plan(8);
+constexpr NsfPlan kStaticFlow12 = nsf_make_static_flow_plan(12);
+template <int P_>
+struct FlowPar { static constexpr int value = P_; };
+template <int P_>
+__device__ __forceinline__ constexpr int flow_par(FlowPar<P_>) { return P_; }
+__device__ __forceinline__ constexpr int flow_par(int p) { return p; }
+static bool flow_plan_is_static(const NsfPlan& pl, const NsfPlan& st) {
+  NsfPlan a = pl;
+  a.B = a.min_w = a.min_h = a.min_d = a.lu_eps = a.sqrt_h = a.inv_sqrt_h = 0.f;
+  a.one_minus_kw = a.one_minus_kh = a.d_const = a.log_z = 0.f;
+  a.ablate = 0;
+  const NsfPlan b = st;
+  return memcmp(&a, &b, sizeof(NsfPlan)) == 0 && (pl.ablate & 0x40000) == 0;   // bit 0x40000: force the dynamic plan
+}
 
 // Only the sampling direction ever launches 12-wave workgroups (nsf_plan_for_rows(..., wide)); the density direction
 // keeps the 512-thread bound so that its register allocation is not capped at three waves per SIMD.
-template <int K, int KSH, bool INV>
+// SP = 0: layout from the kernel argument; SP = 8 / 12: the static default layout for 8- / 12-wave workgroups
+template <int K, int KSH, bool INV, int SP = 0>
 __global__ void __launch_bounds__(INV ? 768 : 512)
-nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float* __restrict__ zstats,
+nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
                 float* __restrict__ astash, long long* __restrict__ dbg) {
 #define TSF(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && li == 1) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
+  const NsfPlan& pl = SP == 8 ? kStaticFlow8 : (SP == 12 ? kStaticFlow12 : pl_);   // LAYOUT only; floats / debug: pl_
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int nthreads = blockDim.x;
@@ -47,7 +77,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
 
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
   float cr[4] = {0.f, 0.f, 0.f, 0.f};   // standardized context of this lane (C <= 16)
-  if (pl.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): start from NaN-filled LDS, so that any read of a
+  if (pl_.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): start from NaN-filled LDS, so that any read of a
     // location the kernel did not write itself shows up in the results
     const int total = pl.lds_w_floats + nw * pl.sc_total;
     for (int i = tid; i < total; i += nthreads) lds[i] = __builtin_nanf("");
@@ -80,15 +110,15 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
   }
   wave_lds_fence();
 
-  for (int li = 0; li < pl.T; ++li) {
+  auto layer = [&](int li, auto parc) {
     const int t = INV ? (pl.T - 1 - li) : li;
-    const int par = pl.ctx_mlp ? 0 : (t & 1);   // D == 1: the same dummy mask [1] in every transform
+    const int par = flow_par(parc);
     const bool has_lu = !pl.ctx_mlp;
     const ShapeDesc& S = pl.shape[par];
     TSF(0);
     __syncthreads();   // every wave is done with the previous layer's weights
     TSF(1);
-    if (!(pl.ablate & 16) || li == 0)
+    if (!(pl_.ablate & 16) || li == 0)
       stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
     TSF(2);
     __syncthreads();
@@ -98,7 +128,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       for (int d = id.g; d < D; d += 4)
         if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
     }
-    if (INV && has_lu && !(pl.ablate & 8)) {
+    if (INV && has_lu && !(pl_.ablate & 8)) {
       lu_inverse(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
@@ -116,7 +146,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       const long long tile16 = (long long)blockIdx.x * nw + wave;
       if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * NSF_AST_SLOTS(pl.NB)) * 1024 + 4 * id.lane;
     }
-    if (!(pl.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast);
+    if (!(pl_.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
     TSF(5);
@@ -127,7 +157,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     {
       const int nchunks = (S.d_tr + pl.DCH - 1) / pl.DCH;
       const int dch_ = pl.DCH, dtr_ = S.d_tr;
-      const bool spl_on = !(pl.ablate & 1);
+      const bool spl_on = !(pl_.ablate & 1);
       // integer offsets (not a pointer array): keeps the accesses in the LDS address space
       auto spline_chunk = [&](int c, auto&& yield) {
         // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id.
@@ -140,7 +170,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
         const int dd = live ? dd_raw : c * pl.DCH;
         const int zi = id.j * pl.ZW + 2 * dd + par;
         float y, ld;
-        rq_spline_pair<K, INV>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl, part,
+        rq_spline_pair<K, INV>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl_, part,
                                y, ld, yield);
         // every lane stores: partner / idle lanes hold the same y for the same zi (idempotent)
         zs[zi] = y;
@@ -189,11 +219,24 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
       }
     }
     TSF(20);
-    if (!INV && has_lu && !(pl.ablate & 8)) {
+    if (!INV && has_lu && !(pl_.ablate & 8)) {
       lu_forward(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
     }
     TSF(21);
+  };
+  if constexpr (SP != 0) {     // parity known at compile time: the transform loop runs in pairs
+    constexpr int T_ = (SP == 8 ? kStaticFlow8 : kStaticFlow12).T;
+    constexpr int p0 = INV ? ((T_ - 1) & 1) : 0;
+    for (int li = 0; li < T_; li += 2) {
+      layer(li, FlowPar<p0>{});
+      if (li + 1 < T_) layer(li + 1, FlowPar<p0 ^ 1>{});
+    }
+  } else {
+    for (int li = 0; li < pl.T; ++li) {
+      const int t = INV ? (pl.T - 1 - li) : li;
+      layer(li, pl.ctx_mlp ? 0 : (t & 1));       // D == 1: the same dummy mask [1] in every transform
+    }
   }
 
   // ---- epilogue ----
@@ -207,7 +250,7 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
     float v = -0.5f * part + ld_acc;
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (id.g == 0 && valid) out_main[row] = v - pl.log_z;
+    if (id.g == 0 && valid) out_main[row] = v - pl_.log_z;
   } else {
     for (int d = id.g; d < D; d += 4) {
       float z = zs[id.j * pl.ZW + d];
@@ -223,12 +266,12 @@ nsf_flow_kernel(const NsfPlan pl, const float* __restrict__ packed, const float*
 
 
 // ---- launch helpers (shared by the forward and inverse translation units)
-template <int K, int KSH, bool INV>
+template <int K, int KSH, bool INV, int SP = 0>
 static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                        const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                        float* z_stash, float* astash, hipStream_t stream) {
   const int64_t lds_bytes = nsf_lds_bytes(pl, nw);
-  auto kern = nsf_flow_kernel<K, KSH, INV>;
+  auto kern = nsf_flow_kernel<K, KSH, INV, SP>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t rows_per_wg = 16 * nw;
@@ -243,6 +286,15 @@ template <int K, bool INV>
 static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                            const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                            float* z_stash, float* astash, hipStream_t st) {
+  if constexpr (K == 10) {     // the benchmark configuration: layout folded into the kernel
+    if constexpr (!INV) {
+      if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8))
+        return launch_flow<10, 13, INV, 8>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    } else {
+      if (nw == 12 && flow_plan_is_static(pl, kStaticFlow12))
+        return launch_flow<10, 13, INV, 12>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    }
+  }
   if (pl.KSH == 13)
     return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
   return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
