@@ -4,7 +4,7 @@
 //   nsf_coop_pack_kernel      flat parameters -> fragment-ordered image (forward AND transposed matrices)
 //   nsf_coop_fwd_kernel       log p (+ noise, + the stash the backward pass needs) for all T transforms
 //   nsf_coop_bwd_kernel       all T transforms backward in one launch: d loss / d theta, per-workgroup partial
-//                             weight-gradient slabs in the throughput path's layout (nsf_grad_reduce_kernel sums them)
+//                             weight-gradient slabs (tile order, nsf_coop_reduce_kernel sums them)
 #include <hip/hip_runtime.h>
 #include "nsf_coop.h"
 #include "nsf_device.h"

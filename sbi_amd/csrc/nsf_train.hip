@@ -12,54 +12,65 @@
 //   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i)
 // block = 64 params x 8 slab groups: enough loads in flight to stream the ~100 MB of partials.
 #define RED_GROUPS 8
+// grid (ceil(PLP / 256), T): one thread sums FOUR consecutive slab words (16-byte loads, 4 x 8-way in flight) over the
+// workgroups' slabs; a slab is indexed relative to its transform's parameter block, so the words are 16-byte aligned
 __global__ void __launch_bounds__(64 * RED_GROUPS)
 nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __restrict__ params,
                        const float* __restrict__ partial, float* __restrict__ grad,
                        const float* __restrict__ logp, float* __restrict__ loss_out, long long n_rows) {
   // rider (saves a launch per step): the per-row loss of the one-call form, loss = -log p
   if (loss_out)
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
-         i += (long long)gridDim.x * blockDim.x)
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_rows;
+         i += (long long)gridDim.x * gridDim.y * blockDim.x)
       loss_out[i] = -logp[i];
-  __shared__ float red[RED_GROUPS][64];
-  __shared__ float red_sgl[RED_GROUPS][64];
+  typedef float f4r __attribute__((ext_vector_type(4)));
+  __shared__ f4r red[RED_GROUPS][64];
+  __shared__ float red_sgl[RED_GROUPS];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + lane;
-  const bool live = idx < pl.n_params;
-  int t = 0;
-  if (live) while (t + 1 < pl.T && idx >= pl.g_layer[t + 1]) ++t;
-  const ShapeDesc& S = pl.shape[t & 1];
-  const int li = idx - pl.g_layer[t];
+  const int t = blockIdx.y;
+  const ShapeDesc& S = pl.shape[pl.ctx_mlp ? 0 : (t & 1)];
+  const int li = 4 * (blockIdx.x * 64 + lane);
+  const bool live = li < S.n_params;
   const float* base = partial + (long long)t * tp.grid * tp.PLP;
   const int ntri = pl.D * (pl.D - 1) / 2;
   const int d0 = S.g_lu + 2 * ntri;
-  const bool is_diag = live && !pl.ctx_mlp && li >= d0 && li < d0 + pl.D;
-  float a = 0.f, sgl = 0.f;
+  f4r a = {0.f, 0.f, 0.f, 0.f};
   if (live) {
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    f4r acc4[4] = {a, a, a, a};
     int w = grp;
     for (; w + 3 * RED_GROUPS < tp.grid; w += 4 * RED_GROUPS) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc4[u] += base[(long long)(w + u * RED_GROUPS) * tp.PLP + li];
+      for (int u = 0; u < 4; ++u) acc4[u] += *reinterpret_cast<const f4r*>(base + (long long)(w + u * RED_GROUPS) * tp.PLP + li);
     }
-    for (; w < tp.grid; w += RED_GROUPS) acc4[0] += base[(long long)w * tp.PLP + li];
+    for (; w < tp.grid; w += RED_GROUPS) acc4[0] += *reinterpret_cast<const f4r*>(base + (long long)w * tp.PLP + li);
     a = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-    if (is_diag)
-      for (int w2 = grp; w2 < tp.grid; w2 += RED_GROUPS) sgl += base[(long long)w2 * tp.PLP + S.n_params];
   }
   red[grp][lane] = a;
-  red_sgl[grp][lane] = sgl;
+  {   // sum_n d loss / d logabsdet_n: one word per slab (slot n_params)
+    float sgl = 0.f;
+    if (!pl.ctx_mlp)
+      for (int w2 = grp * 64 + lane; w2 < tp.grid; w2 += 64 * RED_GROUPS) sgl += base[(long long)w2 * tp.PLP + S.n_params];
+    for (int off = 32; off > 0; off >>= 1) sgl += __shfl_xor(sgl, off);
+    if (lane == 0) red_sgl[grp] = sgl;
+  }
   __syncthreads();
   if (grp == 0 && live) {
-    float tot = 0.f, tsg = 0.f;
+    f4r tot = {0.f, 0.f, 0.f, 0.f};
+    float tsg = 0.f;
 #pragma unroll
-    for (int g = 0; g < RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g][lane]; }
-    if (is_diag) {
-      const float ud = params[idx];
-      const float uii = softplus_f(ud) + pl.lu_eps;
-      tot = (tot + tsg / uii) * (1.f / (1.f + expf(-ud)));
+    for (int g = 0; g < RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (li + r >= S.n_params) continue;
+      const int idx = pl.g_layer[t] + li + r;
+      float v = tot[r];
+      if (!pl.ctx_mlp && li + r >= d0 && li + r < d0 + pl.D) {
+        const float ud = params[idx];
+        const float uii = softplus_f(ud) + pl.lu_eps;
+        v = (v + tsg / uii) * (1.f / (1.f + expf(-ud)));
+      }
+      grad[idx] = v;
     }
-    grad[idx] = tot;
   }
 }
 
@@ -238,8 +249,8 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((pl.n_params + 63) / 64), dim3(64 * RED_GROUPS), 0, st, pl, tp, params,
-                     partial, grad_out, (const float*)(workspace + o_logp), loss_out, (long long)n);
+  hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((tp.PLP / 4 + 63) / 64, pl.T), dim3(64 * RED_GROUPS), 0, st, pl, tp,
+                     params, partial, grad_out, (const float*)(workspace + o_logp), loss_out, (long long)n);
   return (int)hipGetLastError();
 }
 
