@@ -175,6 +175,11 @@ int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples
 int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, const float* p0, const float* p1,
                                 const float* u, float* theta_out, float* logabsdet_out, void* stream);
 
+/* Host-side consistency check of the cooperative kernels' address arithmetic against the plan tables, and of the
+ * compile-time default layout against the run-time plan (no device work; used by the CPU tests).  0 = consistent,
+ * -1 = the configuration has no cooperative image. */
+int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
+
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
 #define SBI_AMD_NSF_ABI_VERSION 106
 int sbi_amd_nsf_abi_version(void);

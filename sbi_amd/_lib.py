@@ -66,6 +66,7 @@ _SIGNATURES = {
     "sbi_amd_nsf_pack": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p]),
     "sbi_amd_nsf_image_kind": (c_int, [POINTER(NSFConfigC), c_int64, c_int32]),
     "sbi_amd_nsf_set_coop_max_rows": (c_int64, [c_int64]),
+    "sbi_amd_nsf_coop_selfcheck": (c_int, [POINTER(NSFConfigC)]),
     "sbi_amd_nsf_pack_images": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_int32, c_void_p]),
     "sbi_amd_nsf_log_prob": (
         c_int,

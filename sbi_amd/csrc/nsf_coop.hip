@@ -164,3 +164,43 @@ int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const 
                      (const float*)(workspace + o_logp), loss_out, (long long)n);
   return (int)hipGetLastError();
 }
+
+// Host-side self-check (CPU tests, no device work): the arithmetic the kernels use in place of table look-ups must
+// reproduce the plan's tables -- slab tile bases (nsf_coop_bwd_kernel: tb_blk0 / blk_tiles / tb_wf) against
+// CoShape::dw_tb, the per-block image strides of CoK against every CoMat offset -- and, for the benchmark
+// configuration, the compile-time layouts (kStaticPl, kStaticTp) must equal the run-time plans bit for bit.
+// Returns 0 or the number of the first failing check.
+extern "C" int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg) {
+  NsfPlan pl;
+  CoopPlan cp;
+  if (!coop_shape_ok(cfg, &pl, &cp)) return -1;
+  CoK k;
+  coop_make_consts(pl, cp, &k);
+  for (int par = 0; par < 2; ++par) {
+    const CoShape& c = cp.sh[par];
+    const ShapeDesc& S = pl.shape[par];
+    const CoKP& q = k.p[par];
+    const int blk_tiles = 4 * k.ntc + 8 * k.nnh, tb_blk0 = 4 * q.nnt0;
+    if (c.dw_tb[0] != 0 || c.dw_nnt[0] != q.nnt0) return 1;
+    for (int b = 0; b < pl.NB; ++b) {
+      if (c.dw_tb[1 + 3 * b] != tb_blk0 + b * blk_tiles || c.dw_nnt[1 + 3 * b] != k.ntc) return 2;
+      if (c.dw_tb[2 + 3 * b] != tb_blk0 + b * blk_tiles + 4 * k.ntc || c.dw_nnt[2 + 3 * b] != k.nnh) return 3;
+      if (c.dw_tb[3 + 3 * b] != tb_blk0 + b * blk_tiles + 4 * k.ntc + 4 * k.nnh || c.dw_nnt[3 + 3 * b] != k.nnh) return 4;
+      if (c.WC[b].off != q.wc0 + b * k.sA || c.W1[b].off != q.w10 + b * k.sA || c.W2[b].off != q.w20 + b * k.sA) return 5;
+      if (c.W1T[b].off != q.w1t0 + b * k.sT || c.W2T[b].off != q.w2t0 + b * k.sT || c.WCT[b].off != q.wct0 + b * k.sC) return 6;
+      if (c.bc[b].off != q.bc0 + b * k.sB || c.b1[b].off != q.b10 + b * k.sB || c.b2[b].off != q.b20 + b * k.sB) return 7;
+      if (c.W1[b].quads != 4 || c.W2[b].quads != 4 || c.W1T[b].quads != 4 || c.W2T[b].quads != 4 || c.WC[b].quads != k.KCQ) return 8;
+    }
+    if (c.dw_tb[S.fin] != tb_blk0 + pl.NB * blk_tiles || c.dw_nnt[S.fin] != k.nnh) return 9;
+    if (c.dw_tail != (c.dw_tb[S.fin] + c.nft * k.nnh) * 256 || c.dw_tail + pl.D * (pl.D - 1) + 2 * pl.D + 1 > cp.PLP) return 10;
+    if (c.W0.quads != k.KCQ + 1 || c.WF.quads != 4 || c.WFT.quads != S.d_tr * pl.PT || c.W0T.quads != 4) return 11;
+    if (c.o_bias % 256 != 0 || c.o_ld >= cp.img_floats) return 12;
+  }
+  if (cfg->D == 10 && cfg->C == 10 && cfg->H == 50 && cfg->K == 10 && cfg->T == 5 && cfg->NB == 2) {
+    NsfPlan p4;
+    TrainPlan tp;
+    if (nsf_build_plan(cfg, TR_NW, &p4) != 0 || build_train_plan(p4, 65536, &tp) != 0) return 20;
+    if (!plan_is_static_default(p4, tp) && !(p4.ablate & 0x40000)) return 21;
+  }
+  return 0;
+}
