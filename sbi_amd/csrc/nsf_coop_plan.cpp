@@ -21,6 +21,13 @@ extern "C" int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows) {
   return prev;
 }
 
+// debug aid: SBI_AMD_COOP_LEAN=0 keeps the forward pass of > 4096-row calls on the two-tile workgroups
+bool coop_lean_forward() {
+  static int lean_env = -1;
+  if (lean_env < 0) { const char* a = getenv("SBI_AMD_COOP_LEAN"); lean_env = a ? atoi(a) : 1; }
+  return lean_env != 0;
+}
+
 static void add_mat(CoMat* m, int* off, int mtiles, int quads, int kind, int lin) {
   m->off = *off;
   m->mtiles = mtiles;
