@@ -9,6 +9,11 @@
  *   sbi_amd_fmpe_velocity        FlowMatchingEstimator.forward / ode_fn
  *                                neural_nets/estimators/flowmatching_estimator.py:206-274, 349-372
  *                                (VectorFieldMLP.forward  net_builders/vector_field_nets.py:683-719)
+ *   sbi_amd_fmpe_velocity_div    the augmented right-hand side of VectorFieldPosterior.log_prob: velocity AND the exact
+ *                                trace of its Jacobian wrt theta_t -- inference/posteriors/vector_field_posterior.py:467-504
+ *                                -> potentials/vector_field_potential.py:149-207 -> samplers/ode_solvers/zuko_ode.py:19-124
+ *                                (zuko's FreeFormJacobianTransform with exact=True: a batched-identity autograd trace;
+ *                                here forward-mode tangents ride in the MFMA tile next to the primal)
  *   sbi_amd_fmpe_loss            FlowMatchingEstimator.loss (validation: no gradient)   :276-347
  *   sbi_amd_fmpe_loss_fwd_bwd    the same loss + loss.backward() of the training loop
  *                                inference/trainers/vfpe/base_vf_inference.py:443-470, trainers/base.py:1160-1190
@@ -55,6 +60,11 @@ int sbi_amd_fmpe_pack(const sbi_amd_fmpe_config* cfg, const float* params, float
 int sbi_amd_fmpe_velocity(const sbi_amd_fmpe_config* cfg, const float* packed, const float* zstats,
                           const float* theta_t, const float* x, int64_t x_rows, const float* times,
                           int64_t t_rows, int64_t n, float* v_out, void* stream);
+
+/* The same velocity (v_out may be NULL) and div_out[n] = sum_f d v_out[n][f] / d theta_t[n][f] (exact, fp32). */
+int sbi_amd_fmpe_velocity_div(const sbi_amd_fmpe_config* cfg, const float* packed, const float* zstats,
+                              const float* theta_t, const float* x, int64_t x_rows, const float* times,
+                              int64_t t_rows, int64_t n, float* v_out, float* div_out, void* stream);
 
 /* loss_out[n] = per-row conditional-flow-matching loss for theta[n][D], x, times[n] ~ U[0,1],
  * noise[n][D] ~ N(0, I) (the draws FlowMatchingEstimator.loss makes internally, made explicit). */

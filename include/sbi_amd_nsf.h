@@ -181,7 +181,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 106
+#define SBI_AMD_NSF_ABI_VERSION 107
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

@@ -141,6 +141,49 @@ class FMPEOracle(nn.Module):
         vm, vs = self.velocity_stats()
         return self.net((theta_t - mu) / sd, c, t) * vs + vm
 
+    def velocity_and_divergence(self, theta_t: Tensor, x: Tensor, t: Tensor):
+        """`velocity` and the exact trace of its Jacobian wrt theta_t: the augmented right-hand side that
+        VectorFieldPosterior.log_prob integrates (sbi/inference/posteriors/vector_field_posterior.py:467-504 ->
+        potentials/vector_field_potential.py:149-207 -> samplers/ode_solvers/zuko_ode.py:100-124, where zuko's
+        FreeFormJacobianTransform(exact=True) -- third-party, zuko >= 1.2, not installed here -- takes the trace with a
+        batched autograd identity).  Here: one reverse pass per theta dim; rows are independent, so the gradient of
+        sum_n v[n, f] picks d v[n, f] / d theta[n, :].  Pinned against the real estimator's ode_fn by
+        tests/test_golden_fmpe.py (fixture key `div`)."""
+        th = theta_t.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            v = self.velocity(th, x, t)
+            div = torch.zeros(th.shape[0], dtype=th.dtype)
+            for f in range(self.D):
+                (gf,) = torch.autograd.grad(v[:, f].sum(), th, retain_graph=True)
+                div = div + gf[:, f]
+        return v.detach(), div.detach()
+
+    def log_prob(self, theta: Tensor, x: Tensor, steps: int = 200, t_min: float = 0.0, t_max: float = 1.0) -> Tensor:
+        """log p(theta | x) of the probability-flow ODE: integrate (theta, ladj)' = (v, div v) from t_min (data)
+        to t_max (noise) and add the N(0, I) base log-density of the end point (zuko's
+        NormalizingFlow.log_prob = base.log_prob(transform(theta)) + ladj; sbi builds the base as
+        DiagNormal(mean_base = 0, std_base = 1), samplers/ode_solvers/zuko_ode.py:118-124).  Classical RK4 on a fixed
+        grid in the module's dtype: run it on `.double()` with a few hundred steps and the result is the ODE's
+        solution to ~1e-9 -- the yardstick the adaptive fp32 device solve is held to."""
+        th = theta.detach().clone()
+        n = th.shape[0]
+        ladj = torch.zeros(n, dtype=th.dtype)
+        hstep = (t_max - t_min) / steps
+
+        def rhs(tt: float, y: Tensor):
+            return self.velocity_and_divergence(y, x, torch.full((n,), tt, dtype=th.dtype))
+
+        for i in range(steps):
+            t0 = t_min + i * hstep
+            k1, d1 = rhs(t0, th)
+            k2, d2 = rhs(t0 + 0.5 * hstep, th + 0.5 * hstep * k1)
+            k3, d3 = rhs(t0 + 0.5 * hstep, th + 0.5 * hstep * k2)
+            k4, d4 = rhs(t0 + hstep, th + hstep * k3)
+            th = th + hstep / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+            ladj = ladj + hstep / 6.0 * (d1 + 2 * d2 + 2 * d3 + d4)
+        base = (-0.5 * th ** 2 - 0.5 * math.log(2.0 * math.pi)).sum(-1)
+        return base + ladj
+
     def loss(self, theta: Tensor, x: Tensor, times: Tensor, noise: Tensor) -> Tensor:
         """FlowMatchingEstimator.loss (flowmatching_estimator.py:276-347) with the draws `times ~ U[0,1]` and
         `noise = theta_1 ~ N(0, I)` made explicit.  Returns the per-row loss (N,)."""

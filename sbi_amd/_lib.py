@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 106    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 107    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -116,6 +116,11 @@ _SIGNATURES = {
         c_int,
         [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
          c_void_p, c_void_p],
+    ),
+    "sbi_amd_fmpe_velocity_div": (
+        c_int,
+        [POINTER(FMPEConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+         c_void_p, c_void_p, c_void_p],
     ),
     "sbi_amd_fmpe_loss": (
         c_int,

@@ -389,7 +389,7 @@ struct FmArgs {
   const float* packed; const float* zstats; const float* theta; const float* x; const float* times;
   const float* noise; const float* row_weight; float uniform_weight;
   long long n; int x_rows, t_rows;
-  float* loss_out; float* v_out; float* stash; float* ln_part;
+  float* loss_out; float* v_out; float* stash; float* ln_part; float* div_out;
   int ntiles;
   long long* timeline;   // debug (env SBI_AMD_FM_TIMELINE): s_memtime stamps of workgroup 0, wave 0
 };
@@ -730,6 +730,252 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
   pipe.drain();
 #undef FM_ENTER
 #undef FM_TS
+}
+
+// ---------------------------------------------------------------- velocity + divergence (log_prob of the flow)
+// d v_f / d theta_f summed over f, exactly (what zuko's FreeFormJacobianTransform computes with a batched autograd
+// identity for sbi's VectorFieldPosterior.log_prob, samplers/ode_solvers/zuko_ode.py:19-124 with exact=True), by
+// FORWARD-mode propagation: the 16 columns of a wave's MFMA tile are not 16 batch rows but ONE row's primal
+// (column 15) next to the tangents of 15 input directions (column c <-> direction 15 chunk + c).  Every linear is
+// the same W X^T product for all columns (bias / time embedding on the primal column only); GELU and LayerNorm
+// need the primal's values in every column, so each lane keeps a copy of the primal's activations of ITS features
+// (hp), refreshed from column 15 by one ds_bpermute per value and layer:
+//     GELU:       a_p = u_p Phi(u_p)                     a_tau = (Phi(u_p) + u_p phi(u_p)) u_tau
+//     LayerNorm:  h_p = gamma s + beta, s = (y_p - mu) r   h_tau = gamma r (y_tau - mean(y_tau) - s mean(s y_tau))
+// A row with more than 15 theta dims takes ceil(D / 15) passes (the primal is recomputed in each).  One workgroup =
+// 8 waves = 8 rows per pass; the weight groups stream through LDS exactly as in the forward kernel.
+#define FM_DIV_PC 15
+__device__ __forceinline__ f4 bcast_primal(f4 v, int g) {
+  const int src = 16 * g + FM_DIV_PC;
+  return f4{__shfl(v[0], src), __shfl(v[1], src), __shfl(v[2], src), __shfl(v[3], src)};
+}
+// primal column: GELU(up); tangent columns: GELU'(up) * u; `ap` receives GELU(up) for every lane
+__device__ __forceinline__ f4 gelu_primal_tangent(f4 up, f4 u, bool primal, f4& ap) {
+  f4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float cdf, ex;
+    gelu_core(up[i], cdf, ex);
+    ap[i] = up[i] * cdf;
+    out[i] = primal ? ap[i] : (cdf + up[i] * 0.3989422804014327f * ex) * u[i];
+  }
+  return out;
+}
+
+template <int HB>
+__global__ void __launch_bounds__(FM_THREADS, 1) fm_div_kernel(const FmPlan pl, const FmArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  float* zs = lds + 2 * pl.lds_fwd_floats;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int D = pl.D, C = pl.C, H = pl.H;
+  const bool primal = c == FM_DIV_PC;
+  float* z_mean = zs; float* z_std = zs + 128; float* z_vstd = zs + 256; float* z_xm = zs + 384; float* z_xi = zs + 512;
+  for (int i = tid; i < 128; i += FM_THREADS) {
+    const float m = i < D ? a.zstats[i] : 0.f, s = i < D ? a.zstats[D + i] : 1.f;
+    z_mean[i] = m; z_std[i] = s; z_vstd[i] = sqrtf(1.0f + s * s);
+    z_xm[i] = i < C ? a.zstats[2 * D + i] : 0.f;
+    z_xi[i] = i < C ? 1.0f / a.zstats[2 * D + C + i] : 0.f;
+  }
+  const float invH = 1.0f / (float)H;
+  const int nchunks = (D + FM_DIV_PC - 1) / FM_DIV_PC;
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  FmPipe pipe;
+  pipe.init(lds, a.packed, pl.fgrp_off, pl.fgrp_floats, pl.nfg, pl.lds_fwd_floats, wave, lane, 0);
+  const float* wb = lds;
+#define FM_ENTER(J)                 \
+  {                                 \
+    pipe.enter(pl.lin[J].fg_first); \
+    wb = pipe.base();               \
+  }
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const long long row_raw = (long long)tile * FM_WAVES + wave;
+    const bool valid = row_raw < a.n;
+    const long long row = valid ? row_raw : a.n - 1;
+    const float t = a.times[a.t_rows == 1 ? 0 : row];
+    const float om = 1.0f - t;
+    const float* th = a.theta + row * D;
+    const float* xr = a.x + (a.x_rows == 1 ? 0 : row) * C;
+    float div = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int dir = FM_DIV_PC * ch + c;      // this column's input direction (tangent columns)
+      f4 acc[HB], temb[HB], h[HB], hp[HB];
+      // ---- input layer: primal = time-dependent z-score of theta_t; tangent of direction f = e_f / scale_f
+      FM_ENTER(J_IN);
+      {
+        const FmLin& q = pl.lin[J_IN];
+        f4 ie[HB];
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob)
+          ie[ob] = primal ? *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g) : zero4;
+        const float* wl = wb + q.lw + c * q.ldk + 4 * g;
+        for (int kb = 0; kb < pl.DB; ++kb) {
+          f4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int f = 16 * kb + 4 * g + i;
+            float val = 0.f;
+            if (f < D) {
+              const float sd = om * z_std[f];
+              const float inv = 1.0f / sqrtf(sd * sd + t * t + 1e-6f);
+              val = primal ? (th[f] - om * z_mean[f]) * inv : (f == dir ? inv : 0.f);
+            }
+            v[i] = val;
+          }
+          gemm_blk<HB>(wl, q.ldk, kb, v, ie);
+        }
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob) {
+          f4 ap;
+          h[ob] = gelu_primal_tangent(bcast_primal(ie[ob], g), ie[ob], primal, ap);
+        }
+      }
+      // ---- merge, first half (theta embedding)
+      FM_ENTER(J_MA);
+      {
+        const FmLin& q = pl.lin[J_MA];
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob)
+          acc[ob] = primal ? *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g) : zero4;
+        gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      }
+      // ---- condition layer: no theta dependence, the tangent columns stay zero
+      FM_ENTER(J_CT);
+      {
+        const FmLin& q = pl.lin[J_CT];
+        f4 ce[HB];
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob)
+          ce[ob] = primal ? *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g) : zero4;
+        const float* wl = wb + q.lw + c * q.ldk + 4 * g;
+        for (int kb = 0; kb < pl.CB; ++kb) {
+          f4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int f = 16 * kb + 4 * g + i;
+            v[i] = (primal && f < C) ? (xr[f] - z_xm[f]) * z_xi[f] : 0.f;
+          }
+          gemm_blk<HB>(wl, q.ldk, kb, v, ce);
+        }
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob) h[ob] = primal ? gelu4(ce[ob]) : zero4;
+      }
+      FM_ENTER(J_MB);
+      {
+        const FmLin& q = pl.lin[J_MB];
+        gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      }
+#pragma unroll
+      for (int ob = 0; ob < HB; ++ob) h[ob] = gelu_primal_tangent(bcast_primal(acc[ob], g), acc[ob], primal, hp[ob]);
+      // ---- time embedding (the same for every column: one row per wave)
+      FM_ENTER(J_TM);
+      {
+        const FmLin& q = pl.lin[J_TM];
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob) temb[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
+        const float* wl = wb + q.lw + c * q.ldk + 4 * g;
+        for (int kb = 0; kb < pl.EB; ++kb) {
+          f4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = 16 * kb + 4 * g + i;
+            float val = 0.f;
+            if (e < pl.E) {
+              const float w = expf(-(float)(e & ~1) * pl.log_max_freq_over_E);
+              const float ang = t * w;
+              val = (e & 1) ? cosf(ang) : sinf(ang);
+            }
+            v[i] = val;
+          }
+          gemm_blk<HB>(wl, q.ldk, kb, v, temb);
+        }
+      }
+      // ---- residual blocks: h <- LayerNorm(GELU(W h + b) + temb + h), primal and tangents
+      for (int l = 0; l < pl.L; ++l) {
+        FM_ENTER(J_L0 + l);
+        const FmLin& q = pl.lin[J_L0 + l];
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob)
+          acc[ob] = primal ? *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g) : zero4;
+        gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+        float s1 = 0.f, sp1 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob) {
+          f4 ap;
+          const f4 at = gelu_primal_tangent(bcast_primal(acc[ob], g), acc[ob], primal, ap);
+          hp[ob] = ap + temb[ob] + hp[ob];                          // y_p (every lane, its features)
+          acc[ob] = primal ? hp[ob] : at + h[ob];                   // y of this column
+          sp1 += (hp[ob][0] + hp[ob][1]) + (hp[ob][2] + hp[ob][3]);
+          s1 += (acc[ob][0] + acc[ob][1]) + (acc[ob][2] + acc[ob][3]);
+        }
+        const float mu = sum_over_g(sp1) * invH;
+        const float m1 = sum_over_g(s1) * invH;
+        float s2 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float d = (16 * ob + 4 * g + i) < H ? hp[ob][i] - mu : 0.f;
+            hp[ob][i] = d;
+            s2 += d * d;
+          }
+        const float rstd = 1.0f / sqrtf(sum_over_g(s2) * invH + pl.ln_eps);
+        float s3 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob) {
+          hp[ob] = hp[ob] * rstd;                                    // s
+          s3 += (hp[ob][0] * acc[ob][0] + hp[ob][1] * acc[ob][1]) + (hp[ob][2] * acc[ob][2] + hp[ob][3] * acc[ob][3]);
+        }
+        const float m2 = sum_over_g(s3) * invH;
+#pragma unroll
+        for (int ob = 0; ob < HB; ++ob) {
+          const f4 gam = *reinterpret_cast<const f4*>(wb + q.lb + 16 * HB + 16 * ob + 4 * g);
+          const f4 bet = *reinterpret_cast<const f4*>(wb + q.lb + 32 * HB + 16 * ob + 4 * g);
+          f4 ht;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            ht[i] = (16 * ob + 4 * g + i) < H ? gam[i] * rstd * (acc[ob][i] - m1 - hp[ob][i] * m2) : 0.f;
+          hp[ob] = hp[ob] * gam + bet;
+          h[ob] = primal ? hp[ob] : ht;
+        }
+      }
+      // ---- output layer: velocity from the primal column, the Jacobian diagonal from the tangent columns
+      FM_ENTER(J_L0 + pl.L);
+      {
+        const FmLin& q = pl.lin[J_L0 + pl.L];
+        const float* wl = wb + q.lw + c * q.ldk + 4 * g;
+        for (int ob = 0; ob < pl.DB; ++ob) {
+          f4 o0 = primal ? *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g) : zero4, o1 = zero4;
+#pragma unroll
+          for (int kb = 0; kb < HB; ++kb) {
+            const f4 av = *reinterpret_cast<const f4*>(wl + ob * 16 * q.ldk + 16 * kb);
+            if (kb & 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o1 = MFMA16(av[r], h[kb][r], o1);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o0 = MFMA16(av[r], h[kb][r], o0);
+            }
+          }
+          o0 += o1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int f = 16 * ob + 4 * g + i;
+            if (f < D) {
+              if (primal) {
+                if (ch == 0 && valid && a.v_out) a.v_out[row * D + f] = o0[i] * z_vstd[f] - z_mean[f];
+              } else if (f == dir) {
+                div += o0[i] * z_vstd[f];
+              }
+            }
+          }
+        }
+      }
+    }
+    div = sum_over_c(sum_over_g(div));
+    if (lane == 0 && valid) a.div_out[row] = div;
+  }
+  pipe.drain();
+#undef FM_ENTER
 }
 
 // ---------------------------------------------------------------- backward (dX chain)
@@ -1156,6 +1402,27 @@ static int fm_launch_fwd(const FmPlan& pl, const FmArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static int fm_launch_div(const FmPlan& pl, const FmArgs& a, hipStream_t st) {
+  const size_t lds = 4ull * (2 * pl.lds_fwd_floats + FM_ZS_FLOATS);
+  const int grid = fm_grid(a.ntiles);
+#define FM_DIV_CASE(HBV)                                                                                        \
+  case HBV: {                                                                                                   \
+    hipError_t e = hipFuncSetAttribute((const void*)fm_div_kernel<HBV>,                                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    if (e != hipSuccess) return (int)e;                                                                         \
+    hipLaunchKernelGGL((fm_div_kernel<HBV>), dim3(grid), dim3(FM_THREADS), lds, st, pl, a);                     \
+    break;                                                                                                      \
+  }
+  switch (pl.HB) {
+    FM_DIV_CASE(4)
+    FM_DIV_CASE(7)
+    FM_DIV_CASE(8)
+    default: return SBI_AMD_E_UNSUPPORTED;
+  }
+#undef FM_DIV_CASE
+  return (int)hipGetLastError();
+}
+
 static int fm_launch_bwd(const FmPlan& pl, const FmArgs& a, int grid, hipStream_t st) {
   const size_t lds = 4ull * 2 * pl.lds_bwd_floats;
 #define FM_BWD_CASE(HBV)                                                                                        \
@@ -1253,6 +1520,24 @@ int sbi_amd_fmpe_velocity(const sbi_amd_fmpe_config* cfg, const float* packed, c
   if (n == 1) { a.x_rows = 1; a.t_rows = 1; }
   a.v_out = v_out; a.ntiles = (int)((n + FM_ROWS - 1) / FM_ROWS);
   return fm_launch_fwd<0>(pl, a, (hipStream_t)stream);
+}
+
+int sbi_amd_fmpe_velocity_div(const sbi_amd_fmpe_config* cfg, const float* packed, const float* zstats,
+                              const float* theta_t, const float* x, int64_t x_rows, const float* times,
+                              int64_t t_rows, int64_t n, float* v_out, float* div_out, void* stream) {
+  FmPlan pl;
+  int rc = fm_build_plan(cfg, &pl);
+  if (rc) return rc;
+  if (!packed || !zstats || !theta_t || !x || !times || !div_out || n < 0) return SBI_AMD_E_BADARG;
+  if ((x_rows != 1 && x_rows != n) || (t_rows != 1 && t_rows != n)) return SBI_AMD_E_BADARG;
+  if (n == 0) return 0;
+  FmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = packed; a.zstats = zstats; a.theta = theta_t; a.x = x; a.times = times; a.n = n;
+  a.x_rows = (int)(x_rows == 1 ? 1 : 2); a.t_rows = (int)(t_rows == 1 ? 1 : 2);
+  if (n == 1) { a.x_rows = 1; a.t_rows = 1; }
+  a.v_out = v_out; a.div_out = div_out; a.ntiles = (int)((n + FM_WAVES - 1) / FM_WAVES);
+  return fm_launch_div(pl, a, (hipStream_t)stream);
 }
 
 int sbi_amd_fmpe_loss(const sbi_amd_fmpe_config* cfg, const float* packed, const float* zstats, const float* theta,

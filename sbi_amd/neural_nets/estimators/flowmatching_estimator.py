@@ -166,6 +166,24 @@ def velocity(net: VectorFieldMLPParams, theta_t: Tensor, x: Tensor, times: Tenso
     return out
 
 
+def velocity_and_divergence(net: VectorFieldMLPParams, theta_t: Tensor, x: Tensor, times: Tensor,
+                            v_out: Optional[Tensor] = None, div_out: Optional[Tensor] = None):
+    """theta_t (n, D), x (n, C) or (1, C), times (n,) or (1,) -> velocity (n, D), sum_f d v_f / d theta_f (n,)."""
+    dev = _lib.require_device(theta_t, x, times, net.flat_params)
+    n = theta_t.shape[0]
+    v = torch.empty_like(theta_t) if v_out is None else v_out
+    div = torch.empty(n, dtype=torch.float32, device=dev) if div_out is None else div_out
+    if n == 0:
+        return v, div
+    with torch.cuda.device(dev):
+        rc = _lib.load().sbi_amd_fmpe_velocity_div(
+            net.hyper.c_config(), _lib.ptr(packed_weights(net)), _lib.ptr(net.zstats), _lib.ptr(theta_t),
+            _lib.ptr(x), x.shape[0], _lib.ptr(times), times.numel(), n, _lib.ptr(v), _lib.ptr(div),
+            _lib.current_stream(dev))
+    _lib.check(rc, "fmpe_velocity_div")
+    return v, div
+
+
 def cfm_loss(net: VectorFieldMLPParams, theta: Tensor, x: Tensor, times: Tensor, noise: Tensor) -> Tensor:
     dev = _lib.require_device(theta, x, times, noise, net.flat_params)
     n = theta.shape[0]
@@ -281,6 +299,21 @@ class FlowMatchingEstimator(ConditionalEstimator):
 
     def ode_fn(self, input: Tensor, condition: Tensor, times: Tensor) -> Tensor:
         return self.forward(input, condition, times)
+
+    def ode_fn_and_divergence(self, input: Tensor, condition: Tensor, times: Tensor, v_out: Optional[Tensor] = None,
+                              div_out: Optional[Tensor] = None):
+        """``ode_fn`` and the exact trace of its Jacobian with respect to ``input`` -- the augmented right-hand side
+        zuko's ``FreeFormJacobianTransform(exact=True)`` integrates for ``VectorFieldPosterior.log_prob``
+        (samplers/ode_solvers/zuko_ode.py:100-124).  input (n, D), condition (n, C) or (1, C), times 1 or n entries."""
+        D, C = self.input_shape[0], self.condition_shape[0]
+        th = input.to(torch.float32).reshape(-1, D).contiguous()
+        cond = condition.to(torch.float32).reshape(-1, C).contiguous()
+        if cond.shape[0] not in (1, th.shape[0]):
+            raise ValueError(f"condition batch {cond.shape[0]} does not match input batch {th.shape[0]}")
+        t = torch.as_tensor(times, dtype=torch.float32, device=th.device).reshape(-1).contiguous()
+        if t.numel() not in (1, th.shape[0]):
+            raise ValueError(f"times has {t.numel()} entries for {th.shape[0]} rows")
+        return velocity_and_divergence(self.net, th, cond, t, v_out, div_out)
 
     def score(self, input: Tensor, condition: Tensor, t: Tensor) -> Tensor:
         """flowmatching_estimator.py:374-399."""

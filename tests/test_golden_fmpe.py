@@ -40,6 +40,42 @@ def test_velocity_matches_reference(name):
     assert (v - g["vel"]).abs().max() <= 1e-5 * g["vel"].abs().max()
 
 
+@pytest.mark.parametrize("name", ["default_D5_C3", "H48_L2_D3_C4"])
+def test_jacobian_trace_matches_reference(name):
+    """The integrand of VectorFieldPosterior.log_prob: exact trace of d ode_fn / d theta_t of the REAL estimator
+    (autograd, tools/make_golden_fmpe.py) against the oracle's, and against central differences of the oracle's own
+    velocity in fp64 (the trace is what it claims to be)."""
+    g, o = load_case(name)
+    v, div = o.velocity_and_divergence(g["theta_q"], g["x"][:1], g["tq"])
+    assert (v - g["vel"]).abs().max() <= 1e-5 * g["vel"].abs().max()
+    assert (div - g["div"]).abs().max() <= 2e-5 * g["div"].abs().max() + 1e-6
+    od = FMPEOracle(g["D"], g["C"], H=o.H, L=o.L).double()
+    od.load_reference_state_dict({k: val.double() for k, val in g["state"].items()})
+    th, x, t = g["theta_q"].double(), g["x"][:1].double(), g["tq"].double()
+    fd = torch.zeros(th.shape[0], dtype=torch.float64)
+    eps = 1e-6
+    with torch.no_grad():
+        for f in range(g["D"]):
+            e = torch.zeros_like(th)
+            e[:, f] = eps
+            fd += (od.velocity(th + e, x, t)[:, f] - od.velocity(th - e, x, t)[:, f]) / (2 * eps)
+    assert (fd - g["div"].double()).abs().max() <= 2e-5 * g["div"].abs().max() + 1e-6
+
+
+def test_oracle_log_prob_is_a_density_in_one_dimension():
+    """theta-dim 1: exp(log_prob) of the oracle's probability-flow ODE integrates to one over theta (trapezoid on a
+    wide grid) -- the sign of the log-det term and the direction of integration are right."""
+    torch.manual_seed(5)
+    o = FMPEOracle(1, 2, H=32, L=2).double()
+    with torch.no_grad():
+        for p in o.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    grid = torch.linspace(-12.0, 12.0, 2401, dtype=torch.float64)[:, None]
+    lp = o.log_prob(grid, torch.tensor([[0.3, -0.2]], dtype=torch.float64), steps=60)
+    mass = torch.trapezoid(lp.exp(), grid[:, 0]).item()
+    assert abs(mass - 1.0) <= 2e-3, mass
+
+
 def test_early_stopping_rule_matches_reference_trainer():
     """FMPE._converged replayed on the sequences tools/make_golden_fmpe_trainer.py fed to sbi's real
     VectorFieldTrainer._converged, in the reference loop order: identical decisions, counters and best losses."""

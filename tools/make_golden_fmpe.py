@@ -4,7 +4,8 @@
 (sbi/neural_nets/net_builders/vector_field_nets.py:136-339, 610-719; estimators/flowmatching_estimator.py).
 Stored per case: the state_dict (all parameters perturbed so the zero-initialised output layer and the unit
 LayerNorm gains are exercised), inputs, the noise the loss drew, per-row losses, d mean-loss / d parameters,
-and the velocity `forward()` returns at a few (theta_t, t) for one observation."""
+the velocity `forward()` returns at a few (theta_t, t) for one observation, and the exact Jacobian trace of
+`ode_fn` there (the integrand of the log-density along the probability-flow ODE)."""
 
 import os
 import sys
@@ -48,7 +49,16 @@ def main():
         theta_q = torch.randn(tq.shape[0], D) * 1.5
         with torch.no_grad():
             vel = est(theta_q, x[:1], tq)
-        cases[name] = dict(D=D, C=C, kw=kw, state=est.state_dict(), theta=theta[:n].clone(), x=x[:n].clone(),
+        # exact trace of d ode_fn / d input: what zuko's FreeFormJacobianTransform(exact=True) integrates for
+        # VectorFieldPosterior.log_prob (zuko itself is not installed here: the trace is taken with plain autograd,
+        # one reverse pass per theta dim, on the real estimator's ode_fn)
+        thq = theta_q.clone().requires_grad_(True)
+        vq = est.ode_fn(thq, x[:1], tq)
+        div = torch.zeros(tq.shape[0])
+        for f in range(D):
+            (gf,) = torch.autograd.grad(vq[:, f].sum(), thq, retain_graph=True)
+            div += gf[:, f]
+        cases[name] = dict(div=div.detach(), D=D, C=C, kw=kw, state=est.state_dict(), theta=theta[:n].clone(), x=x[:n].clone(),
                            times=times, noise=noise, losses=losses.detach(), grads=grads, tq=tq, theta_q=theta_q,
                            vel=vel)
         print(name, "loss", losses[:3].tolist(), "params", sum(p.numel() for p in est.parameters()))
