@@ -8,8 +8,8 @@ Contract (task statement): `python bench.py --gpus N --steps K --warmup W` print
   `python bench.py --gpus N` with N > 1 re-launches ITSELF the same way (`launch_ranks`).  A world size that
   differs from `--gpus`, or fewer visible devices than ranks, is an error -- never a silent 1-GPU run.
 * A "step" of the headline `train` leg is one pass of sbi's training inner loop (trainers/base.py:1150-1193) over
-  one batch: device-side gather of the batch from the resident simulations (fresh permutation, as
-  SubsetRandomSampler) -> weight re-pack -> fused loss forward + backward -> [ONE all-reduce of the flat
+  one batch: device-side gather of the batch from the resident simulations in a fresh pseudo-random order (the
+  role of SubsetRandomSampler; one launch, sbi_amd/utils/shuffle.py) -> weight re-pack -> fused loss forward + backward -> [ONE all-reduce of the flat
   98 025-float gradient over RCCL] -> fused global-norm clip + Adam.  Inputs are resident in HBM.
 * `--scaling weak` (default): 65 536 pairs per GPU per step.  `--scaling strong`: 65 536 pairs per step split N
   ways.  At N > 1 the weak line also carries the strong number as a nested object.
@@ -285,8 +285,9 @@ def roofline(flop_per_unit, units_per_step, steps, dev_ms, kind=None):
 
 # ----------------------------------------------------------------------------------------- legs
 class TrainLeg:
-    """The NPE inner loop on resident simulations: per step a fresh device permutation (drawn eight at a time, as
-    `NPE._epoch_permutations` draws them), the batch gather and the fused step (what `NPE.train` does per minibatch)."""
+    """The NPE inner loop on resident simulations: per step the batch's rows gathered in a fresh pseudo-random order
+    (one launch of the device-side sampler `NPE.train` uses, sbi_amd/utils/shuffle.py: every step is a new epoch's
+    order over the resident training rows) and the fused step (what `NPE.train` does per minibatch)."""
 
     def __init__(self, est, theta_all, x_all, batch, distributed, global_batch):
         from sbi_amd.inference.trainers.fused import FusedTrainStep
@@ -294,19 +295,15 @@ class TrainLeg:
         self.theta_all, self.x_all, self.batch = theta_all, x_all, batch
         self.global_batch = global_batch
         self.stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
-        self.events = []          # (start, end) HIP events around the fused step alone (no permutation / gather)
-        self.perms = []           # drawn eight at a time, as NPE._epoch_permutations does (one batched argsort)
+        self.events = []          # (start, end) HIP events around the fused step alone (no sampler / gather)
+        from sbi_amd.utils.shuffle import ShuffledGather
 
-    def _perm(self):
-        if not self.perms:
-            n, dev = self.theta_all.shape[0], self.theta_all.device
-            keys = torch.randint(0, 2**31 - 1, (8, n), device=dev, dtype=torch.int32)
-            self.perms.extend(keys.argsort(dim=1).unbind(0))
-        return self.perms.pop()
+        self.sampler = ShuffledGather(theta_all, x_all, None, seed=20260924)
+        self.calls = 0
 
     def __call__(self):
-        idx = self._perm()[: self.batch]
-        th, xx = self.theta_all.index_select(0, idx), self.x_all.index_select(0, idx)
+        th, xx = self.sampler.batch(self.calls, 0, self.batch)
+        self.calls += 1
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self.stepper.step(th, xx, global_batch=self.global_batch)
@@ -689,7 +686,7 @@ def main(argv=None):
         leg = TrainLeg(est, th_all, x_all, B, distributed, GB)
         wall, dev_ms = timed(leg, args.steps, args.warmup, device, dist)
         # roofline: the fused step's kernels only (pack, forward, T backward launches, reduce, [all-reduce], clip+Adam),
-        # HIP events on the launch stream around every step; the permutation / gather kernels are in `value` only
+        # HIP events on the launch stream around every step; the sampler's gather kernel is in `value` only
         fused_ms = leg.fused_ms(args.steps)
         results["train"] = {"value": GB * args.steps / wall, "unit": "pairs/s",
                             "ms_per_step": wall / args.steps * 1e3,
@@ -710,7 +707,7 @@ def main(argv=None):
     if args.mode in ("both", "train") and world == 1 and not distributed:
         # The latency regime (cooperative kernels, csrc/nsf_coop.h): sbi's default training_batch_size = 200
         # (npe_base.py:301-316) and the per-GPU share of SURVEY 8(e)'s partitioning -- the 65 536-pair batch split over
-        # 8 GPUs = 8 192 pairs per GPU per step.  Same inner loop as the headline leg (permutation, gather, fused step).
+        # 8 GPUs = 8 192 pairs per GPU per step.  Same inner loop as the headline leg (shuffled gather, fused step).
         small_obj = {}
         for b in (200, 8192):
             leg_b = TrainLeg(est, th_all, x_all, b, False, b)
@@ -742,7 +739,7 @@ def main(argv=None):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: NPE + NSF theta-dim {D}, x-dim {C}, {N_SIMS} simulations "
                                    f"(90 000-row training split resident in HBM), batch {args.batch} {per}, synthetic "
-                                   f"linear-Gaussian; step = device permutation + batch gather + fused NPE training "
+                                   f"linear-Gaussian; step = shuffled batch gather (device sampler) + fused NPE training "
                                    f"step (pack, loss fwd+bwd, grad all-reduce, clip+Adam)"
                        if head == "train" else
                        f"NSF log_prob, theta-dim {D}, x-dim {C}, batch {args.batch} {per}",

@@ -147,6 +147,16 @@ int sbi_amd_nsf_train_backward(const sbi_amd_nsf_config* cfg, const float* param
                                const float* row_weight, float uniform_weight, float* grad_out,
                                float* grad_theta_out, float* grad_x_out, float* workspace, void* stream);
 
+/* The training loop's minibatch sampler (csrc/shuffle.hip): rows offset .. offset + count of a fresh pseudo-random
+ * order of n_perm training rows, gathered in ONE launch: a_out[i] = a[base_idx[pi(offset + i)]] (rows of da floats),
+ * b_out likewise; idx_out (int64) receives the source rows.  Replaces SubsetRandomSampler + DataLoader collation of
+ * trainers/base.py:541-560 (torch.randperm of the training split per epoch, drop_last batches).  pi is a keyed
+ * permutation of [0, n_perm) (6-round Feistel + cycle walking), one `key` per epoch; base_idx NULL = identity (the
+ * split is the first n_perm rows); any of a_out / b_out / idx_out may be NULL. */
+int sbi_amd_shuffled_gather(const float* a, int32_t da, const float* b, int32_t db, const int64_t* base_idx,
+                            int64_t n_perm, uint64_t key, int64_t offset, int64_t count, float* a_out, float* b_out,
+                            int64_t* idx_out, void* stream);
+
 /* Fused global-norm clip + Adam on the flat buffer: replaces
  * clip_grad_norm_(max_norm) + torch.optim.Adam.step (trainers/base.py:1181-1187,
  * :1097).  `step` is the 1-based step count; max_norm <= 0 disables clipping.
@@ -181,7 +191,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 107
+#define SBI_AMD_NSF_ABI_VERSION 108
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

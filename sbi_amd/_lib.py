@@ -7,7 +7,7 @@ made with tensors that are not on a ROCm device, the call raises.
 from __future__ import annotations
 
 import ctypes
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 from typing import Optional
 
 import torch
@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 107    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 108    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -97,6 +97,11 @@ _SIGNATURES = {
     "sbi_amd_adam_clip_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
+         c_void_p, c_void_p],
+    ),
+    "sbi_amd_shuffled_gather": (
+        c_int,
+        [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_int64, c_int64, c_void_p, c_void_p,
          c_void_p, c_void_p],
     ),
     "sbi_amd_mcmc_slice_tick": (

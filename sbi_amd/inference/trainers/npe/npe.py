@@ -421,17 +421,40 @@ class PosteriorEstimatorTrainer:
         perm_of = self._epoch_permutations()
         import os as _os
 
+        # Fused MLE steps on a ROCm device: the epoch's order is never materialised -- one launch per minibatch
+        # gathers the batch's rows in a fresh keyed pseudo-random order of the training split (utils/shuffle.py;
+        # SubsetRandomSampler + collation of base.py:541-560).  The atomic loss (it also needs the prior masks of the
+        # batch) and the autograd path keep the index tensors.
+        sampler = None
+        if fused and not atomic:
+            from sbi_amd.utils.shuffle import ShuffledGather
+
+            sg_seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
+            sampler = ShuffledGather(theta_d, x_d, train_idx, sg_seed)
+
+        def my_range(lo: int, count: int):     # this rank's contiguous share of rows lo .. lo + count of an order
+            if world == 1:
+                return lo, count
+            per = (count + world - 1) // world
+            a = min(rank * per, count)
+            return lo + a, min((rank + 1) * per, count) - a
+
         def launch_epoch(e: int) -> dict:
             """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here
             waits for the device.  Returns the record `finish_epoch` turns into the epoch's host bookkeeping."""
             rec = {"epoch": e, "t0": time.time()}
             net.train()
-            order = perm_of(n_train)   # SubsetRandomSampler
-            epoch_idx = train_idx[order]
             sums = torch.zeros(2, device=self._device)
-            for b in range(n_train_batches):
-                idx = my_slice(epoch_idx[b * B : (b + 1) * B])
-                sums[0] += batch_losses(idx, True, B).sum()
+            if sampler is not None:
+                for b in range(n_train_batches):
+                    th, xx = sampler.batch(e, *my_range(b * B, B))
+                    sums[0] += self._stepper.step(th, xx, global_batch=B).sum()
+            else:
+                order = perm_of(n_train)   # SubsetRandomSampler
+                epoch_idx = train_idx[order]
+                for b in range(n_train_batches):
+                    idx = my_slice(epoch_idx[b * B : (b + 1) * B])
+                    sums[0] += batch_losses(idx, True, B).sum()
             if pipelined:
                 rec["snap"] = self._stepper.snapshot()      # weights + optimizer state after this epoch's steps
             net.eval()
