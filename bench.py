@@ -399,6 +399,26 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
         sample_obj = {"metric": "FMPE posterior.sample draws/sec (ODE, atol 1e-6 rtol 1e-5)", "value": n_draw / dt,
                       "unit": "draws/s", "draws_per_call": n_draw, "ms_per_call": dt * 1e3,
                       "velocity_evals_per_call": calls[0] / reps}
+        # log-density of the same flow (VectorFieldPosterior.log_prob): the augmented ODE with the exact Jacobian
+        # trace, every right-hand side one launch of the velocity + divergence kernel over all rows
+        n_lp = 8192
+        th_lp = post.sample((n_lp,), x=x_f[:1])
+        real2 = fm.ode_fn_and_divergence
+        calls[0] = 0
+        fm.ode_fn_and_divergence = lambda *a_, **k_: (calls.__setitem__(0, calls[0] + 1), real2(*a_, **k_))[1]
+        post.log_prob(th_lp, x=x_f[:1])
+        torch.cuda.synchronize()
+        calls[0] = 0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lp_ = post.log_prob(th_lp, x=x_f[:1])
+        torch.cuda.synchronize()
+        dt_lp = (time.perf_counter() - t0) / reps
+        fm.ode_fn_and_divergence = real2
+        sample_obj["log_prob"] = {"metric": "FMPE posterior.log_prob evals/sec (augmented ODE, exact trace, atol 1e-6 "
+                                            "rtol 1e-5)", "value": n_lp / dt_lp, "unit": "evals/s", "rows": n_lp,
+                                  "theta_dim": DF, "ms_per_call": dt_lp * 1e3,
+                                  "rhs_evals_per_call": calls[0] / reps, "finite": bool(torch.isfinite(lp_).all())}
     # BASELINE configs[4] through the trainer itself: FMPE.train() on 10^6 simulations (theta-dim 50), batch 65 536,
     # validation at 10 fixed times, EMA / early-stopping bookkeeping and the per-epoch host read included
     loop_obj = None

@@ -137,14 +137,28 @@ class FMPE(PosteriorEstimatorTrainer):
             return idx[rank * per : min((rank + 1) * per, idx.numel())]
 
         perm_of = self._epoch_permutations()
+        # fused steps on a ROCm device: the epoch's order is never materialised, one launch per minibatch gathers its
+        # rows in a fresh keyed pseudo-random order of the training split (utils/shuffle.py, as in NPE.train)
+        sampler = None
+        if fused and torch.device(self._device).type == "cuda":
+            from sbi_amd.utils.shuffle import ShuffledGather
+
+            sg_seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
+            sampler = ShuffledGather(theta_d, x_d, train_idx, sg_seed)
         while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
             t0 = time.time()
-            order = perm_of(n_train)
-            epoch_idx = train_idx[order]
+            if sampler is None:
+                order = perm_of(n_train)
+                epoch_idx = train_idx[order]
             sums = torch.zeros(2, device=self._device)
             for b in range(n_train_batches):
-                idx = my_slice(epoch_idx[b * B : (b + 1) * B])
-                th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)
+                if sampler is not None:
+                    per = (B + world - 1) // world
+                    lo = min(rank * per, B)
+                    th, xx = sampler.batch(self.epoch, b * B + lo, min((rank + 1) * per, B) - lo)
+                else:
+                    idx = my_slice(epoch_idx[b * B : (b + 1) * B])
+                    th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)
                 rw = calibration_kernel(xx).float() if calibration_kernel is not None else None
                 if fused:
                     losses = self._stepper.loss_and_grad(th, xx, global_batch=B, row_weight=rw)
