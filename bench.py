@@ -472,6 +472,8 @@ def main(argv=None):
     ap.add_argument("--npe-epochs", type=int, default=200, help="epochs of the NPE.train() (M2) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-sampling", action="store_true", help="fmpe mode: no ODE-sampling leg (profiling passes)")
+    ap.add_argument("--no-small-batch", action="store_true",
+                    help="train leg without the batch-200 / 8 192 object (traffic passes: bytes per step of the headline)")
     ap.add_argument("--no-rccl-leg", action="store_true",
                     help="N = 1: skip the self-launched 1-rank RCCL run of the train leg (`rccl_1rank` object)")
     args = ap.parse_args(argv)
@@ -724,7 +726,7 @@ def main(argv=None):
                           "roofline": roofline(F_TRAIN, Bs, args.steps, leg_s.fused_ms(args.steps))}
 
     small_obj = None
-    if args.mode in ("both", "train") and world == 1 and not distributed:
+    if args.mode in ("both", "train") and world == 1 and not distributed and not args.no_small_batch:
         # The latency regime (cooperative kernels, csrc/nsf_coop.h): sbi's default training_batch_size = 200
         # (npe_base.py:301-316) and the per-GPU share of SURVEY 8(e)'s partitioning -- the 65 536-pair batch split over
         # 8 GPUs = 8 192 pairs per GPU per step.  Same inner loop as the headline leg (shuffled gather, fused step).

@@ -443,6 +443,9 @@ class PosteriorEstimatorTrainer:
             """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here
             waits for the device.  Returns the record `finish_epoch` turns into the epoch's host bookkeeping."""
             rec = {"epoch": e, "t0": time.time()}
+            if pipelined:      # the epoch's own device time (the host clock would also count the NEXT epoch's enqueue)
+                rec["ev0"] = torch.cuda.Event(enable_timing=True)
+                rec["ev0"].record()
             net.train()
             sums = torch.zeros(2, device=self._device)
             if sampler is not None:
@@ -468,7 +471,7 @@ class PosteriorEstimatorTrainer:
             if pipelined:
                 rec["host"] = torch.empty(2, dtype=sums.dtype, pin_memory=True)
                 rec["host"].copy_(sums, non_blocking=True)
-                rec["event"] = torch.cuda.Event()
+                rec["event"] = torch.cuda.Event(enable_timing=True)
                 rec["event"].record()
             else:
                 rec["host"] = sums.cpu()                        # the one sync of the epoch
@@ -479,12 +482,22 @@ class PosteriorEstimatorTrainer:
                 rec["event"].synchronize()
             host = rec["host"]
             if not torch.isfinite(host).all():
+                if "event" in rec and last_good["snap"] is not None:
+                    # pipelined loop: the losses are read one epoch late, so the live weights have already been
+                    # stepped on this epoch's (and possibly the speculative epoch's) non-finite gradients: put the
+                    # weights and optimizer state of the last finite epoch back before giving up
+                    torch.cuda.synchronize(self._device)
+                    self._stepper.net.flat_params.data.copy_(last_good["snap"]["params"])
+                    self._stepper.restore_optimizer(last_good["snap"])
                 raise AssertionError("NaN/Inf present in NPE loss.")
+            if "snap" in rec:
+                last_good["snap"] = rec["snap"]
             train_loss = float(host[0]) / (n_train_batches * B)
             self._val_loss = float(host[1]) / (n_val_batches * Bv)
             self._summary["training_loss"].append(train_loss)
             self._summary["validation_loss"].append(self._val_loss)
-            self._summary["epoch_durations_sec"].append(time.time() - rec["t0"])
+            self._summary["epoch_durations_sec"].append(
+                rec["ev0"].elapsed_time(rec["event"]) * 1e-3 if "ev0" in rec else time.time() - rec["t0"])
             self.epoch = rec["epoch"] + 1
             if self._show_progress_bars and rank == 0:
                 print("\r", f"Training neural network. Epochs trained: {self.epoch}", end="")
@@ -495,7 +508,16 @@ class PosteriorEstimatorTrainer:
         # weights + optimizer state after every epoch are snapshotted on the device, `_converged` scores epoch e with
         # that snapshot, and if it says stop, the speculative epoch e+1 is thrown away (its summary entries are never
         # written, the optimizer state is rolled back, the best weights restored as always).
+        # Where this differs from the eager loop (SBI_AMD_EAGER_EPOCH_SYNC=1) and from the reference's loop:
+        #  * a speculative epoch is always enqueued, so whatever it draws (the contrastive indices of the atomic loss,
+        #    the key of its sampler order) is consumed even when the epoch is discarded: torch's RNG state after
+        #    train() is not the eager loop's;
+        #  * the NaN / Inf check of epoch e fires after epoch e + 1 was enqueued: the weights and the optimizer state
+        #    are put back to the last epoch whose losses were finite before the AssertionError is raised;
+        #  * `epoch_durations_sec` are device times between events around an epoch's own launches (the host clock
+        #    would include the next epoch's enqueue).
         pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"
+        last_good = {"snap": None}
         if not pipelined:
             while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
                 finish_epoch(launch_epoch(self.epoch))

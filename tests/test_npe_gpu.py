@@ -179,3 +179,39 @@ def test_pipelined_epoch_loop_takes_the_eager_loops_decisions(stop_kind, monkeyp
     assert torch.equal(a._stepper.exp_avg, b._stepper.exp_avg) and a._stepper.step_count == b._stepper.step_count
     if stop_kind == "early_stopping":
         assert a.summary["epochs_trained"][-1] < 200
+
+
+def test_pipelined_loop_puts_back_the_last_finite_epoch_before_raising_on_nan(monkeypatch):
+    """The losses of epoch e are read after epoch e + 1 was enqueued: when they turn out non-finite, the weights and
+    the optimizer state must be the ones after the last epoch whose losses were finite, not whatever the non-finite
+    steps left behind."""
+    from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+    dim, n = 2, 400
+    torch.manual_seed(0)
+    prior = MultivariateNormal(torch.zeros(dim, device="cuda"), torch.eye(dim, device="cuda"))
+    theta = prior.sample((n,)).cpu()
+    x = linear_gaussian(theta, -1.0 * torch.ones(dim), 0.3 * torch.eye(dim))
+    real_step = FusedTrainStep.step
+    seen = {"calls": 0, "good": None}
+
+    def step(self, th, xx, **kw):      # one training batch per epoch: call k is epoch k - 1
+        seen["calls"] += 1
+        losses = real_step(self, th, xx, **kw)
+        if seen["calls"] <= 3:
+            seen["good"] = (self.net.flat_params.data.clone(), self.exp_avg.clone(), self.step_count)
+            return losses
+        self.net.flat_params.data.fill_(float("nan"))
+        return losses * float("nan")
+
+    monkeypatch.setattr(FusedTrainStep, "step", step)
+    inf = NPE(prior=prior, density_estimator=NSFConfig(num_transforms=2), device="cuda", show_progress_bars=False)
+    with pytest.raises(AssertionError, match="NaN/Inf"):
+        inf.append_simulations(theta, x).train(training_batch_size=360, max_num_epochs=50)
+    assert seen["calls"] >= 4
+    params, exp_avg, steps = seen["good"]
+    assert torch.isfinite(inf._stepper.net.flat_params).all()
+    assert torch.equal(inf._stepper.net.flat_params.data, params)
+    assert torch.equal(inf._stepper.exp_avg, exp_avg) and inf._stepper.step_count == steps
+    assert len(inf.summary["training_loss"]) == 3        # epochs 0..2 were recorded, the non-finite one was not
+    assert all(d > 0 for d in inf.summary["epoch_durations_sec"])
