@@ -252,7 +252,8 @@ def load_traffic():
     from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (gfx950
     correction of the guide applied: FETCH_SIZE x 2).  bench.py cannot profile itself, so the line carries the
     committed measurement together with its source file and the commit it was measured at."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")), key=os.path.getmtime)
+    # (newest = last in name order, profiles/<round tag>_traffic.json: file times do not survive a checkout)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
     if not files:
         return None
     try:
