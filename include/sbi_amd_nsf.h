@@ -53,7 +53,7 @@ extern "C" {
 typedef struct sbi_amd_nsf_config {
   int32_t D;          /* theta features (>= 2)                 flow.py:393  x_numel          */
   int32_t C;          /* embedded condition features           flow.py:394  y_numel          */
-  int32_t H;          /* hidden_features (<= 64)               flow.py:343                   */
+  int32_t H;          /* hidden_features (<= 128; > 64: the wide cooperative kernels at every batch size) flow.py:343 */
   int32_t K;          /* num_bins (4,5,8,10,16)                flow.py:345                   */
   int32_t T;          /* num_transforms (<= 16)                flow.py:344                   */
   int32_t NB;         /* num_blocks of the ResidualNet (<= 4)  flow.py:349                   */

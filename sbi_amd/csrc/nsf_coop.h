@@ -42,7 +42,8 @@ enum {
   CO_K_PLAIN_T,    // W[k][m]
   CO_K_W0T,        // initial layer transposed, identity columns only: m = identity slot, k = hidden
   CO_K_U, CO_K_L, CO_K_UT, CO_K_LT,
-  CO_K_CTX_T       // context columns of a layer, transposed: m = context feature, k = hidden (d loss / d embedded x)
+  CO_K_CTX_T,      // context columns of a layer, transposed: m = context feature, k = hidden (d loss / d embedded x)
+  CO_K_UI, CO_K_LI // explicit inverses U^-1, L^-1 (sampling direction of the wide kernels)
 };
 struct CoBias {     // D-fragment-ordered bias block: [mtile][16], element 4 g + r <-> row 16 mt + 4 r + g
   int off, mtiles, kind, lin;   // kind: 0 plain, 1 final layer (per (dim, tile)), 2 LULinear bias
@@ -52,6 +53,7 @@ struct CoShape {    // per mask parity
   CoMat W0, WC[NSF_MAX_NB], W1[NSF_MAX_NB], W2[NSF_MAX_NB], WF, U, L;           // forward
   CoMat WFT, W1T[NSF_MAX_NB], W2T[NSF_MAX_NB], W0T, UT, LT;                      // backward
   CoMat WCT[NSF_MAX_NB], W0CT;                                                   // backward, d loss / d context
+  CoMat UI, LI;                                                                  // sampling direction (wide nets only)
   CoBias b0, bc[NSF_MAX_NB], b1[NSF_MAX_NB], b2[NSF_MAX_NB], bf, blu;
   int o_bias;       // first float behind the matrices (256-aligned): bias blocks, then
   int o_ld;         // the slot holding sum_i log U_ii
@@ -67,6 +69,7 @@ struct CoShape {    // per mask parity
 struct CoopPlan {
   CoShape sh[2];
   int img_floats;           // floats per transform in the coop image
+  int MT;                   // hidden m-tiles per wave: 1 (hidden <= 64), 2 (hidden <= 128: nsf_coop_wide_kernel.h)
   int NT, R, RS;            // row tiles per workgroup, rows = 16 NT, row stride of the transposed tiles
   int ZS;                   // row stride of the state rows (odd)
   int PSW, DSTR;            // spline-parameter staging: floats per (row, dim), per row
@@ -88,10 +91,12 @@ struct CoKP {      // per mask parity
   int nnt0;        // n-tiles of d W0 (conditioner input + bias column)
   int dw_tail;     // slab offset of the LULinear block
   int w0, wc0, w10, w20, wf, u, l, wft, w1t0, w2t0, w0t, ut, lt, wct0, w0ct;   // image offsets (block b: + b * stride)
+  int ui, li;      // U^-1, L^-1 (wide nets)
   int b0, bc0, b10, b20, bf, blu, ld;
 };
 struct CoK {
   int D, C, H, NB, T, P, KCQ;
+  int HT, HQ;                  // hidden m-tiles (4 or 8) and K-quads of a hidden-K matrix
   int sA, sT, sC, sB;          // per-block strides of [WC W1 W2], [W1T W2T], [WCT] and of the bias blocks [bc b1 b2]
   int img_floats;
   int ZS, RS, PSW, DSTR;

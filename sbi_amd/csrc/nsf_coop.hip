@@ -5,22 +5,29 @@
 #include <stdlib.h>
 #define NSF_COOP_MAIN_TU
 #include "nsf_train_kernel.h"
-#include "nsf_coop_kernel.h"
+#include "nsf_coop_wide_kernel.h"
 #include "debug_env.h"
 
 template int co_fwd_k<10>(const NsfPlan&, const CoopPlan&, const CoFwdArgs&, hipStream_t);
 template int co_bwd_k<10>(const NsfPlan&, const CoopPlan&, const CoBwdArgs&, hipStream_t);
+template int co_inv_k<10>(const NsfPlan&, const CoopPlan&, const float*, const float*, const float*, const float*,
+                          long long, long long, float*, float*, hipStream_t);
 #define CO_EXTERN(KK)                                                                                       \
   extern template int co_fwd_k<KK>(const NsfPlan&, const CoopPlan&, const CoFwdArgs&, hipStream_t);        \
-  extern template int co_bwd_k<KK>(const NsfPlan&, const CoopPlan&, const CoBwdArgs&, hipStream_t);
+  extern template int co_bwd_k<KK>(const NsfPlan&, const CoopPlan&, const CoBwdArgs&, hipStream_t);        \
+  extern template int co_inv_k<KK>(const NsfPlan&, const CoopPlan&, const float*, const float*, const float*,  \
+                                   const float*, long long, long long, float*, float*, hipStream_t);
 CO_EXTERN(4) CO_EXTERN(5) CO_EXTERN(8) CO_EXTERN(16)
 
 // Does an n-row call take the cooperative kernels?  `training`: the stash-writing forward + backward pair.
 // SBI_AMD_ABLATE bit 16384 switches the path off (A/B measurements, tests of the throughput kernels at small n).
 bool coop_applies(const sbi_amd_nsf_config* cfg, int64_t n, bool training, NsfPlan* pl, CoopPlan* cp) {
-  if (n < 1 || n > coop_max_rows() || (sbi_amd_dbg_ablate() & 16384)) return false;
+  if (n < 1) return false;
   int rc = nsf_build_plan(cfg, 1, pl);
   if (rc && rc != SBI_AMD_E_LDS) return false;   // (E_LDS speaks about the throughput kernels' weight image)
+  // hidden > 64: the wide cooperative kernels are the ONLY path, at every batch size and whatever the switches say
+  const bool wide = pl->H > 16 * NSF_HT;
+  if (!wide && (n > coop_max_rows() || (sbi_amd_dbg_ablate() & 16384))) return false;
   return coop_build_plan(*pl, n, 0, training, cp) == 0;
 }
 // Is there a cooperative image for this configuration at all (any n)?  Deliberately independent of the row
@@ -57,6 +64,20 @@ static int co_dispatch_fwd(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, con
   }
   return SBI_AMD_E_UNSUPPORTED;
 }
+int coop_sample(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
+                const float* zstats, const float* noise, const float* x, int64_t n, int64_t x_rows, float* theta_out,
+                float* logabsdet_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (cfg->K) {
+    case 4: return co_inv_k<4>(pl, cp, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, st);
+    case 5: return co_inv_k<5>(pl, cp, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, st);
+    case 8: return co_inv_k<8>(pl, cp, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, st);
+    case 10: return co_inv_k<10>(pl, cp, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, st);
+    case 16: return co_inv_k<16>(pl, cp, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, st);
+  }
+  return SBI_AMD_E_UNSUPPORTED;
+}
+
 static int co_dispatch_bwd(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const CoBwdArgs& a,
                            hipStream_t st) {
   switch (cfg->K) {

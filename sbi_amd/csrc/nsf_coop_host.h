@@ -11,6 +11,9 @@ int64_t coop_workspace_floats(const NsfPlan& pl, const CoopPlan& cp, int64_t n);
 int coop_log_prob(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
                   const float* zstats, const float* theta, const float* x, int64_t n, int64_t x_rows, float* logp,
                   float* noise, void* stream);
+int coop_sample(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
+                const float* zstats, const float* noise, const float* x, int64_t n, int64_t x_rows, float* theta_out,
+                float* logabsdet_out, void* stream);
 int coop_train_forward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
                        const float* zstats, const float* theta, const float* x, int64_t n, int64_t x_rows,
                        float* logp_out, float* workspace, void* stream);

@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "nsf_train_kernel.h"
-#include "nsf_coop_kernel.h"
+#include "nsf_coop_wide_kernel.h"
 
 template int co_fwd_k<16>(const NsfPlan&, const CoopPlan&, const CoFwdArgs&, hipStream_t);
 template int co_bwd_k<16>(const NsfPlan&, const CoopPlan&, const CoBwdArgs&, hipStream_t);
+template int co_inv_k<16>(const NsfPlan&, const CoopPlan&, const float*, const float*, const float*, const float*,
+                          long long, long long, float*, float*, hipStream_t);

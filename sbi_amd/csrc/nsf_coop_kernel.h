@@ -23,6 +23,31 @@ __device__ __forceinline__ float co_lu_entry(const float* __restrict__ lu, int D
   return k == i ? 1.f : 0.f;
 }
 
+// entry (i, k) of U^-1 (upper) or L^-1 by substitution down / up column k, in double (D <= 16)
+__device__ __forceinline__ float co_lu_inv_entry(const float* __restrict__ lu, int D, float eps, bool upper, int i,
+                                                 int k) {
+  if (i >= D || k >= D) return 0.f;
+  double x[16];
+  if (!upper) {                 // L unit lower triangular: x_k = 1, x_i = - sum_{k <= j < i} L_ij x_j
+    if (i < k) return 0.f;
+    x[k] = 1.0;
+    for (int r = k + 1; r <= i; ++r) {
+      double a = 0.0;
+      for (int j = k; j < r; ++j) a -= (double)co_lu_entry(lu, D, eps, false, r, j) * x[j];
+      x[r] = a;
+    }
+    return (float)x[i];
+  }
+  if (i > k) return 0.f;        // U upper triangular: x_k = 1 / U_kk, x_i = - (sum_{i < j <= k} U_ij x_j) / U_ii
+  x[k] = 1.0 / (double)co_lu_entry(lu, D, eps, true, k, k);
+  for (int r = k - 1; r >= i; --r) {
+    double a = 0.0;
+    for (int j = r + 1; j <= k; ++j) a -= (double)co_lu_entry(lu, D, eps, true, r, j) * x[j];
+    x[r] = a / (double)co_lu_entry(lu, D, eps, true, r, r);
+  }
+  return (float)x[i];
+}
+
 __device__ __forceinline__ float co_mat_value(const CoMat& m, const NsfPlan& pl, const ShapeDesc& S, const CoShape& c,
                                               const float* __restrict__ gl, int rel) {
   const int blk = rel >> 8, lane = (rel >> 2) & 63, r = rel & 3;
@@ -76,6 +101,8 @@ __device__ __forceinline__ float co_mat_value(const CoMat& m, const NsfPlan& pl,
     case CO_K_L: return co_lu_entry(gl + S.g_lu, pl.D, pl.lu_eps, false, mi, k);
     case CO_K_UT: return co_lu_entry(gl + S.g_lu, pl.D, pl.lu_eps, true, k, mi);
     case CO_K_LT: return co_lu_entry(gl + S.g_lu, pl.D, pl.lu_eps, false, k, mi);
+    case CO_K_UI: return co_lu_inv_entry(gl + S.g_lu, pl.D, pl.lu_eps, true, mi, k);
+    case CO_K_LI: return co_lu_inv_entry(gl + S.g_lu, pl.D, pl.lu_eps, false, mi, k);
   }
   return 0.f;
 }
@@ -113,7 +140,7 @@ nsf_coop_pack_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restric
   const float* gl = params + pl.g_layer[t];
   float* img = cimg + (long long)t * cp.img_floats;
   const CoMat* mats = &c.W0;                      // the CoMat members are laid out contiguously ...
-  constexpr int NMAT = 9 + 6 * NSF_MAX_NB;      // W0 WC[] W1[] W2[] WF U L | WFT W1T[] W2T[] W0T UT LT | WCT[] W0CT
+  constexpr int NMAT = 11 + 6 * NSF_MAX_NB;     // W0 WC[] W1[] W2[] WF U L | WFT W1T[] W2T[] W0T UT LT | WCT[] W0CT | UI LI
   const CoBias* bias = &c.b0;                     // ... and so are the CoBias members
   constexpr int NBIAS = 3 + 3 * NSF_MAX_NB;
   const int nblk = cp.img_floats >> 8;
@@ -1224,28 +1251,3 @@ static int co_launch_bwd(const CoK& k, const CoopPlan& cp, const CoBwdArgs& a, h
   return (int)hipGetLastError();
 }
 
-// one translation unit per bin count (parallel build): nsf_coop.hip holds K = 10, nsf_coop_k{4,5,8,16}.hip the rest
-template <int K>
-int co_fwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
-  CoK k;
-  if (cp.NT == 2 && coop_lean_forward()) {
-    // more than 4096 rows: the forward pass runs as one-tile workgroups, two to a CU (the LEAN instantiation, <= 256
-    // registers) -- 17 % faster than the two-tile workgroups the backward pass keeps for its halved partial slabs.
-    // The stash and the per-transform states are laid out per 16-row tile / per row: independent of the workgroup shape.
-    CoopPlan cf;
-    int rc = coop_build_plan(pl, a.n, 1, false, &cf);
-    if (rc) return rc;
-    coop_make_consts(pl, cf, &k);
-    return pl.KSH == 13 ? co_launch_fwd<K, 13, 1, true>(k, cf, a, st) : co_launch_fwd<K, 16, 1, true>(k, cf, a, st);
-  }
-  coop_make_consts(pl, cp, &k);
-  if (pl.KSH == 13) return cp.NT == 2 ? co_launch_fwd<K, 13, 2, false>(k, cp, a, st) : co_launch_fwd<K, 13, 1, false>(k, cp, a, st);
-  return cp.NT == 2 ? co_launch_fwd<K, 16, 2, false>(k, cp, a, st) : co_launch_fwd<K, 16, 1, false>(k, cp, a, st);
-}
-template <int K>
-int co_bwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {
-  CoK k;
-  coop_make_consts(pl, cp, &k);
-  if (pl.KSH == 13) return cp.NT == 2 ? co_launch_bwd<K, 13, 2>(k, cp, a, st) : co_launch_bwd<K, 13, 1>(k, cp, a, st);
-  return cp.NT == 2 ? co_launch_bwd<K, 16, 2>(k, cp, a, st) : co_launch_bwd<K, 16, 1>(k, cp, a, st);
-}

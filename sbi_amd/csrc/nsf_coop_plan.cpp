@@ -47,9 +47,12 @@ static void add_bias(CoBias* b, int* off, int mtiles, int kind, int lin) {
 int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, CoopPlan* cp) {
   memset(cp, 0, sizeof(*cp));
   // shapes: residual-net conditioner (theta-dim >= 2), LULinear as one 16 x 16 MFMA tile, context K-steps in registers
-  if (pl.ctx_mlp || pl.D < 2 || pl.D > 16 || pl.C > 32 || pl.H > 64 || pl.NB < 1 || pl.NB > NSF_MAX_NB)
+  if (pl.ctx_mlp || pl.D < 2 || pl.D > 16 || pl.C > 32 || pl.H > 16 * NSF_HT_WIDE || pl.NB < 1 || pl.NB > NSF_MAX_NB)
     return SBI_AMD_E_UNSUPPORTED;
-  const int HQ = (pl.KSH + 3) / 4;     // K-quads of a hidden-K layer (13 or 16 K-steps)
+  const bool wide = pl.H > 16 * NSF_HT;            // two hidden m-tiles per wave, eight K-quads (nsf_coop_wide_kernel.h)
+  const int HT = wide ? NSF_HT_WIDE : NSF_HT;
+  const int HQ = (pl.KSH + 3) / 4;     // K-quads of a hidden-K layer (13 or 16 K-steps; wide: 32)
+  if (!wide && pl.shape[0].d_tr * pl.PT > 16) return SBI_AMD_E_UNSUPPORTED;   // final-layer tiles: four per wave
   int img = 0, plp = 0;
   for (int par = 0; par < 2; ++par) {
     const ShapeDesc& S = pl.shape[par];
@@ -57,31 +60,35 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
     c.KCQ = (pl.C + 15) / 16;
     c.nft = S.d_tr * pl.PT;
     int o = 0;
-    add_mat(&c.W0, &o, NSF_HT, c.KCQ + 1, CO_K_W0, 0);
+    add_mat(&c.W0, &o, HT, c.KCQ + 1, CO_K_W0, 0);
     for (int b = 0; b < pl.NB; ++b) {
-      add_mat(&c.WC[b], &o, NSF_HT, c.KCQ, CO_K_PLAIN, 1 + 3 * b);
-      add_mat(&c.W1[b], &o, NSF_HT, HQ, CO_K_PLAIN, 2 + 3 * b);
-      add_mat(&c.W2[b], &o, NSF_HT, HQ, CO_K_PLAIN, 3 + 3 * b);
+      add_mat(&c.WC[b], &o, HT, c.KCQ, CO_K_PLAIN, 1 + 3 * b);
+      add_mat(&c.W1[b], &o, HT, HQ, CO_K_PLAIN, 2 + 3 * b);
+      add_mat(&c.W2[b], &o, HT, HQ, CO_K_PLAIN, 3 + 3 * b);
     }
     add_mat(&c.WF, &o, c.nft, HQ, CO_K_WF, S.fin);
     add_mat(&c.U, &o, 1, 1, CO_K_U, -1);
     add_mat(&c.L, &o, 1, 1, CO_K_L, -1);
-    add_mat(&c.WFT, &o, NSF_HT, S.d_tr * pl.PT, CO_K_WFT, S.fin);
+    add_mat(&c.WFT, &o, HT, S.d_tr * pl.PT, CO_K_WFT, S.fin);
     for (int b = 0; b < pl.NB; ++b) {
-      add_mat(&c.W1T[b], &o, NSF_HT, HQ, CO_K_PLAIN_T, 2 + 3 * b);
-      add_mat(&c.W2T[b], &o, NSF_HT, HQ, CO_K_PLAIN_T, 3 + 3 * b);
+      add_mat(&c.W1T[b], &o, HT, HQ, CO_K_PLAIN_T, 2 + 3 * b);
+      add_mat(&c.W2T[b], &o, HT, HQ, CO_K_PLAIN_T, 3 + 3 * b);
     }
     add_mat(&c.W0T, &o, 1, HQ, CO_K_W0T, 0);
     add_mat(&c.UT, &o, 1, 1, CO_K_UT, -1);
     add_mat(&c.LT, &o, 1, 1, CO_K_LT, -1);
+    if (wide) {
+      add_mat(&c.UI, &o, 1, 1, CO_K_UI, -1);
+      add_mat(&c.LI, &o, 1, 1, CO_K_LI, -1);
+    }
     for (int b = 0; b < pl.NB; ++b) add_mat(&c.WCT[b], &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 1 + 3 * b);
     add_mat(&c.W0CT, &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 0);
     c.o_bias = o;        // (256-aligned: every matrix block is 256 floats) the bias blocks and the log-det slot follow
-    add_bias(&c.b0, &o, NSF_HT, 0, 0);
+    add_bias(&c.b0, &o, HT, 0, 0);
     for (int b = 0; b < pl.NB; ++b) {
-      add_bias(&c.bc[b], &o, NSF_HT, 0, 1 + 3 * b);
-      add_bias(&c.b1[b], &o, NSF_HT, 0, 2 + 3 * b);
-      add_bias(&c.b2[b], &o, NSF_HT, 0, 3 + 3 * b);
+      add_bias(&c.bc[b], &o, HT, 0, 1 + 3 * b);
+      add_bias(&c.b1[b], &o, HT, 0, 2 + 3 * b);
+      add_bias(&c.b2[b], &o, HT, 0, 3 + 3 * b);
     }
     add_bias(&c.bf, &o, c.nft, 1, S.fin);
     add_bias(&c.blu, &o, 1, 2, -1);
@@ -93,7 +100,7 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
     int tb = 0;
     for (int k = 0; k <= S.fin; ++k) {
       const LinDesc& L = S.lin[k];
-      const int mts = k == S.fin ? c.nft : NSF_HT;
+      const int mts = k == S.fin ? c.nft : HT;
       c.dw_tb[k] = tb;
       c.dw_nnt[k] = (L.in + 1 + 15) / 16;
       tb += mts * c.dw_nnt[k];
@@ -112,6 +119,8 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   if (nt_force <= 0) nt_force = nt_env;
   int NT = nt_force > 0 ? nt_force : (n > 4096 ? 2 : 1);
   if (NT > CO_MAX_NT) NT = CO_MAX_NT;
+  if (wide) NT = 1;
+  cp->MT = wide ? 2 : 1;
   cp->NT = NT;
   cp->R = 16 * NT;
   cp->RS = cp->R + 4;
@@ -120,8 +129,8 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   const int d_tr_max = pl.shape[0].d_tr;
   cp->DSTR = d_tr_max * cp->PSW;
   if ((cp->DSTR & 1) == 0) cp->DSTR += 1;
-  cp->s_blk = NSF_HT;
-  cp->s_par = NSF_HT + 4 * NSF_HT * pl.NB;
+  cp->s_blk = HT;
+  cp->s_par = HT + 4 * HT * pl.NB;
   cp->slots = cp->s_par + d_tr_max * pl.PT;
   // conditioner-input tile [z_id ; context ; 1 ; 0 ...]^T: rows cover d W0's n-tiles and, from row d_id, d Wc's
   const int d_id_max = pl.shape[0].d_id > pl.shape[1].d_id ? pl.shape[0].d_id : pl.shape[1].d_id;
@@ -133,11 +142,11 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   cp->o_gzs = o; o += round_up_i(cp->R * cp->ZS + 16, 4);
   cp->o_w = o;   o += cp->R;
   cp->o_pst = o; o += round_up_i(cp->R * cp->DSTR, 4);
-  cp->o_ex = o;  o += 2 * CO_WAVES * NT * 256;
+  cp->o_ex = o;  o += 2 * HT * NT * 256;
   cp->o_ldp = o; o += 8 * cp->R;
   if (training) {
-    cp->o_gt = o;  o += 2 * 64 * cp->RS;
-    cp->o_at = o;  o += 2 * 65 * cp->RS;
+    cp->o_gt = o;  o += 2 * 16 * HT * cp->RS;
+    cp->o_at = o;  o += 2 * (16 * HT + 1) * cp->RS;
     cp->o_ct = o;  o += cp->ct_rows * cp->RS;
     cp->o_lut = o; o += 4 * 17 * cp->RS;
     cp->o_ctx = o; o += 32 * cp->R;
@@ -152,6 +161,8 @@ void coop_make_consts(const NsfPlan& pl, const CoopPlan& cp, CoK* k) {
   memset(k, 0, sizeof(*k));
   k->D = pl.D; k->C = pl.C; k->H = pl.H; k->NB = pl.NB; k->T = pl.T; k->P = pl.P;
   k->KCQ = cp.sh[0].KCQ;
+  k->HT = 4 * cp.MT;
+  k->HQ = cp.sh[0].W1[0].quads;
   const CoShape& c0 = cp.sh[0];
   k->sA = pl.NB > 1 ? c0.W1[1].off - c0.W1[0].off : 0;
   k->sT = pl.NB > 1 ? c0.W1T[1].off - c0.W1T[0].off : 0;
@@ -179,6 +190,7 @@ void coop_make_consts(const NsfPlan& pl, const CoopPlan& cp, CoK* k) {
     q.w0 = c.W0.off; q.wc0 = c.WC[0].off; q.w10 = c.W1[0].off; q.w20 = c.W2[0].off; q.wf = c.WF.off;
     q.u = c.U.off; q.l = c.L.off; q.wft = c.WFT.off; q.w1t0 = c.W1T[0].off; q.w2t0 = c.W2T[0].off;
     q.w0t = c.W0T.off; q.ut = c.UT.off; q.lt = c.LT.off; q.wct0 = c.WCT[0].off; q.w0ct = c.W0CT.off;
+    q.ui = c.UI.off; q.li = c.LI.off;
     q.b0 = c.b0.off; q.bc0 = c.bc[0].off; q.b10 = c.b1[0].off; q.b20 = c.b2[0].off; q.bf = c.bf.off;
     q.blu = c.blu.off; q.ld = c.o_ld;
   }

@@ -69,6 +69,7 @@ extern "C" int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, 
   if (!cfg) return SBI_AMD_E_BADARG;
   NsfPlan pl;
   CoopPlan cp;
+  if (cfg->H > 16 * NSF_HT) return coop_shape_ok(cfg, &pl, &cp) ? 1 : SBI_AMD_E_UNSUPPORTED;   // wide nets: always
   return coop_applies(cfg, n, training != 0, &pl, &cp) ? 1 : 0;
 }
 
@@ -80,7 +81,7 @@ extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const floa
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, 1, &pl);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
-  if (images & 1)
+  if ((images & 1) && pl.img_floats > 0)
     hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
   if (images & 2) {
     rc = coop_pack(cfg, params, packed + nsf_packed_floats(pl), stream);
@@ -109,5 +110,13 @@ extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* 
 extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                   const float* noise, const float* x, int64_t n, int64_t x_rows,
                                   float* theta_out, float* logabsdet_out, void* stream) {
+  if (n > 0 && cfg && cfg->H > 16 * NSF_HT) {     // hidden > 64: the wide cooperative kernel, sampling direction
+    if (!packed || !zstats || !noise || !x || !theta_out || x_rows < 1) return SBI_AMD_E_BADARG;
+    NsfPlan pl;
+    CoopPlan cp;
+    if (!coop_applies(cfg, n, false, &pl, &cp)) return SBI_AMD_E_UNSUPPORTED;
+    return coop_sample(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, noise, x, n, x_rows, theta_out,
+                       logabsdet_out, stream);
+  }
   return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, stream);
 }

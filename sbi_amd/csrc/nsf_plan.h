@@ -15,7 +15,8 @@
 #define NSF_MAX_T 16
 #define NSF_MAX_NB 4
 #define NSF_MAX_LIN (2 + 3 * NSF_MAX_NB)
-#define NSF_HT 4          // hidden tiles of 16 -> H <= 64
+#define NSF_HT 4          // hidden tiles of 16 of the throughput kernels (weights of a transform in LDS) -> H <= 64
+#define NSF_HT_WIDE 8     // hidden tiles the wide cooperative kernels take (weights from L2, nsf_coop_wide_kernel.h) -> H <= 128
 #define NSF_MAX_DCH 2     // spline dims per chunk: one (row, dim) task per lane pair (lane, lane^32)
 #define NSF_LDS_LIMIT_BYTES (160 * 1024)
 
@@ -47,7 +48,7 @@ struct NsfPlan {
   int D, C, H, K, T, NB, P, PT;   // P = 3K-1, PT = ceil(P/16)
   int ctx_mlp;                    // D == 1: sbi's ContextSplineMap conditioner (flow.py:1419-1478): params from
                                   // the context only (C->H relu, H->H relu, H->P), mask [1], no LULinear
-  int KSH;                        // hidden-layer K-steps the kernel template is instantiated for (13 or 16)
+  int KSH;                        // hidden-layer K-steps the kernel template is instantiated for (13 or 16; 32: H > 64)
   float B, min_w, min_h, min_d, lu_eps, sqrt_h, inv_sqrt_h;
   float one_minus_kw, one_minus_kh;   // 1 - min_w*K, 1 - min_h*K
   float d_const;                      // log(exp(1-min_d)-1): boundary derivative pre-activation

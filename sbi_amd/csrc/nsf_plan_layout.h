@@ -14,7 +14,7 @@ constexpr int nsf_supported_bins(int K) { return K == 4 || K == 5 || K == 8 || K
 constexpr int nsf_check_cfg(const sbi_amd_nsf_config* c) {
   if (!c) return SBI_AMD_E_BADARG;
   if (c->D < 1 || c->C < 1 || c->H < 1 || c->T < 1 || c->NB < 0) return SBI_AMD_E_BADARG;
-  if (c->H > 16 * NSF_HT || c->T > NSF_MAX_T || c->NB > NSF_MAX_NB || !nsf_supported_bins(c->K))
+  if (c->H > 16 * NSF_HT_WIDE || c->T > NSF_MAX_T || c->NB > NSF_MAX_NB || !nsf_supported_bins(c->K))
     return SBI_AMD_E_UNSUPPORTED;
   if (c->D > 64 || c->C > 256) return SBI_AMD_E_UNSUPPORTED;
   if (c->min_bin_width * c->K > 1.0f || c->min_bin_height * c->K > 1.0f) return SBI_AMD_E_BADARG;
@@ -59,7 +59,8 @@ constexpr int nsf_build_layout(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* p
   pl->D = D; pl->C = C; pl->H = H; pl->K = K; pl->T = T; pl->NB = NB;
   pl->P = 3 * K - 1;
   pl->PT = (pl->P + 15) / 16;
-  pl->KSH = ((H + 3) / 4 == 13) ? 13 : 16;   // kernels are instantiated for 13 (H=49..52) and 16
+  // kernels are instantiated for 13 (H=49..52) and 16; hidden > 64 (wide cooperative kernels only): whole K-quads
+  pl->KSH = H > 16 * NSF_HT ? 4 * NSF_HT_WIDE : (((H + 3) / 4 == 13) ? 13 : 16);
 
   for (int par = 0; par < 2; ++par) {
     ShapeDesc* s = &pl->shape[par];
@@ -150,6 +151,12 @@ constexpr int nsf_build_layout(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* p
   pl->sc_cin = pl->sc_pst2;
   pl->sc_total = nsf_round_up(o, 4);
   if (4ll * ((int64_t)pl->lds_w_floats + (int64_t)nw * pl->sc_total) > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
+  // hidden > 64: the throughput kernels (four hidden m-tiles per wave, one transform's image in LDS) never take the
+  // shape, whatever its image happens to weigh; the flat-parameter part of the plan is what the wide kernels use
+  if (H > 16 * NSF_HT) {
+    pl->img_floats = 0;        // no throughput image is ever packed for it
+    return SBI_AMD_E_LDS;
+  }
   return 0;
 }
 

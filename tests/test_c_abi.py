@@ -53,7 +53,15 @@ def test_version_arch_and_layout_helpers():
 
 def test_unsupported_configs_are_refused_not_degraded():
     lib = _lib.load()
-    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, hidden_features=128).c_config()) == _lib.E_UNSUPPORTED
+    assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, hidden_features=129).c_config()) == _lib.E_UNSUPPORTED
+    # hidden 65 ... 128: the wide cooperative kernels (every batch size reads the cooperative image); shapes those
+    # kernels do not take (theta-dim 1, theta-dim > 16, x-dim > 32) have no kernel at that width and say so
+    wide = NSFHyper(D=10, C=10, hidden_features=128)
+    assert lib.sbi_amd_nsf_param_count(wide.c_config()) == wide.param_count() > 0
+    assert lib.sbi_amd_nsf_image_kind(wide.c_config(), 65536, 0) == 1
+    assert lib.sbi_amd_nsf_packed_floats(wide.c_config()) > 0
+    for kw in (dict(D=1, C=3), dict(D=20, C=5), dict(D=5, C=40)):
+        assert lib.sbi_amd_nsf_image_kind(NSFHyper(hidden_features=100, **kw).c_config(), 100, 0) == _lib.E_UNSUPPORTED
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, num_bins=7).c_config()) == _lib.E_UNSUPPORTED
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=0, C=10).c_config()) == _lib.E_BADARG
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=1, C=3).c_config()) == NSFHyper(D=1, C=3).param_count() == 21145
@@ -92,5 +100,10 @@ def test_training_envelope_and_refusals_are_host_side_decisions():
     small = lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10).c_config(), 1024)
     big = lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10).c_config(), 65536)
     assert 0 < small < big
-    assert lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10, hidden_features=128).c_config(), 1024) == \
+    # hidden 65 ... 128 trains on the wide cooperative kernels at every batch size; beyond, and for the shapes those
+    # kernels do not take, the refusal is a host-side answer as well
+    assert lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10, hidden_features=128).c_config(), 1024) > 0
+    assert lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10, hidden_features=100).c_config(), 65536) > 0
+    assert lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=10, C=10, hidden_features=129).c_config(), 1024) == \
         _lib.E_UNSUPPORTED
+    assert lib.sbi_amd_nsf_train_workspace_floats(NSFHyper(D=20, C=10, hidden_features=100).c_config(), 1024) < 0
