@@ -745,6 +745,21 @@ def main(argv=None):
             / small_obj["batch_8192"]["fused_step_device_ms"],
             "note": "one 65 536-pair step on 1 GPU vs the same step's 8 192-pair share on each of 8 GPUs; the RCCL "
                     "all-reduce of the 392 KB gradient comes on top (rccl_1rank.allreduce_us_98025_floats)"}
+        # hidden_features = 100 (wide cooperative kernels, csrc/nsf_coop_wide_kernel.h): same inner loop, same data
+        from sbi_amd.neural_nets.net_builders.flow import build_nsf
+
+        torch.manual_seed(0)
+        est_w = build_nsf(th_all[:4096].cpu(), x_all[:4096].cpu(), hidden_features=100).to(device)
+        wide_obj = {"hidden_features": 100, "parameters": int(est_w.net.flat_params.numel())}
+        for b in (200, 8192):
+            leg_w = TrainLeg(est_w, th_all, x_all, b, False, b)
+            ks = 100
+            wall_w, _ = timed(leg_w, ks, 10, device)
+            tb, xb = th_all[:b].contiguous(), x_all[:b].contiguous()
+            _, lp_ms = timed(lambda: est_w.log_prob(tb, xb), ks, 10, device)
+            wide_obj[f"batch_{b}"] = {"train_ms_per_step": wall_w / ks * 1e3, "fused_step_device_ms": leg_w.fused_ms(ks) / ks,
+                                      "train_value": b * ks / wall_w, "unit": "pairs/s", "log_prob_device_ms": lp_ms / ks}
+        small_obj["wide_hidden_100"] = wide_obj
 
     npe_obj = npe_train_leg(device, rank, world, args.npe_epochs) if args.mode == "both" else None
     fm_out = fmpe_leg(args, B, rank, world, device, dist, distributed, GB) if args.mode == "both" else None

@@ -31,7 +31,8 @@ class _OracleLogProb:
 
 
 @pytest.mark.parametrize("combined", [False, True])
-@pytest.mark.parametrize("cfg", [dict(D=4, C=7), dict(D=10, C=10)], ids=["D4-C7", "D10-C10"])
+@pytest.mark.parametrize("cfg", [dict(D=4, C=7), dict(D=10, C=10), dict(D=4, C=7, hidden_features=100, num_transforms=3)],
+                         ids=["D4-C7", "D10-C10", "D4-C7-hidden100"])
 def test_fused_atomic_loss_and_grad_match_oracle_autograd(cfg, combined):
     oracle, est, theta_d, x_d = matched_pair(**cfg)
     B, A = 333, 10
