@@ -119,8 +119,9 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
   if (nt_force <= 0) nt_force = nt_env;
   int NT = nt_force > 0 ? nt_force : (n > 4096 ? 2 : 1);
   if (NT > CO_MAX_NT) NT = CO_MAX_NT;
-  if (wide) NT = 1;
   cp->MT = wide ? 2 : 1;
+  const int nt_first = NT;
+retry_nt:
   cp->NT = NT;
   cp->R = 16 * NT;
   cp->RS = cp->R + 4;
@@ -152,7 +153,12 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
     cp->o_ctx = o; o += 32 * cp->R;
   }
   cp->lds_floats = round_up_i(o, 4);
-  if (4ll * cp->lds_floats > NSF_LDS_LIMIT_BYTES) return SBI_AMD_E_LDS;
+  if (4ll * cp->lds_floats > NSF_LDS_LIMIT_BYTES) {
+    // wide nets: the 128-feature transposed tiles of two row tiles may not fit next to a large spline staging area;
+    // one row tile per workgroup always does
+    if (wide && NT == 2 && nt_first == 2 && nt_force <= 0) { NT = 1; goto retry_nt; }
+    return SBI_AMD_E_LDS;
+  }
   cp->grid = (int)((n + cp->R - 1) / cp->R);
   return 0;
 }

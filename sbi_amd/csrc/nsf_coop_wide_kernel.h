@@ -283,18 +283,35 @@ static int cow_launch_fwd(const CoK& k, const CoopPlan& cp, const float* cimg, c
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Same phases, LDS tiles, stash and slab formats as nsf_coop_bwd_kernel (one 16-row tile per workgroup); wave w owns
-// hidden m-tiles w and w + 4 everywhere: the d-activation chain (transposed matrices, K = eight quads), the transposed
-// tiles it publishes and the weight-gradient tiles of those output features (up to nine n-tiles per m-tile).
+// Same phases, LDS tiles, stash and slab formats as nsf_coop_bwd_kernel; wave w owns hidden m-tiles w and w + 4
+// everywhere: the d-activation chain (transposed matrices, K = eight quads), the transposed tiles it publishes and the
+// weight-gradient tiles of those output features (up to nine n-tiles per m-tile).  NT = 16-row tiles per workgroup: two
+// above 4 096 rows when the tiles fit LDS (the weight gradients then contract over 32 rows: half the partial slabs).
 // d loss / d embedded x (trainable embedding nets) is not offered at this width.
-template <int K>
+template <int NT>
+__device__ __forceinline__ void cow_gather_nt(float* __restrict__ ex, int& buf, int wave, int lane,
+                                              const f4 (&mine)[2][NT], f4 (&out)[NT][COW_HT]) {
+  f4* e = reinterpret_cast<f4*>(ex) + buf * (COW_HT * NT * 64);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) e[((wave + CO_WAVES * q) * NT + u) * 64 + lane] = mine[q][u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int mt = 0; mt < COW_HT; ++mt) out[u][mt] = e[(mt * NT + u) * 64 + lane];
+  buf ^= 1;
+}
+
+template <int K, int NT>
 __global__ void __launch_bounds__(64 * CO_WAVES, 1)
 nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __restrict__ zstats,
                      const float* __restrict__ x, long long n, long long x_rows, const float* __restrict__ row_w,
                      const float uni_w, const float* __restrict__ z_last, const float* __restrict__ zst,
                      const float* __restrict__ ast, float* __restrict__ partial, float* __restrict__ grad_theta) {
   constexpr int PT = (3 * K - 1 + 15) / 16;
-  constexpr int R = 16;
+  constexpr int R = 16 * NT;
   constexpr int NNH = COW_HT + 1;          // n-tiles of a hidden-input layer: 8 x 16 inputs + the bias column
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -325,9 +342,13 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int ntc = k.ntc, nnh = k.nnh;
   const int blk_tiles = COW_HT * ntc + 2 * COW_HT * nnh;     // slab tiles of one residual block: d Wc | d W1 | d W2
-  const long long t16 = (row0 >> 4) < nt16 ? (row0 >> 4) : nt16 - 1;
-  const float* abase = ast + t16 * k.slots * 256 + 4 * id.lane;
   const long long astride = nt16 * k.slots * 256;
+  const float* abase[NT];       // stash of this workgroup's tiles (clamped: tiles past the last row were never written)
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const long long t16 = (row0 >> 4) + u < nt16 ? (row0 >> 4) + u : nt16 - 1;
+    abase[u] = ast + t16 * k.slots * 256 + 4 * id.lane;
+  }
 
   for (int i = tid; i < k.o_w - k.o_zs; i += 64 * CO_WAVES) lds[k.o_zs + i] = 0.f;   // state rows incl. padding
   if (tid < R) {
@@ -350,31 +371,39 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
   int buf = 0;
   __syncthreads();
 
-  // weight-gradient tiles of one output m-tile: acc[nt] of lane (g, j) = d W[out0 + j][16 nt + 4 g + r]
+  // weight-gradient tiles of one output m-tile: acc[nt] of lane (g, j) = d W[out0 + j][16 nt + 4 g + r], contracted
+  // over all rows of the workgroup
   auto dw_tiles = [&](const float* Gt, const float* At, int out0, int in_off, int nnt, f4 (&acc)[NNH], f4* accb) {
-    const f4 b = *reinterpret_cast<const f4*>(Gt + (out0 + id.j) * RS + 4 * id.g);
+    f4 b[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) b[u] = *reinterpret_cast<const f4*>(Gt + (out0 + id.j) * RS + 16 * u + 4 * id.g);
 #pragma unroll
     for (int nt = 0; nt < NNH; ++nt) {
       acc[nt] = zero4;
       if (nt < nnt) {
-        const f4 a = *reinterpret_cast<const f4*>(At + (in_off + 16 * nt + id.j) * RS + 4 * id.g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[nt] = MFMA16(a[s], b[s], acc[nt]);
+        for (int u = 0; u < NT; ++u) {
+          const f4 a = *reinterpret_cast<const f4*>(At + (in_off + 16 * nt + id.j) * RS + 16 * u + 4 * id.g);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[nt] = MFMA16(a[s], b[u][s], acc[nt]);
+        }
       }
     }
     if (accb) {
       *accb = zero4;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) *accb = MFMA16(1.f, b[s], *accb);
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *accb = MFMA16(1.f, b[u][s], *accb);
     }
   };
-  auto store_T = [&](float* T, int f0, const f4& v, bool relu, int ones_row) {
+  auto store_T = [&](float* T, int f0, int u, const f4& v, bool relu, int ones_row) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = f0 + 4 * r + id.g;
       float a = relu ? fmaxf(v[r], 0.f) : v[r];
       a = (f == ones_row) ? 1.f : a;
-      T[f * RS + id.j] = a;
+      T[f * RS + 16 * u + id.j] = a;
     }
   };
 
@@ -383,7 +412,9 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
     const CoKP& kp = k.p[par];
     const float* img = cimg + (long long)t * k.img_floats;
     float* part = (k.ablate & 32768) ? nullptr : partial + ((long long)t * gridDim.x + blockIdx.x) * k.PLP;
-    const float* at = abase + t * astride;
+    const float* at[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) at[u] = abase[u] + t * astride;
     const int tb_blk0 = COW_HT * kp.nnt0;             // slab tile bases: d W0 | blocks | d Wf | LULinear tail
     const int tb_wf = tb_blk0 + NB * blk_tiles;
     // ---- P0: state rows + conditioner-input tile, spline parameters -> LDS; LULinear backward
@@ -399,19 +430,23 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
       CT[kk * RS + r] = kk < kp.in0 ? ctx[(kk - kp.d_id) * R + r] : (kk == kp.in0 ? 1.f : 0.f);
     }
     for (int mt = wave; mt < kp.nft; mt += CO_WAVES) {
-      const f4 pt4 = *reinterpret_cast<const f4*>(at + (k.s_par + mt) * 256);
       const int dd = mt / PT, pt = mt - dd * PT;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pst[id.j * k.DSTR + dd * k.PSW + 16 * pt + 4 * r + id.g] = pt4[r];
+      for (int u = 0; u < NT; ++u) {
+        const f4 pt4 = *reinterpret_cast<const f4*>(at[u] + (k.s_par + mt) * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pst[(16 * u + id.j) * k.DSTR + dd * k.PSW + 16 * pt + 4 * r + id.g] = pt4[r];
+      }
     }
-    if (wave == 0) {   // g_u = L^T g_z, g_y = U^T g_u
+    if (wave < NT) {   // g_u = L^T g_z, g_y = U^T g_u for row tile `wave`
+      const int u = wave;
       const f4 a_lt = *(reinterpret_cast<const f4*>(img + kp.lt) + id.lane);
       const f4 a_ut = *(reinterpret_cast<const f4*>(img + kp.ut) + id.lane);
       f4 gu = zero4, gy = zero4;
       float gz[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        gz[s] = gzs[id.j * ZS + 4 * s + id.g];
+        gz[s] = gzs[(16 * u + id.j) * ZS + 4 * s + id.g];
         gu = MFMA16(a_lt[s], gz[s], gu);
       }
 #pragma unroll
@@ -419,9 +454,9 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 4 * r + id.g;
-        if (d < D) gys[id.j * ZS + d] = gy[r];
-        GUT[d * RS + id.j] = gu[r];
-        GZT[d * RS + id.j] = gz[r];
+        if (d < D) gys[(16 * u + id.j) * ZS + d] = gy[r];
+        GUT[d * RS + 16 * u + id.j] = gu[r];
+        GZT[d * RS + 16 * u + id.j] = gz[r];
       }
     }
     __syncthreads();
@@ -430,71 +465,91 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
       const int slt = id.g & 1, sp = id.g >> 1;
       const int dd = 2 * wave + slt;
       if (dd < kp.d_tr) {
-        const int zi = id.j * ZS + 2 * dd + par;
-        float yv, gxv;
-        rq_spline_pair_bwd<K>(pst + id.j * k.DSTR + dd * k.PSW, 16 * PT, zs[zi], gys[zi], -wrow[id.j], k, sp, yv, gxv);
-        if (sp == 0) {
-          zs[zi] = yv;
-          gys[zi] = gxv;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          const int r = 16 * u + id.j;
+          const int zi = r * ZS + 2 * dd + par;
+          float yv, gxv;
+          rq_spline_pair_bwd<K>(pst + r * k.DSTR + dd * k.PSW, 16 * PT, zs[zi], gys[zi], -wrow[r], k, sp, yv, gxv);
+          if (sp == 0) {
+            zs[zi] = yv;
+            gys[zi] = gxv;
+          }
         }
       }
     }
     __syncthreads();
     // ---- P2: u = U y (LU parameter gradients), h_last -> activation tile, g_h = Wf^T g_p
-    if (wave == 0) {
+    if (wave < NT) {
+      const int u = wave;
       const f4 a_u = *(reinterpret_cast<const f4*>(img + kp.u) + id.lane);
       f4 uv = zero4;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float yv = zs[id.j * ZS + 4 * s + id.g];
+        const float yv = zs[(16 * u + id.j) * ZS + 4 * s + id.g];
         uv = MFMA16(a_u[s], yv, uv);
-        YT[(4 * s + id.g) * RS + id.j] = yv;
+        YT[(4 * s + id.g) * RS + 16 * u + id.j] = yv;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) UTt[(4 * r + id.g) * RS + id.j] = uv[r];
+      for (int r = 0; r < 4; ++r) UTt[(4 * r + id.g) * RS + 16 * u + id.j] = uv[r];
     }
-    f4 gh[2];
+    f4 gh[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int mt = wave + CO_WAVES * q;
-      const f4 hl = *reinterpret_cast<const f4*>(at + (k.s_blk + 4 * COW_HT * (NB - 1) + 3 * COW_HT + mt) * 256);
-      store_T(AT0, 16 * mt, hl, false, ones_h);
-      f4 acc0 = zero4, acc1 = zero4;
+      f4 acc0[NT], acc1[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const f4 hl = *reinterpret_cast<const f4*>(at[u] + (k.s_blk + 4 * COW_HT * (NB - 1) + 3 * COW_HT + mt) * 256);
+        store_T(AT0, 16 * mt, u, hl, false, ones_h);
+        acc0[u] = zero4;
+        acc1[u] = zero4;
+      }
       const f4* ap = reinterpret_cast<const f4*>(img + kp.wft + mt * kp.d_tr * PT * 256) + id.lane;
       for (int dd = 0; dd < kp.d_tr; ++dd) {
 #pragma unroll
         for (int qq = 0; qq < PT; ++qq) {
           const f4 a = ap[(dd * PT + qq) * 64];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float bv = pst[id.j * k.DSTR + dd * k.PSW + 16 * qq + 4 * r + id.g];
-            if (qq & 1) acc1 = MFMA16(a[r], bv, acc1);
-            else acc0 = MFMA16(a[r], bv, acc0);
-          }
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+              const float bv = pst[(16 * u + id.j) * k.DSTR + dd * k.PSW + 16 * qq + 4 * r + id.g];
+              if (qq & 1) acc1[u] = MFMA16(a[r], bv, acc1[u]);
+              else acc0[u] = MFMA16(a[r], bv, acc0[u]);
+            }
         }
       }
-      gh[q] = acc0 + acc1;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) gh[q][u] = acc0[u] + acc1[u];
     }
     __syncthreads();
     // ---- d Wf (parameter tiles wave, wave + 4, ...), LULinear parameter gradients
     for (int mt = wave; mt < kp.nft; mt += CO_WAVES) {
       const int dd = mt / PT, pt = mt - dd * PT;
       f4 acc[NNH], accb = zero4;
-      float bv[4];    // B side = g_p: parameter 16 pt + j of rows 4 g + s
+      float bv[NT][4];    // B side = g_p: parameter 16 pt + j of rows 16 u + 4 g + s
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bv[s] = pst[(4 * id.g + s) * k.DSTR + dd * k.PSW + 16 * pt + id.j];
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bv[u][s] = pst[(16 * u + 4 * id.g + s) * k.DSTR + dd * k.PSW + 16 * pt + id.j];
 #pragma unroll
       for (int nt = 0; nt < NNH; ++nt) {
         acc[nt] = zero4;
         if (nt < nnh) {
-          const f4 a = *reinterpret_cast<const f4*>(AT0 + (16 * nt + id.j) * RS + 4 * id.g);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[nt] = MFMA16(a[s], bv[s], acc[nt]);
+          for (int u = 0; u < NT; ++u) {
+            const f4 a = *reinterpret_cast<const f4*>(AT0 + (16 * nt + id.j) * RS + 16 * u + 4 * id.g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[nt] = MFMA16(a[s], bv[u][s], acc[nt]);
+          }
         }
       }
       if (hbf) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) accb = MFMA16(1.f, bv[s], accb);
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) accb = MFMA16(1.f, bv[u][s], accb);
       }
       const bool p_ok = 16 * pt + id.j < k.P;
 #pragma unroll
@@ -510,7 +565,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
       float* pbias = pdiag + D;
       if (wave == 3 || wave == 2) {   // d U = g_u (x) y (wave 3), d L = g_z (x) u (wave 2): one 16 x 16 tile each
         f4 acc[1];
-        co_dw<1, 1>(wave == 3 ? GUT : GZT, wave == 3 ? YT : UTt, RS, 0, 0, 1, id, acc, nullptr);
+        co_dw<NT, 1>(wave == 3 ? GUT : GZT, wave == 3 ? YT : UTt, RS, 0, 0, 1, id, acc, nullptr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = id.j, kk = 4 * id.g + r;
@@ -539,7 +594,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
     for (int b = NB - 1; b >= 0; --b) {
       const int sb = k.s_blk + 4 * COW_HT * b;
       const int tb_c = tb_blk0 + b * blk_tiles, tb_1 = tb_c + COW_HT * ntc, tb_2 = tb_1 + COW_HT * nnh;
-      f4 t1[2], hin[2], ga[2], bg[COW_HT];
+      f4 t1[2][NT], hin[2][NT], ga[2][NT], bg[NT][COW_HT];
       f4 a2t[2][COW_KQ], a1t[2][COW_KQ];     // both transposed matrices of the block: one L2 round trip with the stash
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -550,29 +605,35 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int mt = wave + CO_WAVES * q;
-        t1[q] = *reinterpret_cast<const f4*>(at + (sb + mt) * 256);
-        const f4 t2 = *reinterpret_cast<const f4*>(at + (sb + COW_HT + mt) * 256);
-        const f4 sg = *reinterpret_cast<const f4*>(at + (sb + 2 * COW_HT + mt) * 256);
-        hin[q] = *reinterpret_cast<const f4*>(at + (b == 0 ? mt : sb - COW_HT + mt) * 256);   // h_0 or h_b of block b - 1
-        f4 gc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ga[q][r] = gh[q][r] * sg[r];                                  // d t2
-          gc[r] = gh[q][r] * t2[r] * sg[r] * (1.f - sg[r]);             // d (Wc c + bc)
+        for (int u = 0; u < NT; ++u) {
+          t1[q][u] = *reinterpret_cast<const f4*>(at[u] + (sb + mt) * 256);
+          const f4 t2 = *reinterpret_cast<const f4*>(at[u] + (sb + COW_HT + mt) * 256);
+          const f4 sg = *reinterpret_cast<const f4*>(at[u] + (sb + 2 * COW_HT + mt) * 256);
+          hin[q][u] = *reinterpret_cast<const f4*>(at[u] + (b == 0 ? mt : sb - COW_HT + mt) * 256);   // h_0 or h_b
+          f4 gc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ga[q][u][r] = gh[q][u][r] * sg[r];                                  // d t2
+            gc[r] = gh[q][u][r] * t2[r] * sg[r] * (1.f - sg[r]);                // d (Wc c + bc)
+          }
+          store_T(GT0, 16 * mt, u, ga[q][u], false, -1);
+          store_T(GT1, 16 * mt, u, gc, false, -1);
+          store_T(AT1, 16 * mt, u, t1[q][u], true, ones_h);
         }
-        store_T(GT0, 16 * mt, ga[q], false, -1);
-        store_T(GT1, 16 * mt, gc, false, -1);
-        store_T(AT1, 16 * mt, t1[q], true, ones_h);
       }
-      cow_gather(ex, buf, wave, id.lane, ga, bg);
+      cow_gather_nt<NT>(ex, buf, wave, id.lane, ga, bg);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int mt = wave + CO_WAVES * q;
         const bool out_ok = 16 * mt + id.j < H;
-        f4 gr = zero4;
-        cow_gemm(a2t[q], bg, gr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ga[q][r] = t1[q][r] > 0.f ? gr[r] : 0.f;     // d t1
+        for (int u = 0; u < NT; ++u) {
+          f4 gr = zero4;
+          cow_gemm(a2t[q], bg[u], gr);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ga[q][u][r] = t1[q][u][r] > 0.f ? gr[r] : 0.f;     // d t1
+        }
         f4 acc[NNH], accb;
         dw_tiles(GT0, AT1, 16 * mt, 0, nnh, acc, hbf ? &accb : nullptr);
 #pragma unroll
@@ -588,18 +649,24 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int mt = wave + CO_WAVES * q;
-        store_T(GT0, 16 * mt, ga[q], false, -1);
-        store_T(AT0, 16 * mt, hin[q], true, ones_h);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          store_T(GT0, 16 * mt, u, ga[q][u], false, -1);
+          store_T(AT0, 16 * mt, u, hin[q][u], true, ones_h);
+        }
       }
-      cow_gather(ex, buf, wave, id.lane, ga, bg);
+      cow_gather_nt<NT>(ex, buf, wave, id.lane, ga, bg);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int mt = wave + CO_WAVES * q;
         const bool out_ok = 16 * mt + id.j < H;
-        f4 gr = zero4;
-        cow_gemm(a1t[q], bg, gr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gh[q][r] += hin[q][r] > 0.f ? gr[r] : 0.f;
+        for (int u = 0; u < NT; ++u) {
+          f4 gr = zero4;
+          cow_gemm(a1t[q], bg[u], gr);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gh[q][u][r] += hin[q][u][r] > 0.f ? gr[r] : 0.f;
+        }
         f4 acc[NNH], accb;
         dw_tiles(GT0, AT0, 16 * mt, 0, nnh, acc, hbf ? &accb : nullptr);
 #pragma unroll
@@ -611,19 +678,24 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
     }
     // ---- initial layer
     {
-      f4 bg[COW_HT];
+      f4 bg[NT][COW_HT];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) store_T(GT0, 16 * (wave + CO_WAVES * q), gh[q], false, -1);
-      cow_gather(ex, buf, wave, id.lane, gh, bg);
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) store_T(GT0, 16 * (wave + CO_WAVES * q), u, gh[q][u], false, -1);
+      cow_gather_nt<NT>(ex, buf, wave, id.lane, gh, bg);
       if (wave == 0) {      // identity features receive W0[:, :d_id]^T g_h0
         f4 a0t[COW_KQ];
         co_load_a<COW_KQ>(img + kp.w0t, id.lane, a0t);
-        f4 gin = zero4;
-        cow_gemm(a0t, bg, gin);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kk = 4 * r + id.g;
-          if (kk < kp.d_id) gys[id.j * ZS + 2 * kk + (1 - par)] += gin[r];
+        for (int u = 0; u < NT; ++u) {
+          f4 gin = zero4;
+          cow_gemm(a0t, bg[u], gin);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = 4 * r + id.g;
+            if (kk < kp.d_id) gys[(16 * u + id.j) * ZS + 2 * kk + (1 - par)] += gin[r];
+          }
         }
       }
 #pragma unroll
@@ -652,10 +724,10 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
   }
 }
 
-template <int K>
+template <int K, int NT>
 static int cow_launch_bwd(const CoK& k, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {
   if (a.grad_x) return SBI_AMD_E_UNSUPPORTED;      // d loss / d embedded x: narrow nets only
-  auto kern = nsf_coopw_bwd_kernel<K>;
+  auto kern = nsf_coopw_bwd_kernel<K, NT>;
   const int lds_bytes = 4 * cp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
@@ -669,9 +741,14 @@ static int cow_launch_bwd(const CoK& k, const CoopPlan& cp, const CoBwdArgs& a, 
 template <int K>
 int co_fwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
   CoK k;
-  if (cp.MT == 2) {       // hidden > 64: the wide kernel, one tile per workgroup
-    coop_make_consts(pl, cp, &k);
-    return cow_launch_fwd<K, false>(k, cp, a.cimg, a.zstats, a.theta, a.x, a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast,
+  if (cp.MT == 2) {       // hidden > 64: the wide kernel, always one tile per workgroup (the backward pass may take two)
+    CoopPlan cf = cp;
+    if (cp.NT != 1) {
+      int rc = coop_build_plan(pl, a.n, 1, false, &cf);
+      if (rc) return rc;
+    }
+    coop_make_consts(pl, cf, &k);
+    return cow_launch_fwd<K, false>(k, cf, a.cimg, a.zstats, a.theta, a.x, a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast,
                                     st);
   }
   if (cp.NT == 2 && coop_lean_forward()) {
@@ -694,14 +771,19 @@ int co_inv_k(const NsfPlan& pl, const CoopPlan& cp, const float* cimg, const flo
              const float* x, long long n, long long x_rows, float* theta_out, float* logabsdet_out, hipStream_t st) {
   if (cp.MT != 2) return SBI_AMD_E_UNSUPPORTED;
   CoK k;
-  coop_make_consts(pl, cp, &k);
-  return cow_launch_fwd<K, true>(k, cp, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, st);
+  CoopPlan cf = cp;
+  if (cp.NT != 1) {
+    int rc = coop_build_plan(pl, n, 1, false, &cf);
+    if (rc) return rc;
+  }
+  coop_make_consts(pl, cf, &k);
+  return cow_launch_fwd<K, true>(k, cf, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, st);
 }
 template <int K>
 int co_bwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {
   CoK k;
   coop_make_consts(pl, cp, &k);
-  if (cp.MT == 2) return cow_launch_bwd<K>(k, cp, a, st);
+  if (cp.MT == 2) return cp.NT == 2 ? cow_launch_bwd<K, 2>(k, cp, a, st) : cow_launch_bwd<K, 1>(k, cp, a, st);
   if (pl.KSH == 13) return cp.NT == 2 ? co_launch_bwd<K, 13, 2>(k, cp, a, st) : co_launch_bwd<K, 13, 1>(k, cp, a, st);
   return cp.NT == 2 ? co_launch_bwd<K, 16, 2>(k, cp, a, st) : co_launch_bwd<K, 16, 1>(k, cp, a, st);
 }

@@ -145,3 +145,27 @@ def test_trains_end_to_end_at_hidden_100():
     score = c2st(samples, target).item()
     print("c2st at hidden 100:", score)
     assert 0.4 <= score <= 0.62
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[1], CONFIGS[4]], ids=_ids)
+def test_training_pass_above_4096_rows_two_tiles_per_workgroup(cfg):
+    """More than 4 096 rows: the backward pass contracts the weight gradients over two 16-row tiles per workgroup when
+    its tiles fit LDS (half the partial slabs), one otherwise; ragged row count, the forward pass stays at one tile."""
+    oracle, est, theta_d, x_d = matched_pair(n=5000, **cfg)
+    n = 4999
+    theta, x = theta_d[:n], x_d[:n]
+    w = torch.full((n,), 1.0 / n)
+    near = spline_knot_distances(oracle, theta, x).min(1).values < 2.0
+    assert int(near.sum()) <= 8
+    w[near] = 0.0
+    l64, g64, gth64, _ = _oracle_grad(oracle, est, theta, x, w)
+    l_c, g_c, gth_c, _ = _hip_pass(est, theta, x, w)
+    scale = g64.abs().max().item()
+    e_c = (g_c.double() - g64).abs().max().item() / scale
+    e_l = (l_c.double() - l64).abs().max().item() / (1 + l64.abs().max().item())
+    e_t = (gth_c.double() - gth64).abs().max().item() / max(gth64.abs().max().item(), 1e-12)
+    record("wide_train", _ids(cfg) + f" | n={n}", grad_rel_hip_vs_f64=e_c, loss_rel=e_l, grad_theta_rel=e_t)
+    assert e_l <= 2e-5 and e_c <= 3e-4 and e_t <= 3e-4, (e_l, e_c, e_t)
+    for key, off, cnt, _ in est.net._slices():
+        a, b = g_c[off : off + cnt].double(), g64[off : off + cnt]
+        assert (a - b).abs().max().item() <= 3e-4 * max(b.abs().max().item(), 1e-3 * scale) + 1e-9, key
