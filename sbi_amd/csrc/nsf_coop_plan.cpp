@@ -47,9 +47,11 @@ static void add_bias(CoBias* b, int* off, int mtiles, int kind, int lin) {
 int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, CoopPlan* cp) {
   memset(cp, 0, sizeof(*cp));
   // shapes: residual-net conditioner (theta-dim >= 2), LULinear as one 16 x 16 MFMA tile, context K-steps in registers
-  if (pl.ctx_mlp || pl.D < 2 || pl.D > 16 || pl.C > 32 || pl.H > 16 * NSF_HT_WIDE || pl.NB < 1 || pl.NB > NSF_MAX_NB)
-    return SBI_AMD_E_UNSUPPORTED;
   const bool wide = pl.H > 16 * NSF_HT;            // two hidden m-tiles per wave, eight K-quads (nsf_coop_wide_kernel.h)
+  // x-dim: the context K-steps live in registers (two quads; the wide kernels, which have no fallback, four)
+  if (pl.ctx_mlp || pl.D < 2 || pl.D > 16 || pl.C > (wide ? 64 : 32) || pl.H > 16 * NSF_HT_WIDE || pl.NB < 1 ||
+      pl.NB > NSF_MAX_NB)
+    return SBI_AMD_E_UNSUPPORTED;
   const int HT = wide ? NSF_HT_WIDE : NSF_HT;
   const int HQ = (pl.KSH + 3) / 4;     // K-quads of a hidden-K layer (13 or 16 K-steps; wide: 32)
   if (!wide && pl.shape[0].d_tr * pl.PT > 16) return SBI_AMD_E_UNSUPPORTED;   // final-layer tiles: four per wave
@@ -150,7 +152,7 @@ retry_nt:
     cp->o_at = o;  o += 2 * (16 * HT + 1) * cp->RS;
     cp->o_ct = o;  o += cp->ct_rows * cp->RS;
     cp->o_lut = o; o += 4 * 17 * cp->RS;
-    cp->o_ctx = o; o += 32 * cp->R;
+    cp->o_ctx = o; o += (pl.C > 32 ? 64 : 32) * cp->R;
   }
   cp->lds_floats = round_up_i(o, 4);
   if (4ll * cp->lds_floats > NSF_LDS_LIMIT_BYTES) {

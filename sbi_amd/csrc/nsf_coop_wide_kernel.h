@@ -15,6 +15,8 @@
 
 #define COW_HT 8      // hidden m-tiles
 #define COW_KQ 8      // K-quads of a hidden-K matrix
+#define COW_CQ 4      // K-quads of the context part of the initial / gate layers: x-dim <= 64 (no throughput kernel to
+                      // fall back to at this width, so the wide kernels take twice the narrow kernels' x-dim)
 
 // all-gather of the eight hidden D fragments (wave w holds m-tiles w and w + 4); one barrier
 __device__ __forceinline__ void cow_gather(float* __restrict__ ex, int& buf, int wave, int lane, const f4 (&mine)[2],
@@ -33,9 +35,9 @@ __device__ __forceinline__ void cow_gemm(const f4 (&a)[COW_KQ], const f4 (&b)[CO
   for (int s = 0; s < 4 * COW_KQ; ++s) acc = MFMA16(a[s >> 2][s & 3], b[s >> 2][s & 3], acc);
 }
 // acc += A (context quads) * standardized context (K-steps of the context live in registers)
-__device__ __forceinline__ void cow_gemm_ctx(const f4 (&a)[2], int kcq, const float (&cb)[8], f4& acc) {
+__device__ __forceinline__ void cow_gemm_ctx(const f4 (&a)[COW_CQ], int kcq, const float (&cb)[4 * COW_CQ], f4& acc) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < COW_CQ; ++q)
     if (q < kcq) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = MFMA16(a[q][r], cb[4 * q + r], acc);
@@ -70,13 +72,13 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
   // ---- prologue: state rows -> LDS (density direction: z-scored theta; sampling direction: the noise as it is);
   //      standardized context as B fragments (K-step s <-> c = 4 s + g)
   for (int i = tid; i < R * ZS + 16; i += 64 * CO_WAVES) zs[i] = 0.f;
-  float cb[8];
+  float cb[4 * COW_CQ];
   {
     const long long row = row0 + id.j;
     const long long rs = row < n ? row : 0;
     const long long xr = (x_rows == n) ? rs : (x_rows == 1 ? 0 : rs % x_rows);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 4 * COW_CQ; ++s) {
       const int c = 4 * s + id.g;
       const int cc = c < C ? c : 0;
       cb[s] = (c < C && row < n) ? (x[xr * C + cc] - x_mean[cc]) / x_std[cc] : 0.f;
@@ -130,12 +132,13 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int mt = wave + CO_WAVES * q;
-      f4 a[3];
-      co_load_a<3>(img + kp.w0 + mt * (kcq + 1) * 256, id.lane, a);
+      f4 a[COW_CQ + 1];
+      co_load_a<COW_CQ + 1>(img + kp.w0 + mt * (kcq + 1) * 256, id.lane, a);
       h[q] = co_load_bias(img + kp.b0, mt, id.g);
-      const f4 wc[2] = {a[0], a[1]};
+      const f4 wc[COW_CQ] = {a[0], a[1], a[2], a[3]};
       cow_gemm_ctx(wc, kcq, cb, h[q]);
-      const f4 az = kcq == 1 ? a[1] : a[2];     // the identity features' quad sits behind the context quads
+      // the identity features' quad sits behind the context quads
+      const f4 az = kcq == 1 ? a[1] : (kcq == 2 ? a[2] : (kcq == 3 ? a[3] : a[4]));
 #pragma unroll
       for (int sz = 0; sz < 2; ++sz) {
         const int kz = 4 * sz + id.g;
@@ -160,9 +163,9 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int mt = wave + CO_WAVES * q;
-        f4 a[COW_KQ], ac[2];
+        f4 a[COW_KQ], ac[COW_CQ];
         co_load_a<COW_KQ>(img + kp.w10 + b * k.sA + mt * COW_KQ * 256, id.lane, a);
-        co_load_a<2>(img + kp.wc0 + b * k.sA + mt * kcq * 256, id.lane, ac);
+        co_load_a<COW_CQ>(img + kp.wc0 + b * k.sA + mt * kcq * 256, id.lane, ac);
         f4 u1 = co_load_bias(img + kp.b10 + b * k.sB, mt, id.g);
         gate[q] = co_load_bias(img + kp.bc0 + b * k.sB, mt, id.g);
         cow_gemm_ctx(ac, kcq, cb, gate[q]);
@@ -642,7 +645,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
         if (hbf) co_write_tile(part, tb_2 + mt * nnh + COW_HT, out_ok, COW_HT, H, id, accb);
         dw_tiles(GT1, CT, 16 * mt, kp.d_id, ntc, acc, nullptr);
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
+        for (int nt = 0; nt < COW_CQ + 1; ++nt)
           if (nt < ntc) co_write_tile(part, tb_c + mt * ntc + nt, out_ok, nt, C, id, acc[nt]);
       }
       wave_lds_fence();
@@ -705,7 +708,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
         f4 acc[NNH];
         dw_tiles(GT0, CT, 16 * mt, 0, kp.nnt0, acc, nullptr);
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
+        for (int nt = 0; nt < COW_CQ + 2; ++nt)
           if (nt < kp.nnt0) co_write_tile(part, mt * kp.nnt0 + nt, out_ok, nt, kp.in0, id, acc[nt]);
       }
     }

@@ -60,7 +60,8 @@ def test_unsupported_configs_are_refused_not_degraded():
     assert lib.sbi_amd_nsf_param_count(wide.c_config()) == wide.param_count() > 0
     assert lib.sbi_amd_nsf_image_kind(wide.c_config(), 65536, 0) == 1
     assert lib.sbi_amd_nsf_packed_floats(wide.c_config()) > 0
-    for kw in (dict(D=1, C=3), dict(D=20, C=5), dict(D=5, C=40)):
+    assert lib.sbi_amd_nsf_image_kind(NSFHyper(D=5, C=64, hidden_features=100).c_config(), 100, 0) == 1
+    for kw in (dict(D=1, C=3), dict(D=20, C=5), dict(D=5, C=65)):
         assert lib.sbi_amd_nsf_image_kind(NSFHyper(hidden_features=100, **kw).c_config(), 100, 0) == _lib.E_UNSUPPORTED
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=10, C=10, num_bins=7).c_config()) == _lib.E_UNSUPPORTED
     assert lib.sbi_amd_nsf_param_count(NSFHyper(D=0, C=10).c_config()) == _lib.E_BADARG

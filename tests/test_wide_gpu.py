@@ -20,6 +20,8 @@ CONFIGS = [
     dict(D=5, C=20, hidden_features=96, num_transforms=2, num_blocks=1, num_bins=16),
     dict(D=16, C=32, hidden_features=80, num_transforms=2, num_bins=8),
     dict(D=7, C=3, hidden_features=128, num_transforms=2, num_blocks=3, num_bins=4),
+    dict(D=5, C=50, hidden_features=100, num_transforms=2),                    # x-dim 33 ... 64: four context quads
+    dict(D=10, C=64, hidden_features=128, num_transforms=2, num_blocks=1),
 ]
 
 
