@@ -44,12 +44,16 @@ int64_t coop_packed_floats(const sbi_amd_nsf_config* cfg) {
   return coop_shape_ok(cfg, &pl, &cp) ? coop_image_floats(pl, cp) : 0;
 }
 
-int coop_pack(const sbi_amd_nsf_config* cfg, const float* params, float* cimg, void* stream) {
+int coop_pack(const sbi_amd_nsf_config* cfg, const float* params, float* cimg, int which, void* stream) {
   NsfPlan pl;
   CoopPlan cp;
   if (!coop_shape_ok(cfg, &pl, &cp)) return 0;
-  hipLaunchKernelGGL(nsf_coop_pack_kernel, dim3(pl.T, cp.img_floats >> 8), dim3(256), 0, (hipStream_t)stream, pl, cp,
-                     params, cimg);
+  if (which & 1)      // the image log_prob and the training pass read
+    hipLaunchKernelGGL(nsf_coop_pack_kernel, dim3(pl.T, cp.img_floats >> 8), dim3(256), 0, (hipStream_t)stream, pl, cp,
+                       params, cimg, 0);
+  if ((which & 2) && cp.sh[0].UI.mtiles > 0)      // + the explicit LU inverses (sampling direction, wide nets)
+    hipLaunchKernelGGL(nsf_coop_pack_kernel, dim3(pl.T, cp.img_floats >> 8), dim3(256), 0, (hipStream_t)stream, pl, cp,
+                       params, cimg, 1);
   return (int)hipGetLastError();
 }
 

@@ -132,7 +132,10 @@ __device__ __forceinline__ float co_bias_value(const CoBias& b, const NsfPlan& p
 // behind the matrices is searched per element.
 __global__ void __launch_bounds__(256)
 nsf_coop_pack_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict__ params,
-                     float* __restrict__ cimg) {
+                     float* __restrict__ cimg, const int inverses) {
+  // inverses = 0: everything but the explicit LU inverses (what log_prob and the training pass read; re-packed every
+  // optimizer step); 1: only U^-1 / L^-1 (sampling direction of the wide nets: a column substitution in fp64 per entry,
+  // four times the cost of the rest of the image, so it is not paid per training step)
   const int t = blockIdx.x;
   const int par = t & 1;
   const ShapeDesc& S = pl.shape[par];
@@ -153,8 +156,11 @@ nsf_coop_pack_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restric
         const int sz = mats[m].mtiles * mats[m].quads * 256;
         if (sz > 0 && (blk << 8) >= mats[m].off && (blk << 8) < mats[m].off + sz) mi = m;
       }
+      const bool is_inv = mi >= 0 && (mats[mi].kind == CO_K_UI || mats[mi].kind == CO_K_LI);
+      if (is_inv != (inverses != 0)) continue;
       if (mi >= 0) v = co_mat_value(mats[mi], pl, S, c, gl, idx - mats[mi].off);
     } else {
+      if (inverses) continue;
       for (int b = 0; b < NBIAS; ++b) {
         const CoBias& B = bias[b];
         const int sz = 16 * B.mtiles;

@@ -73,7 +73,8 @@ extern "C" int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, 
   return coop_applies(cfg, n, training != 0, &pl, &cp) ? 1 : 0;
 }
 
-// images: bit 0 the throughput image, bit 1 the cooperative image (a training loop at a fixed batch size only ever
+// images: bit 0 the throughput image, bit 1 the cooperative image, bit 2 the cooperative image's explicit LU inverses
+// (only the sampling direction of nets with hidden > 64 reads them) (a training loop at a fixed batch size only ever
 // needs one of them re-packed per step)
 extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const float* params, float* packed,
                                        int32_t images, void* stream) {
@@ -83,15 +84,15 @@ extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const floa
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   if ((images & 1) && pl.img_floats > 0)
     hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
-  if (images & 2) {
-    rc = coop_pack(cfg, params, packed + nsf_packed_floats(pl), stream);
+  if (images & 6) {     // bit 1: the cooperative image; bit 2: its explicit LU inverses (sampling direction, wide nets)
+    rc = coop_pack(cfg, params, packed + nsf_packed_floats(pl), (images >> 1) & 3, stream);
     if (rc) return rc;
   }
   return (int)hipGetLastError();
 }
 
 extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream) {
-  return sbi_amd_nsf_pack_images(cfg, params, packed, 3, stream);
+  return sbi_amd_nsf_pack_images(cfg, params, packed, 7, stream);
 }
 
 extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,

@@ -225,7 +225,7 @@ class NSFNet(nn.Module):
 
 
 # --------------------------------------------------------------------- kernel calls
-def packed_weights(net: NSFNet, rows: Optional[int] = None, training: bool = False) -> Tensor:
+def packed_weights(net: NSFNet, rows: Optional[int] = None, training: bool = False, sampling: bool = False) -> Tensor:
     """Kernel-side weight images of ``net.flat_params`` (re-packed lazily when the parameter tensor was modified or
     moved; tracked through its version counter).  The buffer holds two images (include/sbi_amd_nsf.h): the throughput
     kernels' and the cooperative small-batch kernels'; a call that knows its row count (`rows`) only re-packs the one
@@ -235,7 +235,11 @@ def packed_weights(net: NSFNet, rows: Optional[int] = None, training: bool = Fal
     cache = net.__dict__.get("_packed_cache")
     lib = _lib.load()
     cfg = net.hyper.c_config()
-    want = 3 if rows is None else (2 if lib.sbi_amd_nsf_image_kind(cfg, int(rows), int(training)) == 1 else 1)
+    # bits: 1 throughput image, 2 cooperative image, 4 its explicit LU inverses (read by the sampling direction of nets
+    # with hidden_features > 64 only: four times the packing cost of the rest, so not paid per training step)
+    want = 7 if rows is None else (2 if lib.sbi_amd_nsf_image_kind(cfg, int(rows), int(training)) == 1 else 1)
+    if sampling and want == 2:
+        want = 6
     have = 0
     if cache is not None and cache[0] == key:
         have = net.__dict__.get("_packed_images", 0)
@@ -286,7 +290,8 @@ def _sample_call(net: NSFNet, noise: Tensor, x: Tensor, want_ld: bool) -> Tuple[
     if n == 0:
         return theta, ld
     cfg = net.hyper.c_config()
-    packed = packed_weights(net, rows=0)    # the sampling direction always runs on the throughput kernels
+    # (the sampling direction runs on the throughput kernels; hidden > 64: on the wide cooperative kernel + LU inverses)
+    packed = packed_weights(net, rows=0, sampling=True)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_sample(
             cfg, _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(noise), _lib.ptr(x), n, x.shape[0],

@@ -171,3 +171,25 @@ def test_training_pass_above_4096_rows_two_tiles_per_workgroup(cfg):
     for key, off, cnt, _ in est.net._slices():
         a, b = g_c[off : off + cnt].double(), g64[off : off + cnt]
         assert (a - b).abs().max().item() <= 3e-4 * max(b.abs().max().item(), 1e-3 * scale) + 1e-9, key
+
+
+def test_lu_inverses_are_packed_for_the_sampling_direction_only():
+    from sbi_amd.neural_nets.estimators.nsf_flow import packed_weights
+
+    _, est, theta, x = matched_pair(D=4, C=3, hidden_features=100, num_transforms=2)
+    net = est.net
+    net.__dict__.pop("_packed_cache", None)
+    net.__dict__.pop("_packed_images", None)
+    packed_weights(net, rows=200, training=True)
+    assert net.__dict__["_packed_images"] == 2          # the image the training pass reads, without U^-1 / L^-1
+    est.log_prob(theta[:50].cuda(), x[:50].cuda())
+    assert net.__dict__["_packed_images"] == 2
+    a = est.sample_from_noise(torch.randn(50, 4, device="cuda"), x[:50].cuda())
+    assert net.__dict__["_packed_images"] == 6          # + the inverses, packed once per weight version
+    with torch.no_grad():
+        net.flat_params.add_(0.01)
+    b = est.sample_from_noise(torch.randn(50, 4, device="cuda"), x[:50].cuda())
+    assert net.__dict__["_packed_images"] == 6 and torch.isfinite(a).all() and torch.isfinite(b).all()
+    z = est.inverse_transform(b, x[:50].cuda())
+    back = est.sample_from_noise(z, x[:50].cuda())
+    assert (back - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())     # inverses of the NEW weights
