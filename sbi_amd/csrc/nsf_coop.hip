@@ -205,21 +205,28 @@ extern "C" int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg) {
     const CoShape& c = cp.sh[par];
     const ShapeDesc& S = pl.shape[par];
     const CoKP& q = k.p[par];
-    const int blk_tiles = 4 * k.ntc + 8 * k.nnh, tb_blk0 = 4 * q.nnt0;
+    const int HT = k.HT, HQ = k.HQ;         // 4 / 4 (hidden <= 64) or 8 / 8 (the wide kernels' COW_HT / COW_KQ)
+    if (HT != 4 * cp.MT || HQ != 4 * cp.MT || (cp.MT == 2) != (pl.H > 16 * NSF_HT)) return 13;
+    const int blk_tiles = HT * k.ntc + 2 * HT * k.nnh, tb_blk0 = HT * q.nnt0;
     if (c.dw_tb[0] != 0 || c.dw_nnt[0] != q.nnt0) return 1;
     for (int b = 0; b < pl.NB; ++b) {
       if (c.dw_tb[1 + 3 * b] != tb_blk0 + b * blk_tiles || c.dw_nnt[1 + 3 * b] != k.ntc) return 2;
-      if (c.dw_tb[2 + 3 * b] != tb_blk0 + b * blk_tiles + 4 * k.ntc || c.dw_nnt[2 + 3 * b] != k.nnh) return 3;
-      if (c.dw_tb[3 + 3 * b] != tb_blk0 + b * blk_tiles + 4 * k.ntc + 4 * k.nnh || c.dw_nnt[3 + 3 * b] != k.nnh) return 4;
+      if (c.dw_tb[2 + 3 * b] != tb_blk0 + b * blk_tiles + HT * k.ntc || c.dw_nnt[2 + 3 * b] != k.nnh) return 3;
+      if (c.dw_tb[3 + 3 * b] != tb_blk0 + b * blk_tiles + HT * k.ntc + HT * k.nnh || c.dw_nnt[3 + 3 * b] != k.nnh) return 4;
       if (c.WC[b].off != q.wc0 + b * k.sA || c.W1[b].off != q.w10 + b * k.sA || c.W2[b].off != q.w20 + b * k.sA) return 5;
       if (c.W1T[b].off != q.w1t0 + b * k.sT || c.W2T[b].off != q.w2t0 + b * k.sT || c.WCT[b].off != q.wct0 + b * k.sC) return 6;
       if (c.bc[b].off != q.bc0 + b * k.sB || c.b1[b].off != q.b10 + b * k.sB || c.b2[b].off != q.b20 + b * k.sB) return 7;
-      if (c.W1[b].quads != 4 || c.W2[b].quads != 4 || c.W1T[b].quads != 4 || c.W2T[b].quads != 4 || c.WC[b].quads != k.KCQ) return 8;
+      if (c.W1[b].quads != HQ || c.W2[b].quads != HQ || c.W1T[b].quads != HQ || c.W2T[b].quads != HQ || c.WC[b].quads != k.KCQ) return 8;
+      if (c.W1[b].mtiles != HT || c.W2T[b].mtiles != HT || c.WC[b].mtiles != HT) return 14;
     }
     if (c.dw_tb[S.fin] != tb_blk0 + pl.NB * blk_tiles || c.dw_nnt[S.fin] != k.nnh) return 9;
     if (c.dw_tail != (c.dw_tb[S.fin] + c.nft * k.nnh) * 256 || c.dw_tail + pl.D * (pl.D - 1) + 2 * pl.D + 1 > cp.PLP) return 10;
-    if (c.W0.quads != k.KCQ + 1 || c.WF.quads != 4 || c.WFT.quads != S.d_tr * pl.PT || c.W0T.quads != 4) return 11;
+    if (c.W0.quads != k.KCQ + 1 || c.WF.quads != HQ || c.WFT.quads != S.d_tr * pl.PT || c.W0T.quads != HQ) return 11;
     if (c.o_bias % 256 != 0 || c.o_ld >= cp.img_floats) return 12;
+    // the wide kernels' stash slots (h0 | per block t1 t2 sigmoid(gate) h | parameter tiles) and their packed LU inverses
+    if (cp.s_blk != HT || cp.s_par != HT + 4 * HT * pl.NB || cp.slots != cp.s_par + pl.shape[0].d_tr * pl.PT) return 15;
+    if (cp.MT == 2 && (c.UI.mtiles != 1 || c.LI.mtiles != 1 || q.ui != c.UI.off || q.li != c.LI.off || k.KCQ > 4)) return 16;
+    if (cp.MT == 1 && (c.UI.mtiles != 0 || k.KCQ > 2 || c.nft > 16)) return 17;
   }
   if (cfg->D == 10 && cfg->C == 10 && cfg->H == 50 && cfg->K == 10 && cfg->T == 5 && cfg->NB == 2) {
     NsfPlan p4;

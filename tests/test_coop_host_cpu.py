@@ -14,7 +14,10 @@ def _cfg(**kw):
 
 
 SHAPES = [dict(), dict(D=2, C=2), dict(D=16, C=32), dict(D=5, C=3, hidden_features=64, num_blocks=4, num_bins=16),
-          dict(D=7, C=17, hidden_features=33, num_bins=4, num_transforms=3, num_blocks=1), dict(D=15, C=20, num_bins=8)]
+          dict(D=7, C=17, hidden_features=33, num_bins=4, num_transforms=3, num_blocks=1), dict(D=15, C=20, num_bins=8),
+          # hidden 65 ... 128: the wide kernels (eight hidden m-tiles, eight K-quads, x-dim up to 64, packed LU inverses)
+          dict(hidden_features=100), dict(hidden_features=128, num_blocks=4), dict(D=16, C=64, hidden_features=65, num_bins=16),
+          dict(D=2, C=33, hidden_features=96, num_bins=4, num_transforms=2, num_blocks=1)]
 
 
 @pytest.mark.parametrize("kw", SHAPES, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()) or "default")
@@ -44,6 +47,23 @@ def test_row_threshold_routes_calls_and_never_changes_the_packed_size():
     finally:
         lib.sbi_amd_nsf_set_coop_max_rows(prev)
     assert size > 5 * 20000 * 2                                   # throughput image + forward and transposed coop image
+
+
+def test_wide_nets_take_the_cooperative_path_at_every_batch_size():
+    lib = _lib.load()
+    c = _cfg(hidden_features=100)
+    prev = lib.sbi_amd_nsf_set_coop_max_rows(0)          # the switch that turns the narrow cooperative path off ...
+    try:
+        assert [lib.sbi_amd_nsf_image_kind(c, n, t) for n in (1, 200, 65536, 10**6) for t in (0, 1)] == [1] * 8   # ... is ignored
+        assert lib.sbi_amd_nsf_train_workspace_floats(c, 65536) > lib.sbi_amd_nsf_train_workspace_floats(c, 200) > 0
+    finally:
+        lib.sbi_amd_nsf_set_coop_max_rows(prev)
+    # only the cooperative image exists for them; it carries eight m-tiles x eight quads per hidden matrix, both directions
+    assert lib.sbi_amd_nsf_packed_floats(c) > 5 * 2 * (2 * 2 * 128 * 128)
+    # a 16-bin, theta-dim-16 net has 24 final-layer tiles: the narrow kernels (four per wave) leave it to the throughput
+    # kernels, the wide ones loop over them
+    assert lib.sbi_amd_nsf_image_kind(_cfg(D=16, C=8, num_bins=16), 200, 0) == 0
+    assert lib.sbi_amd_nsf_image_kind(_cfg(D=16, C=8, num_bins=16, hidden_features=80), 200, 0) == 1
 
 
 def test_workspace_grows_with_rows_and_switches_workgroup_shape():
