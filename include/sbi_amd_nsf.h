@@ -85,9 +85,9 @@ int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* 
  * launch: csrc/nsf_coop.h; sbi's default training_batch_size = 200, npe_base.py:301-316, lives here).
  * sbi_amd_nsf_image_kind says which image an n-row call reads (0 throughput, 1 cooperative; `training` != 0 for
  * train_forward / train_backward / loss_fwd_bwd); sbi_amd_nsf_pack_images re-packs only the images named in the
- * bit mask (1 throughput, 2 cooperative, 4 the cooperative image's explicit U^-1 / L^-1, which only
- * sbi_amd_nsf_sample of a net with hidden_features > 64 reads) -- a training loop at a fixed batch size needs one of
- * them per step.  sbi_amd_nsf_pack packs everything. */
+ * bit mask (1 throughput, 2 cooperative; 8 / 4: the explicit U^-1 / L^-1 of the throughput / cooperative image, which
+ * only sbi_amd_nsf_sample reads -- hidden_features <= 64: bit 8, above: bit 4) -- a training loop at a fixed batch size
+ * needs ONE of bits 1 / 2 per step and never the inverses.  sbi_amd_nsf_pack packs everything. */
 int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, int32_t training);
 /* Tuning / test hook: calls of at most `rows` rows take the cooperative kernels (0: never; default 12 288 or the
  * environment variable SBI_AMD_COOP_MAX_ROWS); returns the previous value.  Process-wide; images packed before a
@@ -192,7 +192,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 109
+#define SBI_AMD_NSF_ABI_VERSION 110
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

@@ -4,18 +4,19 @@
 #include "nsf_flow_kernel.h"
 #include "nsf_coop_host.h"
 
-// one workgroup per transform: flat parameters -> packed MFMA weight image
+// flat parameters -> packed MFMA weight image, grid (T, workgroups per transform).  inverses = 0: everything but the
+// explicit LU inverses (what log_prob and the training pass read: re-packed every optimizer step); 1: only U^-1 / L^-1,
+// one workgroup per transform (a serial fp64 substitution that only the sampling direction needs)
 __global__ void __launch_bounds__(512)
-nsf_pack_kernel(const NsfPlan pl, const float* __restrict__ params, float* __restrict__ packed) {
+nsf_pack_kernel(const NsfPlan pl, const float* __restrict__ params, float* __restrict__ packed, const int inverses) {
   const int t = blockIdx.x;
   const ShapeDesc& S = pl.shape[pl.ctx_mlp ? 0 : (t & 1)];
   float* img = packed + (long long)t * pl.img_floats;
-  if (blockIdx.y == gridDim.y - 1 && S.l_Ui >= 0) {   // one workgroup of the row does the LU inverses instead
-    pack_lu_inverse(img, params + pl.g_layer[t], S, pl.D, pl.lu_eps, threadIdx.x, blockDim.x);
+  if (inverses) {
+    if (S.l_Ui >= 0) pack_lu_inverse(img, params + pl.g_layer[t], S, pl.D, pl.lu_eps, threadIdx.x, blockDim.x);
     return;
   }
-  const int packers = S.l_Ui >= 0 ? gridDim.y - 1 : gridDim.y;
-  pack_layer(img, params + pl.g_layer[t], pl, S, blockIdx.y * blockDim.x + threadIdx.x, packers * blockDim.x);
+  pack_layer(img, params + pl.g_layer[t], pl, S, blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
 }
 
 
@@ -74,7 +75,8 @@ extern "C" int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, 
 }
 
 // images: bit 0 the throughput image, bit 1 the cooperative image, bit 2 the cooperative image's explicit LU inverses
-// (only the sampling direction of nets with hidden > 64 reads them) (a training loop at a fixed batch size only ever
+// (only the sampling direction of nets with hidden > 64 reads them), bit 3 the throughput image's explicit LU inverses
+// (only sbi_amd_nsf_sample reads them) (a training loop at a fixed batch size only ever
 // needs one of them re-packed per step)
 extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const float* params, float* packed,
                                        int32_t images, void* stream) {
@@ -83,7 +85,9 @@ extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const floa
   int rc = nsf_build_plan(cfg, 1, &pl);
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   if ((images & 1) && pl.img_floats > 0)
-    hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed);
+    hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 24), dim3(256), 0, (hipStream_t)stream, pl, params, packed, 0);
+  if ((images & 8) && pl.img_floats > 0)      // the throughput image's explicit LU inverses (sampling direction only)
+    hipLaunchKernelGGL(nsf_pack_kernel, dim3(pl.T, 1), dim3(256), 0, (hipStream_t)stream, pl, params, packed, 1);
   if (images & 6) {     // bit 1: the cooperative image; bit 2: its explicit LU inverses (sampling direction, wide nets)
     rc = coop_pack(cfg, params, packed + nsf_packed_floats(pl), (images >> 1) & 3, stream);
     if (rc) return rc;
@@ -92,7 +96,7 @@ extern "C" int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const floa
 }
 
 extern "C" int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream) {
-  return sbi_amd_nsf_pack_images(cfg, params, packed, 7, stream);
+  return sbi_amd_nsf_pack_images(cfg, params, packed, 15, stream);
 }
 
 extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,

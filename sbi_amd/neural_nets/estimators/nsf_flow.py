@@ -235,11 +235,11 @@ def packed_weights(net: NSFNet, rows: Optional[int] = None, training: bool = Fal
     cache = net.__dict__.get("_packed_cache")
     lib = _lib.load()
     cfg = net.hyper.c_config()
-    # bits: 1 throughput image, 2 cooperative image, 4 its explicit LU inverses (read by the sampling direction of nets
-    # with hidden_features > 64 only: four times the packing cost of the rest, so not paid per training step)
-    want = 7 if rows is None else (2 if lib.sbi_amd_nsf_image_kind(cfg, int(rows), int(training)) == 1 else 1)
-    if sampling and want == 2:
-        want = 6
+    # bits: 1 throughput image, 2 cooperative image, 8 / 4 their explicit LU inverses (read by the sampling direction
+    # only: a serial fp64 substitution per transform, not paid per training step)
+    want = 15 if rows is None else (2 if lib.sbi_amd_nsf_image_kind(cfg, int(rows), int(training)) == 1 else 1)
+    if sampling:
+        want |= 4 if want == 2 else 8
     have = 0
     if cache is not None and cache[0] == key:
         have = net.__dict__.get("_packed_images", 0)
