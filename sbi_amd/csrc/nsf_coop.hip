@@ -225,8 +225,8 @@ extern "C" int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg) {
     if (c.o_bias % 256 != 0 || c.o_ld >= cp.img_floats) return 12;
     // the wide kernels' stash slots (h0 | per block t1 t2 sigmoid(gate) h | parameter tiles) and their packed LU inverses
     if (cp.s_blk != HT || cp.s_par != HT + 4 * HT * pl.NB || cp.slots != cp.s_par + pl.shape[0].d_tr * pl.PT) return 15;
-    if (cp.MT == 2 && (c.UI.mtiles != 1 || c.LI.mtiles != 1 || q.ui != c.UI.off || q.li != c.LI.off || k.KCQ > 4)) return 16;
-    if (cp.MT == 1 && (c.UI.mtiles != 0 || k.KCQ > 2 || c.nft > 16)) return 17;
+    if (c.UI.mtiles != 1 || c.LI.mtiles != 1 || q.ui != c.UI.off || q.li != c.LI.off) return 16;
+    if (k.KCQ > (cp.MT == 2 ? 4 : 2) || (cp.MT == 1 && c.nft > 16)) return 17;
   }
   if (cfg->D == 10 && cfg->C == 10 && cfg->H == 50 && cfg->K == 10 && cfg->T == 5 && cfg->NB == 2) {
     NsfPlan p4;

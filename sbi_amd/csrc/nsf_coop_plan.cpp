@@ -79,10 +79,8 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
     add_mat(&c.W0T, &o, 1, HQ, CO_K_W0T, 0);
     add_mat(&c.UT, &o, 1, 1, CO_K_UT, -1);
     add_mat(&c.LT, &o, 1, 1, CO_K_LT, -1);
-    if (wide) {
-      add_mat(&c.UI, &o, 1, 1, CO_K_UI, -1);
-      add_mat(&c.LI, &o, 1, 1, CO_K_LI, -1);
-    }
+    add_mat(&c.UI, &o, 1, 1, CO_K_UI, -1);       // explicit inverses: the sampling direction (nsf_coop_wide_kernel.h)
+    add_mat(&c.LI, &o, 1, 1, CO_K_LI, -1);
     for (int b = 0; b < pl.NB; ++b) add_mat(&c.WCT[b], &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 1 + 3 * b);
     add_mat(&c.W0CT, &o, (pl.C + 15) / 16, HQ, CO_K_CTX_T, 0);
     c.o_bias = o;        // (256-aligned: every matrix block is 256 floats) the bias blocks and the log-det slot follow

@@ -18,21 +18,23 @@
 #define COW_CQ 4      // K-quads of the context part of the initial / gate layers: x-dim <= 64 (no throughput kernel to
                       // fall back to at this width, so the wide kernels take twice the narrow kernels' x-dim)
 
-// all-gather of the eight hidden D fragments (wave w holds m-tiles w and w + 4); one barrier
-__device__ __forceinline__ void cow_gather(float* __restrict__ ex, int& buf, int wave, int lane, const f4 (&mine)[2],
-                                           f4 (&out)[COW_HT]) {
-  f4* e = reinterpret_cast<f4*>(ex) + buf * (COW_HT * 64);
-  e[wave * 64 + lane] = mine[0];
-  e[(wave + CO_WAVES) * 64 + lane] = mine[1];
+// all-gather of the 4 MT hidden D fragments (wave w holds m-tiles w, w + 4, ...); one barrier
+template <int MT>
+__device__ __forceinline__ void cow_gather(float* __restrict__ ex, int& buf, int wave, int lane, const f4 (&mine)[MT],
+                                           f4 (&out)[4 * MT]) {
+  f4* e = reinterpret_cast<f4*>(ex) + buf * (4 * MT * 64);
+#pragma unroll
+  for (int q = 0; q < MT; ++q) e[(wave + CO_WAVES * q) * 64 + lane] = mine[q];
   __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < COW_HT; ++mt) out[mt] = e[mt * 64 + lane];
+  for (int mt = 0; mt < 4 * MT; ++mt) out[mt] = e[mt * 64 + lane];
   buf ^= 1;
 }
-// acc += A (one m-tile, eight quads) * B (the eight gathered fragments): 32 K-steps
-__device__ __forceinline__ void cow_gemm(const f4 (&a)[COW_KQ], const f4 (&b)[COW_HT], f4& acc) {
+// acc += A (one m-tile, KQ quads) * B (the KQ gathered fragments): 4 KQ K-steps
+template <int KQ>
+__device__ __forceinline__ void cow_gemm(const f4 (&a)[KQ], const f4 (&b)[KQ], f4& acc) {
 #pragma unroll
-  for (int s = 0; s < 4 * COW_KQ; ++s) acc = MFMA16(a[s >> 2][s & 3], b[s >> 2][s & 3], acc);
+  for (int s = 0; s < 4 * KQ; ++s) acc = MFMA16(a[s >> 2][s & 3], b[s >> 2][s & 3], acc);
 }
 // acc += A (context quads) * standardized context (K-steps of the context live in registers)
 __device__ __forceinline__ void cow_gemm_ctx(const f4 (&a)[COW_CQ], int kcq, const float (&cb)[4 * COW_CQ], f4& acc) {
@@ -45,7 +47,9 @@ __device__ __forceinline__ void cow_gemm_ctx(const f4 (&a)[COW_CQ], int kcq, con
 }
 
 // ------------------------------------------------------------------------------------------------ forward / inverse
-template <int K, bool INV>
+// MT = hidden m-tiles per wave: 2 (hidden 65 ... 128: eight m-tiles, eight K-quads) or 1 (hidden <= 64: four / four, the
+// narrow image) -- the latter is instantiated for the SAMPLING direction only, which the tuned narrow family lacks.
+template <int K, bool INV, int MT>
 __global__ void __launch_bounds__(64 * CO_WAVES, 1)
 nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __restrict__ zstats,
                      const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
@@ -53,6 +57,7 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
                      float* __restrict__ ast) {
   constexpr int PT = (3 * K - 1 + 15) / 16;
   constexpr int R = 16;
+  constexpr int HT = 4 * MT, KQ = 4 * MT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6;
   const LaneId id = make_lane();
@@ -128,9 +133,9 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
       __syncthreads();
     }
     // ---- initial layer: h = W0 [context ; z_id] + b0   (m-tiles wave, wave + 4)
-    f4 h[2], gate[2], tt[2];
+    f4 h[MT], gate[MT], tt[MT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < MT; ++q) {
       const int mt = wave + CO_WAVES * q;
       f4 a[COW_CQ + 1];
       co_load_a<COW_CQ + 1>(img + kp.w0 + mt * (kcq + 1) * 256, id.lane, a);
@@ -153,23 +158,23 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
     //  trips better than requesting a block's matrices up front at one wave per SIMD -- measured: 0.95 vs 1.65 ms at
     //  65 536 rows, 0.072 vs 0.077 ms at 200)
     for (int b = 0; b < NB; ++b) {
-      f4 bg[COW_HT];
+      f4 bg[HT];
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < MT; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) tt[q][r] = fmaxf(h[q][r], 0.f);
-      cow_gather(ex, buf, wave, id.lane, tt, bg);
-      const int sb = k.s_blk + 4 * COW_HT * b;      // stash slots of the block: t1 | t2 | sigmoid(gate) | h_{b+1}
+      cow_gather<MT>(ex, buf, wave, id.lane, tt, bg);
+      const int sb = k.s_blk + 4 * HT * b;      // stash slots of the block: t1 | t2 | sigmoid(gate) | h_{b+1}
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < MT; ++q) {
         const int mt = wave + CO_WAVES * q;
-        f4 a[COW_KQ], ac[COW_CQ];
-        co_load_a<COW_KQ>(img + kp.w10 + b * k.sA + mt * COW_KQ * 256, id.lane, a);
+        f4 a[KQ], ac[COW_CQ];
+        co_load_a<KQ>(img + kp.w10 + b * k.sA + mt * KQ * 256, id.lane, a);
         co_load_a<COW_CQ>(img + kp.wc0 + b * k.sA + mt * kcq * 256, id.lane, ac);
         f4 u1 = co_load_bias(img + kp.b10 + b * k.sB, mt, id.g);
         gate[q] = co_load_bias(img + kp.bc0 + b * k.sB, mt, id.g);
         cow_gemm_ctx(ac, kcq, cb, gate[q]);
-        cow_gemm(a, bg, u1);
+        cow_gemm<KQ>(a, bg, u1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gate[q][r] = sigmoid_f(gate[q][r]);
@@ -177,34 +182,34 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
         }
         if (ab) {
           *reinterpret_cast<f4*>(ab + (sb + mt) * 256) = u1;                         // t1 (pre-relu)
-          *reinterpret_cast<f4*>(ab + (sb + 2 * COW_HT + mt) * 256) = gate[q];       // sigmoid(gate)
+          *reinterpret_cast<f4*>(ab + (sb + 2 * HT + mt) * 256) = gate[q];       // sigmoid(gate)
         }
       }
-      cow_gather(ex, buf, wave, id.lane, tt, bg);
+      cow_gather<MT>(ex, buf, wave, id.lane, tt, bg);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < MT; ++q) {
         const int mt = wave + CO_WAVES * q;
-        f4 a[COW_KQ];
-        co_load_a<COW_KQ>(img + kp.w20 + b * k.sA + mt * COW_KQ * 256, id.lane, a);
+        f4 a[KQ];
+        co_load_a<KQ>(img + kp.w20 + b * k.sA + mt * KQ * 256, id.lane, a);
         f4 u2 = co_load_bias(img + kp.b20 + b * k.sB, mt, id.g);
-        cow_gemm(a, bg, u2);
+        cow_gemm<KQ>(a, bg, u2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[q][r] += u2[r] * gate[q][r];
         if (ab) {
-          *reinterpret_cast<f4*>(ab + (sb + COW_HT + mt) * 256) = u2;                // t2
-          *reinterpret_cast<f4*>(ab + (sb + 3 * COW_HT + mt) * 256) = h[q];          // h_{b+1}
+          *reinterpret_cast<f4*>(ab + (sb + HT + mt) * 256) = u2;                // t2
+          *reinterpret_cast<f4*>(ab + (sb + 3 * HT + mt) * 256) = h[q];          // h_{b+1}
         }
       }
     }
     // ---- final layer: parameter tiles wave, wave + 4, ... -> staging rows pst[row][dim][3K-1 raw outputs]
     {
-      f4 hb[COW_HT];
-      cow_gather(ex, buf, wave, id.lane, h, hb);
+      f4 hb[HT];
+      cow_gather<MT>(ex, buf, wave, id.lane, h, hb);
       for (int mt = wave; mt < kp.nft; mt += CO_WAVES) {
-        f4 a[COW_KQ];
-        co_load_a<COW_KQ>(img + kp.wf + mt * COW_KQ * 256, id.lane, a);
+        f4 a[KQ];
+        co_load_a<KQ>(img + kp.wf + mt * KQ * 256, id.lane, a);
         f4 acc = co_load_bias(img + kp.bf, mt, id.g);
-        cow_gemm(a, hb, acc);
+        cow_gemm<KQ>(a, hb, acc);
         const int dd = mt / PT, pt = mt - dd * PT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pst[id.j * k.DSTR + dd * k.PSW + 16 * pt + 4 * r + id.g] = acc[r];
@@ -272,11 +277,11 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
   }
 }
 
-template <int K, bool INV>
+template <int K, bool INV, int MT>
 static int cow_launch_fwd(const CoK& k, const CoopPlan& cp, const float* cimg, const float* zstats, const float* in,
                           const float* x, long long n, long long x_rows, float* out_main, float* out_aux, float* zst,
                           float* ast, hipStream_t st) {
-  auto kern = nsf_coopw_fwd_kernel<K, INV>;
+  auto kern = nsf_coopw_fwd_kernel<K, INV, MT>;
   const int lds_bytes = 4 * cp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
@@ -633,7 +638,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           f4 gr = zero4;
-          cow_gemm(a2t[q], bg[u], gr);
+          cow_gemm<COW_KQ>(a2t[q], bg[u], gr);
 #pragma unroll
           for (int r = 0; r < 4; ++r) ga[q][u][r] = t1[q][u][r] > 0.f ? gr[r] : 0.f;     // d t1
         }
@@ -666,7 +671,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           f4 gr = zero4;
-          cow_gemm(a1t[q], bg[u], gr);
+          cow_gemm<COW_KQ>(a1t[q], bg[u], gr);
 #pragma unroll
           for (int r = 0; r < 4; ++r) gh[q][u][r] += hin[q][u][r] > 0.f ? gr[r] : 0.f;
         }
@@ -693,7 +698,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           f4 gin = zero4;
-          cow_gemm(a0t, bg[u], gin);
+          cow_gemm<COW_KQ>(a0t, bg[u], gin);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kk = 4 * r + id.g;
@@ -751,7 +756,7 @@ int co_fwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStrea
       if (rc) return rc;
     }
     coop_make_consts(pl, cf, &k);
-    return cow_launch_fwd<K, false>(k, cf, a.cimg, a.zstats, a.theta, a.x, a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast,
+    return cow_launch_fwd<K, false, 2>(k, cf, a.cimg, a.zstats, a.theta, a.x, a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast,
                                     st);
   }
   if (cp.NT == 2 && coop_lean_forward()) {
@@ -768,11 +773,11 @@ int co_fwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStrea
   if (pl.KSH == 13) return cp.NT == 2 ? co_launch_fwd<K, 13, 2, false>(k, cp, a, st) : co_launch_fwd<K, 13, 1, false>(k, cp, a, st);
   return cp.NT == 2 ? co_launch_fwd<K, 16, 2, false>(k, cp, a, st) : co_launch_fwd<K, 16, 1, false>(k, cp, a, st);
 }
-// sampling direction (wide nets only: the narrow ones keep the throughput kernel nsf_flow_kernel<..., INV = true>)
+// sampling direction: wide nets at every batch size; narrow nets (MT = 1 instantiation of the same kernel) for the small
+// calls the cooperative family takes -- above, they keep the throughput kernel nsf_flow_kernel<..., INV = true>
 template <int K>
 int co_inv_k(const NsfPlan& pl, const CoopPlan& cp, const float* cimg, const float* zstats, const float* noise,
              const float* x, long long n, long long x_rows, float* theta_out, float* logabsdet_out, hipStream_t st) {
-  if (cp.MT != 2) return SBI_AMD_E_UNSUPPORTED;
   CoK k;
   CoopPlan cf = cp;
   if (cp.NT != 1) {
@@ -780,7 +785,9 @@ int co_inv_k(const NsfPlan& pl, const CoopPlan& cp, const float* cimg, const flo
     if (rc) return rc;
   }
   coop_make_consts(pl, cf, &k);
-  return cow_launch_fwd<K, true>(k, cf, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, st);
+  if (cp.MT == 2)
+    return cow_launch_fwd<K, true, 2>(k, cf, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, st);
+  return cow_launch_fwd<K, true, 1>(k, cf, cimg, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, st);
 }
 template <int K>
 int co_bwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoBwdArgs& a, hipStream_t st) {

@@ -115,13 +115,18 @@ extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* 
 extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                   const float* noise, const float* x, int64_t n, int64_t x_rows,
                                   float* theta_out, float* logabsdet_out, void* stream) {
-  if (n > 0 && cfg && cfg->H > 16 * NSF_HT) {     // hidden > 64: the wide cooperative kernel, sampling direction
-    if (!packed || !zstats || !noise || !x || !theta_out || x_rows < 1) return SBI_AMD_E_BADARG;
+  if (n > 0 && cfg) {
+    // hidden > 64: the wide cooperative kernel at every batch size; narrower nets: its one-m-tile-per-wave instantiation
+    // for the small calls the cooperative family takes (half the latency of the throughput kernel below ~4 000 draws)
     NsfPlan pl;
     CoopPlan cp;
-    if (!coop_applies(cfg, n, false, &pl, &cp)) return SBI_AMD_E_UNSUPPORTED;
-    return coop_sample(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, noise, x, n, x_rows, theta_out,
-                       logabsdet_out, stream);
+    const bool wide = cfg->H > 16 * NSF_HT;
+    if (coop_applies(cfg, n, false, &pl, &cp)) {
+      if (!packed || !zstats || !noise || !x || !theta_out || x_rows < 1) return SBI_AMD_E_BADARG;
+      return coop_sample(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, noise, x, n, x_rows, theta_out,
+                         logabsdet_out, stream);
+    }
+    if (wide) return SBI_AMD_E_UNSUPPORTED;
   }
   return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, stream);
 }

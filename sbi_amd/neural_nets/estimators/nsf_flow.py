@@ -290,8 +290,9 @@ def _sample_call(net: NSFNet, noise: Tensor, x: Tensor, want_ld: bool) -> Tuple[
     if n == 0:
         return theta, ld
     cfg = net.hyper.c_config()
-    # (the sampling direction runs on the throughput kernels; hidden > 64: on the wide cooperative kernel + LU inverses)
-    packed = packed_weights(net, rows=0, sampling=True)
+    # (small calls and every call of a net with hidden > 64 run on the cooperative kernels, the rest on the throughput
+    #  kernel: sbi_amd_nsf_image_kind answers for the sampling direction as it does for log_prob; + the LU inverses)
+    packed = packed_weights(net, rows=n, sampling=True)
     with torch.cuda.device(dev):
         rc = lib.sbi_amd_nsf_sample(
             cfg, _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(noise), _lib.ptr(x), n, x.shape[0],

@@ -206,7 +206,11 @@ def test_packed_weights_repacks_only_the_image_a_call_reads():
         a = est.log_prob(theta[:100].cuda(), x[:100].cuda())[0]
         assert net.__dict__["_packed_images"] == 2
         b = est.sample_from_noise(torch.randn(100, 4, device="cuda"), x[:100].cuda())
-        assert net.__dict__["_packed_images"] == 11 and torch.isfinite(a).all() and torch.isfinite(b).all()
+        # a small sampling call reads the cooperative image + its LU inverses (bit 4); a large one the throughput
+        # image + its inverses (bit 8)
+        assert net.__dict__["_packed_images"] == 6 and torch.isfinite(a).all() and torch.isfinite(b).all()
+        est.sample_from_noise(torch.randn(20000, 4, device="cuda"), x[:1].cuda())
+        assert net.__dict__["_packed_images"] == 15
     with family("throughput"):
         c = est.log_prob(theta[:100].cuda(), x[:100].cuda())[0]
     assert (a - c).abs().max() <= 1e-4
@@ -240,3 +244,35 @@ def test_npe_default_batch_trains_on_the_cooperative_kernels():
     score = float(c2st(s, ref))
     record("coop_npe_c2st", "D3-batch200", c2st=score)
     assert 0.42 <= score <= 0.6, score
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=_ids)
+def test_sampling_direction_matches_oracle_and_throughput_kernel(cfg):
+    """Small sampling calls run on the cooperative inverse kernel (one-m-tile instantiation of nsf_coopw_fwd_kernel with
+    the packed LU inverses): against the oracle, against the throughput inverse kernel, and as the inverse of log_prob's
+    transform, ragged row counts included."""
+    oracle, est, theta_d, x_d = matched_pair(**cfg)
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 17, 600, 5000):
+        noise = torch.randn(n, cfg["D"], generator=g)
+        x = x_d[:n] if n <= x_d.shape[0] else x_d[torch.randint(0, x_d.shape[0], (n,), generator=g)]
+        with torch.no_grad():
+            ref, ref_ld = oracle.sample_from_noise(noise, x)
+        with family("cooperative"):
+            got, got_ld = est.sample_from_noise(noise.cuda(), x.cuda(), with_logabsdet=True)
+            back = est.inverse_transform(got, x.cuda())
+        with family("throughput"):
+            try:
+                thr, thr_ld = est.sample_from_noise(noise.cuda(), x.cuda(), with_logabsdet=True)
+            except RuntimeError:
+                thr = None
+        scale = max(1.0, ref.abs().max().item())
+        e = (got.cpu() - ref).abs().max().item()
+        e_ld = (got_ld.cpu() - ref_ld).abs().max().item()
+        record("coop_sample", _ids(cfg) + f" | n={n}", max_abs_coop_vs_oracle32=e, max_abs_logabsdet=e_ld,
+               max_abs_ref=ref.abs().max().item())
+        assert e <= 2e-5 * scale and e_ld <= 2e-5 * max(1.0, ref_ld.abs().max().item()) + 1e-5, (n, e, e_ld)
+        assert (back.cpu() - noise).abs().max().item() <= 2e-4 * max(1.0, noise.abs().max().item()), n
+        if thr is not None:
+            assert (got - thr).abs().max().item() <= 4e-5 * scale, n
+            assert (got_ld - thr_ld).abs().max().item() <= 4e-5 * max(1.0, ref_ld.abs().max().item()) + 2e-5, n

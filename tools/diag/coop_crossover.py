@@ -1,5 +1,5 @@
-"""Where do the cooperative small-batch kernels stop paying?  Device time of log_prob and of the fused training step
-at several batch sizes, once per kernel family (sbi_amd_nsf_set_coop_max_rows)."""
+"""Where do the cooperative small-batch kernels stop paying?  Device time of log_prob, of the sampling direction and of
+the fused training step at several batch sizes, once per kernel family (sbi_amd_nsf_set_coop_max_rows)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from sbi_amd import _lib
@@ -33,8 +33,10 @@ for B in [int(a) for a in sys.argv[1:]] or [200, 1024, 4096, 8192, 12288, 16384,
     for fam, rows in (("coop", 1 << 40), ("thr", 0)):
         lib.sbi_amd_nsf_set_coop_max_rows(rows)
         st = FusedTrainStep(est)
+        nz = torch.randn(B, 10, device="cuda")
         with torch.no_grad():
             lp = dev_ms(lambda: est.log_prob(tb, xb))
+            sm = dev_ms(lambda: est.sample_from_noise(nz, xb))
         tr = dev_ms(lambda: st.step(tb, xb))
-        out.append(f"{fam}: log_prob {lp:.3f} ms, train step {tr:.3f} ms")
+        out.append(f"{fam}: log_prob {lp:.3f} ms, sample {sm:.3f} ms, train step {tr:.3f} ms")
     print(f"batch {B:6d} | " + " | ".join(out), flush=True)
