@@ -9,8 +9,13 @@
 // same partial slabs and reduction as the narrow kernels; one 16-row tile per workgroup at any batch size.  The schedule is
 // the plain one (weights requested where they are used, the stash written where it is produced): these kernels exist for
 // coverage of the shape, the tuned pipeline of nsf_coop_kernel.h is not repeated here.
-//   nsf_coopw_fwd_kernel<K, INV>   log p (+ noise, + training stash)  |  INV: the sampling direction (theta from noise)
-//   nsf_coopw_bwd_kernel<K>        all T transforms backward in one launch, partial slabs as the narrow kernel writes them
+//   nsf_coopw_fwd_kernel<K, INV, MT>   log p (+ noise, + training stash)  |  INV: the sampling direction (theta from noise,
+//                                      nflows Flow._sample -> CompositeTransform.inverse behind NFlowsFlow.sample,
+//                                      nflows_flow.py:111-128), with U^-1 / L^-1 packed into the image.  MT = 2: the wide nets;
+//                                      MT = 1 (hidden <= 64, the narrow image) is instantiated for INV only: small sampling
+//                                      calls of ordinary nets, which the tuned narrow family has no kernel for
+//   nsf_coopw_bwd_kernel<K, NT>        all T transforms backward in one launch, partial slabs as the narrow kernel writes
+//                                      them; NT = 16-row tiles per workgroup (two above 4 096 rows when they fit LDS)
 #include "nsf_coop_kernel.h"
 
 #define COW_HT 8      // hidden m-tiles
