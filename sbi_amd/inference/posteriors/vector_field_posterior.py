@@ -107,6 +107,10 @@ class VectorFieldPosterior:
         exact Jacobian trace comes out of the same HIP launch as the velocity (``sbi_amd_fmpe_velocity_div``); the
         state of all rows, log-det included, stays on the device for the whole solve (``odeint_dopri5``).
 
+        ``x`` with more than one row is a set of iid observations (vector_field_posterior.py:489-497,
+        vector_field_potential.py:175-192): the log-densities of the per-observation flows are summed and
+        ``(n_iid - 1) * prior.log_prob(theta)`` is subtracted; that needs a prior.
+
         ``ode_kwargs``: ``atol`` / ``rtol`` (defaults: the posterior's, sbi's 1e-6 / 1e-5); ``exact=False`` (zuko's
         Hutchinson estimate) is not offered."""
         if track_gradients:
@@ -117,8 +121,15 @@ class VectorFieldPosterior:
         atol, rtol = float(kw.pop("atol", self.atol)), float(kw.pop("rtol", self.rtol))
         if kw:
             raise TypeError(f"unsupported ode_kwargs: {sorted(kw)}")
-        x = self._x_else_default_x(x)
         est = self.vector_field_estimator
+        if x is not None and torch.as_tensor(x).dim() == len(est.condition_shape) + 1 and torch.as_tensor(x).shape[0] > 1:
+            xs = torch.as_tensor(x, dtype=torch.float32).to(self._device)
+            if xs.shape[1:] != est.condition_shape:
+                raise ValueError(f"expected observations of shape {tuple(est.condition_shape)}, got {tuple(xs.shape[1:])}")
+            if self.prior is None:
+                raise AssertionError("Prior is required for evaluating log_prob with iid observations.")
+        else:
+            xs = self._x_else_default_x(x)
         D = est.input_shape[0]
         theta = torch.as_tensor(theta, dtype=torch.float32)
         if theta.dim() == 1:
@@ -129,8 +140,13 @@ class VectorFieldPosterior:
         if theta.shape[0] == 0:
             return torch.empty(0, dtype=torch.float32, device=self._device)
         cap = max_batch_size or self.max_sampling_batch_size
-        out = [self._log_prob_via_ode(theta[i : i + cap], x, atol, rtol) for i in range(0, theta.shape[0], cap)]
-        log_probs = torch.cat(out)
+        log_probs = torch.zeros(theta.shape[0], dtype=torch.float32, device=self._device)
+        for i_obs in range(xs.shape[0]):          # one flow per iid observation (one observation: the usual case)
+            x_i = xs[i_obs : i_obs + 1]
+            log_probs = log_probs + torch.cat([self._log_prob_via_ode(theta[i : i + cap], x_i, atol, rtol)
+                                               for i in range(0, theta.shape[0], cap)])
+        if xs.shape[0] > 1:
+            log_probs = log_probs - (xs.shape[0] - 1) * self.prior.log_prob(theta).reshape(-1)
         if self.prior is not None:
             inside = within_support(self.prior, theta)
             log_probs = torch.where(inside, log_probs, torch.full_like(log_probs, float("-inf")))

@@ -130,6 +130,24 @@ def test_log_prob_is_minus_inf_outside_the_prior_and_validates_arguments():
     assert post.log_prob(torch.zeros(0, 3)).shape == (0,)
 
 
+def test_iid_observations_sum_the_flows_and_subtract_the_prior():
+    """x with several rows = iid observations (vector_field_potential.py:175-192): sum_i log p(theta | x_i) - (n - 1) log
+    p(theta); one row of x behaves as before; no prior is an error."""
+    from sbi_amd.inference.posteriors.vector_field_posterior import VectorFieldPosterior
+
+    o64, est, theta, x = make_pair(D=3, C=2, H=32, L=1)
+    post = _posterior(est, 3)
+    th = theta[:20] * 0.5
+    xs = x[:3]
+    singles = torch.stack([post.log_prob(th, x=xs[i : i + 1]) for i in range(3)])
+    iid = post.log_prob(th, x=xs)
+    want = singles.sum(0) - 2.0 * post.prior.log_prob(th.cuda())
+    assert (iid - want).abs().max().item() <= 1e-4
+    assert torch.equal(post.log_prob(th, x=xs[:1]), singles[0])
+    with pytest.raises(AssertionError):
+        VectorFieldPosterior(est, None).log_prob(th, x=xs)
+
+
 def test_density_integrates_to_one_in_one_dimension():
     """theta-dim 1: exp(log_prob) over a wide grid integrates to one -- sign of the log-det and direction of the solve."""
     o64, est, theta, x = make_pair(D=1, C=2, H=32, L=2, scale=0.3)
