@@ -423,10 +423,11 @@ class PosteriorEstimatorTrainer:
 
         # Fused MLE steps on a ROCm device: the epoch's order is never materialised -- one launch per minibatch
         # gathers the batch's rows in a fresh keyed pseudo-random order of the training split (utils/shuffle.py;
-        # SubsetRandomSampler + collation of base.py:541-560).  The atomic loss (it also needs the prior masks of the
-        # batch) and the autograd path keep the index tensors.
+        # SubsetRandomSampler + collation of base.py:541-560).  The atomic loss also needs the prior masks of the batch:
+        # it takes the batch's source rows from the same sampler (`indices`) and gathers with them; the autograd path
+        # keeps the argsort permutations.
         sampler = None
-        if fused and not atomic:
+        if fused:
             from sbi_amd.utils.shuffle import ShuffledGather
 
             sg_seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
@@ -448,10 +449,13 @@ class PosteriorEstimatorTrainer:
                 rec["ev0"].record()
             net.train()
             sums = torch.zeros(2, device=self._device)
-            if sampler is not None:
+            if sampler is not None and not atomic:
                 for b in range(n_train_batches):
                     th, xx = sampler.batch(e, *my_range(b * B, B))
                     sums[0] += self._stepper.step(th, xx, global_batch=B).sum()
+            elif sampler is not None:
+                for b in range(n_train_batches):
+                    sums[0] += batch_losses(sampler.indices(e, *my_range(b * B, B)), True, B).sum()
             else:
                 order = perm_of(n_train)   # SubsetRandomSampler
                 epoch_idx = train_idx[order]
