@@ -81,7 +81,7 @@ int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* 
 
 /* `packed` holds two images: the throughput kernels' (one LDS image per transform) and, for the shapes they take
  * (theta-dim 2..16, x-dim <= 32), the fragment-ordered image of the latency-oriented kernels that calls of at most
- * 12 288 rows are routed to (four cooperating wavefronts per 16-row tile, all transforms of the backward pass in one
+ * 12 288 rows (training passes: 8 192) are routed to (four cooperating wavefronts per 16-row tile, all transforms of the backward pass in one
  * launch: csrc/nsf_coop.h; sbi's default training_batch_size = 200, npe_base.py:301-316, lives here).
  * sbi_amd_nsf_image_kind says which image an n-row call reads (0 throughput, 1 cooperative; `training` != 0 for
  * train_forward / train_backward / loss_fwd_bwd); sbi_amd_nsf_pack_images re-packs only the images named in the
@@ -89,8 +89,9 @@ int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* 
  * only sbi_amd_nsf_sample reads -- hidden_features <= 64: bit 8, above: bit 4) -- a training loop at a fixed batch size
  * needs ONE of bits 1 / 2 per step and never the inverses.  sbi_amd_nsf_pack packs everything. */
 int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, int32_t training);
-/* Tuning / test hook: calls of at most `rows` rows take the cooperative kernels (0: never; default 12 288 or the
- * environment variable SBI_AMD_COOP_MAX_ROWS); returns the previous value.  Process-wide; images packed before a
+/* Tuning / test hook: calls of at most `rows` rows take the cooperative kernels (0: never; default 12 288, and 8 192
+ * for training passes; the environment variable SBI_AMD_COOP_MAX_ROWS, like this call, sets both); returns the
+ * previous value.  Process-wide; images packed before a
  * change stay valid (both images live in `packed`), but a training workspace belongs to the path that sized it. */
 int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows);
 int sbi_amd_nsf_pack_images(const sbi_amd_nsf_config* cfg, const float* params, float* packed, int32_t images,

@@ -113,5 +113,6 @@ void coop_make_consts(const NsfPlan& pl, const CoopPlan& cp, CoK* k);
 int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, CoopPlan* cp);
 // rows up to which the cooperative path is preferred (env SBI_AMD_COOP_MAX_ROWS overrides; 0 disables)
 int64_t coop_max_rows();
+int64_t coop_train_rows();  // the same for the training pass (default 8 192)
 bool coop_lean_forward();   // forward pass of > 4096-row calls as one-tile workgroups, two to a CU (nsf_coop_plan.cpp)
 static inline int64_t coop_image_floats(const NsfPlan& pl, const CoopPlan& cp) { return (int64_t)pl.T * cp.img_floats; }

@@ -27,7 +27,7 @@ bool coop_applies(const sbi_amd_nsf_config* cfg, int64_t n, bool training, NsfPl
   if (rc && rc != SBI_AMD_E_LDS) return false;   // (E_LDS speaks about the throughput kernels' weight image)
   // hidden > 64: the wide cooperative kernels are the ONLY path, at every batch size and whatever the switches say
   const bool wide = pl->H > 16 * NSF_HT;
-  if (!wide && (n > coop_max_rows() || (sbi_amd_dbg_ablate() & 16384))) return false;
+  if (!wide && (n > (training ? coop_train_rows() : coop_max_rows()) || (sbi_amd_dbg_ablate() & 16384))) return false;
   return coop_build_plan(*pl, n, 0, training, cp) == 0;
 }
 // Is there a cooperative image for this configuration at all (any n)?  Deliberately independent of the row

@@ -6,18 +6,26 @@
 
 static int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 
-static int64_t g_coop_max_rows = -1;
+// measured cross-overs against the throughput kernels: log_prob and the sampling direction win up to
+// 12 288 rows; the training pass up to 8 192 rows (256 two-tile backward workgroups = one round; beyond, the throughput
+// backward kernel's persistent workgroups are faster)
+static int64_t g_coop_max_rows = -1, g_coop_train_rows = -1;
 int64_t coop_max_rows() {
   if (g_coop_max_rows < 0) {
     const char* a = getenv("SBI_AMD_COOP_MAX_ROWS");
-    g_coop_max_rows = a ? atoll(a) : 12288;   // measured cross-over against the throughput kernels: DESIGN.md section 4
+    g_coop_max_rows = a ? atoll(a) : 12288;
+    g_coop_train_rows = a ? g_coop_max_rows : 8192;      // (the environment variable and the setter move both)
   }
   return g_coop_max_rows;
+}
+int64_t coop_train_rows() {
+  coop_max_rows();
+  return g_coop_train_rows;
 }
 // tuning / test hook: route calls of <= `rows` rows to the cooperative kernels (0: never); returns the previous value
 extern "C" int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows) {
   const int64_t prev = coop_max_rows();
-  g_coop_max_rows = rows < 0 ? 0 : rows;
+  g_coop_max_rows = g_coop_train_rows = rows < 0 ? 0 : rows;
   return prev;
 }
 

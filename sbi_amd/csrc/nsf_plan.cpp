@@ -25,22 +25,36 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl) {
 }
 
 int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out, bool wide) {
-  // 16 rows per wave; aim for >= 256 workgroups (one per CU) before growing the workgroup: 8, 4, 2, 1 waves.
+  // 16 rows per wave, 1 / 2 / 4 / 8 waves per workgroup, one workgroup per CU at a time (the weight image fills most of a
+  // CU's LDS): the launch runs in ceil(workgroups / 256) rounds of roughly equal length whatever the workgroup size
+  // (measured per round: 0.085 / 0.083 / 0.10 ms for 2 / 4 / 8 waves), so the size is chosen to minimise the rounds --
+  // 12 288 rows as 192 four-wave workgroups in ONE round (0.083 ms) rather than 384 two-wave workgroups in two (0.166),
+  // 24 576 rows as 192 eight-wave workgroups rather than 384 four-wave ones -- and, among equals, to spread over more CUs.
   // `wide` (the sampling direction): 12 waves (3 per SIMD, single staging buffer per wave) when there are enough rows
   // and the image leaves room; SBI_AMD_ABLATE bit 4096 switches it off (the density direction is compiled for <= 8 waves and never takes it).
   const int abl = sbi_amd_dbg_ablate();
   if (wide && !(abl & (1024 | 4096)) && (n + 16 * 12 - 1) / (16 * 12) >= 256) {
     if (nsf_build_plan(cfg, 12, pl) == 0) { *nw_out = 12; return 0; }
   }
-  int nw = 8;
-  while (nw > 1 && (n + 16 * nw - 1) / (16 * nw) < 256) nw >>= 1;
-  if ((sbi_amd_dbg_ablate() & 1024) && nw > 4) nw = 4;   // debug aid: forward kernel with one wave per SIMD
-  for (; nw >= 1; nw >>= 1) {
-    int rc = nsf_build_plan(cfg, nw, pl);
-    if (rc == 0) { *nw_out = nw; return 0; }
-    if (rc != SBI_AMD_E_LDS) return rc;
+  const int nw_max = (abl & 1024) ? 4 : 8;               // debug aid: forward kernel with one wave per SIMD
+  int best = 0;
+  double best_cost = 0.0;
+  NsfPlan cand;
+  for (int nw = nw_max; nw >= 1; nw >>= 1) {
+    const int rc = nsf_build_plan(cfg, nw, &cand);
+    if (rc == SBI_AMD_E_LDS) continue;
+    if (rc) return rc;
+    const int64_t wgs = (n + 16 * nw - 1) / (16 * nw);
+    const double cost = (double)((wgs + 255) / 256) * (nw == 8 ? 1.2 : 1.0);      // two waves per SIMD: ~1.2 x per round
+    if (best == 0 || cost <= best_cost) {          // (<=: among equals the smaller workgroup = more CUs busy)
+      best = nw;
+      best_cost = cost;
+      *pl = cand;
+    }
   }
-  return SBI_AMD_E_LDS;
+  if (best == 0) return SBI_AMD_E_LDS;
+  *nw_out = best;
+  return 0;
 }
 
 extern "C" int64_t sbi_amd_nsf_param_count(const sbi_amd_nsf_config* cfg) {

@@ -66,6 +66,21 @@ def test_wide_nets_take_the_cooperative_path_at_every_batch_size():
     assert lib.sbi_amd_nsf_image_kind(_cfg(D=16, C=8, num_bins=16, hidden_features=80), 200, 0) == 1
 
 
+def test_default_thresholds_inference_12288_training_8192():
+    """Measured cross-overs: log_prob / sampling stay on the cooperative kernels up to 12 288 rows, the
+    training pass up to 8 192 (one round of two-tile backward workgroups).  (Fresh process: the setter moves both.)"""
+    import subprocess
+    import sys
+
+    code = ("from sbi_amd import _lib; from sbi_amd.neural_nets.estimators.nsf_flow import NSFHyper; "
+            "lib = _lib.load(); c = NSFHyper(D=10, C=10).c_config(); "
+            "print([lib.sbi_amd_nsf_image_kind(c, n, t) for t in (0, 1) for n in (8192, 8193, 12288, 12289)])")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(_lib.__file__).rsplit("/", 2)[0],
+                         env={k: v for k, v in __import__("os").environ.items() if k != "SBI_AMD_COOP_MAX_ROWS"})
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "[1, 1, 1, 0, 1, 0, 0, 0]"
+
+
 def test_workspace_grows_with_rows_and_switches_workgroup_shape():
     lib, c = _lib.load(), _cfg()
     w16, w17, w4096, w4097, w8192 = [lib.sbi_amd_nsf_train_workspace_floats(c, n) for n in (16, 17, 4096, 4097, 8192)]
