@@ -89,6 +89,9 @@ int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* 
  * only sbi_amd_nsf_sample reads -- hidden_features <= 64: bit 8, above: bit 4) -- a training loop at a fixed batch size
  * needs ONE of bits 1 / 2 per step and never the inverses.  sbi_amd_nsf_pack packs everything. */
 int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, int32_t training);
+/* Host-side answer (tests, tuning): waves of 16 rows per workgroup the throughput forward kernel (sampling != 0: the
+ * sampling-direction kernel) launches for an n-row call -- chosen to minimise the rounds over the CUs -- or SBI_AMD_E_*. */
+int sbi_amd_nsf_plan_waves(const sbi_amd_nsf_config* cfg, int64_t n, int32_t sampling);
 /* Tuning / test hook: calls of at most `rows` rows take the cooperative kernels (0: never; default 12 288, and 8 192
  * for training passes; the environment variable SBI_AMD_COOP_MAX_ROWS, like this call, sets both); returns the
  * previous value.  Process-wide; images packed before a
@@ -193,7 +196,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 110
+#define SBI_AMD_NSF_ABI_VERSION 111
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 110    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 111    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -159,6 +159,7 @@ _SIGNATURES = {
         [POINTER(MAFConfigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "sbi_amd_nsf_plan_waves": (c_int, [POINTER(NSFConfigC), c_int64, c_int32]),
     "sbi_amd_nsf_abi_version": (c_int, []),
     "sbi_amd_nsf_arch": (c_char_p, []),
 }

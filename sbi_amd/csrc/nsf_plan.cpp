@@ -57,6 +57,14 @@ int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int
   return 0;
 }
 
+// host-side answer (tests, tuning): waves per workgroup the throughput forward / sampling kernel uses for an n-row call
+extern "C" int sbi_amd_nsf_plan_waves(const sbi_amd_nsf_config* cfg, int64_t n, int32_t sampling) {
+  NsfPlan pl;
+  int nw = 0;
+  const int rc = nsf_plan_for_rows(cfg, n < 1 ? 1 : n, &pl, &nw, sampling != 0);
+  return rc ? rc : nw;
+}
+
 extern "C" int64_t sbi_amd_nsf_param_count(const sbi_amd_nsf_config* cfg) {
   NsfPlan pl;
   int rc = nsf_build_plan(cfg, 1, &pl);

@@ -75,6 +75,22 @@ def test_unsupported_configs_are_refused_not_degraded():
         _lib.check(_lib.E_UNSUPPORTED, "x")
 
 
+def test_throughput_workgroup_size_minimises_rounds_over_the_cus():
+    """csrc/nsf_plan.cpp::nsf_plan_for_rows: 16 rows per wave, 1 / 2 / 4 / 8 waves per workgroup, one workgroup per CU at a
+    time => ceil(workgroups / 256) rounds of about equal length; the size is chosen to minimise the rounds (x 1.2 for eight
+    waves), smaller workgroups among equals.  12 288 rows used to run as 384 two-wave workgroups (two rounds)."""
+    lib = _lib.load()
+    c = NSFHyper(D=10, C=10).c_config()
+    got = {n: lib.sbi_amd_nsf_plan_waves(c, n, 0) for n in (1, 200, 4096, 4097, 8192, 8193, 12288, 16384, 16385, 24576,
+                                                            32768, 40000, 65536, 10**6)}
+    assert got == {1: 1, 200: 1, 4096: 1, 4097: 2, 8192: 2, 8193: 4, 12288: 4, 16384: 4, 16385: 8, 24576: 8, 32768: 8,
+                   40000: 8, 65536: 8, 10**6: 8}, got
+    # the sampling direction takes twelve-wave workgroups once they fill the chip
+    assert lib.sbi_amd_nsf_plan_waves(c, 10**6, 1) == 12 and lib.sbi_amd_nsf_plan_waves(c, 12288, 1) == 4
+    # a net wider than 64 has no throughput kernel at all
+    assert lib.sbi_amd_nsf_plan_waves(NSFHyper(D=10, C=10, hidden_features=100).c_config(), 4096, 0) == _lib.E_LDS
+
+
 def test_training_envelope_and_refusals_are_host_side_decisions():
     """`sbi_amd_nsf_train_workspace_floats` answers on the host (no device call) whether a shape trains: the
     wave-specialised backward kernel's shapes, the generic training pass beyond them (theta-dim > 15, 3-4 blocks,
