@@ -434,11 +434,9 @@ class PosteriorEstimatorTrainer:
             sampler = ShuffledGather(theta_d, x_d, train_idx, sg_seed)
 
         def my_range(lo: int, count: int):     # this rank's contiguous share of rows lo .. lo + count of an order
-            if world == 1:
-                return lo, count
-            per = (count + world - 1) // world
-            a = min(rank * per, count)
-            return lo + a, min((rank + 1) * per, count) - a
+            from sbi_amd.utils.shuffle import rank_window
+
+            return rank_window(lo, count, rank, world)
 
         def launch_epoch(e: int) -> dict:
             """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here

@@ -153,9 +153,9 @@ class FMPE(PosteriorEstimatorTrainer):
             sums = torch.zeros(2, device=self._device)
             for b in range(n_train_batches):
                 if sampler is not None:
-                    per = (B + world - 1) // world
-                    lo = min(rank * per, B)
-                    th, xx = sampler.batch(self.epoch, b * B + lo, min((rank + 1) * per, B) - lo)
+                    from sbi_amd.utils.shuffle import rank_window
+
+                    th, xx = sampler.batch(self.epoch, *rank_window(b * B, B, rank, world))
                 else:
                     idx = my_slice(epoch_idx[b * B : (b + 1) * B])
                     th, xx = theta_d.index_select(0, idx), x_d.index_select(0, idx)

@@ -26,6 +26,16 @@ def epoch_key(seed: int, epoch: int) -> int:
     return z ^ (z >> 31)
 
 
+def rank_window(lo: int, count: int, rank: int, world: int) -> Tuple[int, int]:
+    """(offset, rows) of rank `rank`'s contiguous share of rows lo .. lo + count of an order: ceil(count / world) rows per
+    rank, the last ranks possibly fewer or none -- the same split the index path makes (`my_slice` in the trainers)."""
+    if world == 1:
+        return lo, count
+    per = (count + world - 1) // world
+    a = min(rank * per, count)
+    return lo + a, min((rank + 1) * per, count) - a
+
+
 class ShuffledGather:
     """``batch(epoch, offset, count) -> (theta rows, x rows)`` of the epoch's order over ``base_idx`` (the training
     split's row numbers inside ``theta_all`` / ``x_all``); ``indices`` returns the source rows instead."""

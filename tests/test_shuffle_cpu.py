@@ -5,7 +5,7 @@ kernel itself is held to this restatement index for index by tests/test_shuffle_
 import numpy as np
 import pytest
 
-from sbi_amd.utils.shuffle import epoch_key
+from sbi_amd.utils.shuffle import epoch_key, rank_window
 from tests.shuffle_restatement import half_bits, prp
 
 
@@ -42,3 +42,21 @@ def test_epoch_keys_differ_and_orders_look_random():
         head = [prp(i, 300, k) for i in range(30)]
         hits[head] += 1
     assert abs(hits.mean() - 40.0) < 1e-9 and hits.std() < 3.0 * np.sqrt(40 * 0.9)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("count", [1, 7, 200, 65536])
+def test_rank_windows_tile_a_batch_like_the_index_split(world, count):
+    """Data-parallel runs: rank r takes a contiguous window of every global batch -- the windows tile the batch exactly, in
+    rank order, and equal the slice the index path (`my_slice`: ceil(count / world) rows per rank) takes."""
+    lo = 1000
+    idx = list(range(lo, lo + count))
+    per = (count + world - 1) // world
+    covered = []
+    for r in range(world):
+        off, rows = rank_window(lo, count, r, world)
+        assert rows >= 0 and (rows == 0 or lo <= off < lo + count)
+        want = idx[r * per : min((r + 1) * per, count)]
+        assert list(range(off, off + rows)) == want
+        covered += want
+    assert covered == idx
