@@ -3,6 +3,7 @@
 import torch
 
 from oracle.nsf_oracle import NSFOracle
+from sbi_amd.neural_nets.estimators.nsf_flow import loss_fwd_bwd, train_workspace
 from sbi_amd.neural_nets.net_builders.flow import build_nsf
 
 
@@ -84,3 +85,35 @@ def spline_knot_distances(oracle, theta, x, include_bounds=True):
         mod.unconstrained_rational_quadratic_spline = real
         oracle.float()
     return torch.cat([c.reshape(theta.shape[0], -1) for c in captured], dim=1)
+
+
+# ---- one training pass: autograd through the oracle / the HIP kernels through the C ABI (shared by the GPU test modules)
+def oracle_training_grad(oracle, est, theta, x, w=None, double=True):
+    dt = torch.float64 if double else torch.float32
+    oracle.double() if double else oracle.float()
+    oracle.zero_grad()
+    th = theta.to(dt).requires_grad_(True)
+    xx = x.to(dt).requires_grad_(True)
+    xe = xx if xx.shape[0] == th.shape[0] else xx.expand(th.shape[0], -1)
+    l = oracle.loss(th, xe)
+    ww = torch.full((th.shape[0],), 1.0 / th.shape[0], dtype=dt) if w is None else w.to(dt)
+    (l * ww).sum().backward()
+    named = dict(oracle.named_parameters())
+    flat = torch.zeros(est.net.flat_params.numel(), dtype=dt)
+    for key, off, n_, _ in est.net._slices():
+        flat[off : off + n_] = named["net." + key].grad.reshape(-1)
+    oracle.float()
+    return l.detach(), flat, th.grad, xx.grad
+
+
+def hip_training_pass(est, theta, x, w=None, want_gx=False):
+    n = theta.shape[0]
+    grad = torch.empty_like(est.net.flat_params.data)
+    ws = train_workspace(est.net, n, "cuda")
+    ws.fill_(float("nan"))
+    gx = torch.full((n, x.shape[1]), float("nan"), device="cuda") if want_gx else None
+    losses, gth = loss_fwd_bwd(est.net, theta.cuda().contiguous(), x.cuda().contiguous(),
+                               None if w is None else w.cuda().contiguous(), 1.0 / n, grad, want_grad_theta=True,
+                               workspace=ws, grad_x_out=gx)
+    torch.cuda.synchronize()
+    return losses.cpu(), grad.cpu(), gth.cpu(), (gx.cpu() if want_gx else None)

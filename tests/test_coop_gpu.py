@@ -12,8 +12,8 @@ import pytest
 import torch
 
 from sbi_amd import _lib
-from sbi_amd.neural_nets.estimators.nsf_flow import loss_fwd_bwd, packed_weights, train_workspace
-from tests.helpers import make_inputs, matched_pair
+from sbi_amd.neural_nets.estimators.nsf_flow import packed_weights
+from tests.helpers import hip_training_pass as _hip_pass, make_inputs, matched_pair, oracle_training_grad as _oracle_grad
 from tests.parity_log import record
 
 pytestmark = pytest.mark.gpu
@@ -48,37 +48,6 @@ class family:
 
     def __exit__(self, *a):
         _lib.load().sbi_amd_nsf_set_coop_max_rows(self.prev)
-
-
-def _oracle_grad(oracle, est, theta, x, w=None, double=True):
-    dt = torch.float64 if double else torch.float32
-    oracle.double() if double else oracle.float()
-    oracle.zero_grad()
-    th = theta.to(dt).requires_grad_(True)
-    xx = x.to(dt).requires_grad_(True)
-    xe = xx if xx.shape[0] == th.shape[0] else xx.expand(th.shape[0], -1)
-    l = oracle.loss(th, xe)
-    ww = torch.full((th.shape[0],), 1.0 / th.shape[0], dtype=dt) if w is None else w.to(dt)
-    (l * ww).sum().backward()
-    named = dict(oracle.named_parameters())
-    flat = torch.zeros(est.net.flat_params.numel(), dtype=dt)
-    for key, off, n_, _ in est.net._slices():
-        flat[off : off + n_] = named["net." + key].grad.reshape(-1)
-    oracle.float()
-    return l.detach(), flat, th.grad, xx.grad
-
-
-def _hip_pass(est, theta, x, w=None, want_gx=False):
-    n = theta.shape[0]
-    grad = torch.empty_like(est.net.flat_params.data)
-    ws = train_workspace(est.net, n, "cuda")
-    ws.fill_(float("nan"))
-    gx = torch.full((n, x.shape[1]), float("nan"), device="cuda") if want_gx else None
-    losses, gth = loss_fwd_bwd(est.net, theta.cuda().contiguous(), x.cuda().contiguous(),
-                               None if w is None else w.cuda().contiguous(), 1.0 / n, grad, want_grad_theta=True,
-                               workspace=ws, grad_x_out=gx)
-    torch.cuda.synchronize()
-    return losses.cpu(), grad.cpu(), gth.cpu(), (gx.cpu() if want_gx else None)
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=_ids)

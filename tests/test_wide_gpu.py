@@ -7,9 +7,9 @@ import pytest
 import torch
 
 from sbi_amd import _lib
-from tests.helpers import make_inputs, matched_pair, spline_knot_distances
+from tests.helpers import hip_training_pass as _hip_pass, make_inputs, matched_pair, oracle_training_grad as _oracle_grad, \
+    spline_knot_distances
 from tests.parity_log import record
-from tests.test_coop_gpu import _hip_pass, _oracle_grad
 
 pytestmark = pytest.mark.gpu
 
