@@ -241,7 +241,7 @@ def timed(step, steps, warmup, device, dist=None):
     LAST_TIMED.update(host_enqueue_ms_max=max(host) * 1e3, host_enqueue_ms_argmax=host.index(max(host)),
                       host_enqueue_ms_median=sorted(host)[len(host) // 2] * 1e3)
     dev_ms = ev0.elapsed_time(ev1)     # HIP events on the stream the kernels are launched on
-    t = torch.tensor([wall], device=device, dtype=torch.float64)
+    t = torch.tensor([wall], dtype=torch.float64, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item()), dev_ms
@@ -366,7 +366,9 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
     torch.manual_seed(1)
     fm = build_flow_matching_estimator(th_f[:4096].cpu(), x_f[:4096].cpu()).to(device)
     if distributed:
-        dist.broadcast(fm.net.flat_params.data, src=0)
+        from sbi_amd.utils.collectives import broadcast_from_rank0
+
+        broadcast_from_rank0(dist, fm.net.flat_params.data)
     stepper = FusedFMPEStep(fm, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
     wall, dev_ms = timed(lambda: stepper.step(th_f, x_f, global_batch=global_batch), args.steps, args.warmup, device,
                          dist)
@@ -483,7 +485,8 @@ def main(argv=None):
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: become one (one process per GPU, RCCL)
-        raise SystemExit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else argv))
+        raise SystemExit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else argv,
+                                      require_gpus=os.environ.get("SBI_AMD_BENCH_SHARE_GPU") != "1"))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -494,6 +497,13 @@ def main(argv=None):
     distributed = world > 1 or (os.environ.get("SBI_AMD_FORCE_DIST") == "1" and "RANK" in os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU path)")
+    # SBI_AMD_BENCH_SHARE_GPU=1 (tests, 1-GPU boxes): every rank sits on device 0 and the group is `gloo` (RCCL refuses
+    # two ranks on one device; device buffers are staged through the host by sbi_amd/utils/collectives.py).  The DP
+    # code path -- windows of one global batch, 1/global_batch weighting, all-reduce, max-over-ranks timing -- is the
+    # product's; the NUMBER is not a scaling measurement and the line says so (`config.shared_gpu`).
+    share_gpu = os.environ.get("SBI_AMD_BENCH_SHARE_GPU") == "1" and world > 1
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -505,21 +515,26 @@ def main(argv=None):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        from sbi_amd.utils.collectives import all_reduce_sum, broadcast_from_rank0
+
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         probe = torch.ones(1, device=device)
-        dist.all_reduce(probe)
+        all_reduce_sum(dist, probe)
         rccl_world = int(probe.item())          # the number of ranks RCCL actually reduced over
         if rccl_world != world:
             raise SystemExit(f"bench.py: RCCL all-reduce saw {rccl_world} ranks, expected {world}")
         # the collective of one training step in isolation: all-reduce of a flat 98 025-float gradient buffer
         gbuf = torch.zeros(98_025, device=device)
         for _ in range(10):
-            dist.all_reduce(gbuf)
+            all_reduce_sum(dist, gbuf)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(50):
-            dist.all_reduce(gbuf)
+            all_reduce_sum(dist, gbuf)
         e1.record()
         torch.cuda.synchronize()
         allreduce_us = e0.elapsed_time(e1) / 50 * 1e3
@@ -534,7 +549,7 @@ def main(argv=None):
     theta, x = make_data(B, device, seed=rank)     # this rank's evaluation batch
     est = build_estimator(*make_data(BATCH, "cpu", seed=0), device)
     if distributed:
-        dist.broadcast(est.net.flat_params.data, src=0)
+        broadcast_from_rank0(dist, est.net.flat_params.data)
 
     results = {}
     if args.mode in ("both", "log_prob"):
@@ -721,7 +736,9 @@ def main(argv=None):
             Bs = args.batch // world
             leg_s = TrainLeg(est, th_all, x_all, Bs, distributed, args.batch)
             wall_s, dev_ms_s = timed(leg_s, args.steps, args.warmup, device, dist)
-            strong_obj = {"scaling": "strong", "global_batch": args.batch, "rows_per_gpu": Bs,
+            strong_obj = {"scaling": "strong", "baseline_config": "BASELINE configs[2]: the 65 536-pair batch of "
+                          "configs[1] (100 000 simulations cannot feed more than one such batch) split over the GPUs",
+                          "global_batch": args.batch, "rows_per_gpu": Bs,
                           "value": args.batch * args.steps / wall_s, "unit": "pairs/s",
                           "ms_per_step": wall_s / args.steps * 1e3,
                           "roofline": roofline(F_TRAIN, Bs, args.steps, leg_s.fused_ms(args.steps))}
@@ -782,7 +799,14 @@ def main(argv=None):
                        if head == "train" else
                        f"NSF log_prob, theta-dim {D}, x-dim {C}, batch {args.batch} {per}",
                        "parallelism": f"dp{world}", "rccl_ranks": rccl_world if distributed else 1,
-                       "rccl_allreduce_us_98025_floats": allreduce_us},
+                       "rccl_allreduce_us_98025_floats": allreduce_us,
+                       "baseline_config": ("configs[1]" if world == 1 else
+                                           "configs[2] (strong: one 65 536-pair batch split over the GPUs)"
+                                           if args.scaling == "strong" else
+                                           "configs[1] replicated per GPU (weak); configs[2] itself is the nested "
+                                           "`strong_scaling` object"),
+                       **({"shared_gpu": "all ranks on device 0 over gloo (SBI_AMD_BENCH_SHARE_GPU=1): a code-path "
+                                         "run, not a scaling measurement"} if share_gpu else {})},
             # whole step (forward + T backward launches + reduce + clip/Adam) against dense fp32 MFMA;
             # per-kernel durations: profiles/*kernel_stats.csv
             "roofline": r["roofline"],

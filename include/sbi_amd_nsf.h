@@ -80,13 +80,15 @@ int64_t sbi_amd_nsf_packed_floats(const sbi_amd_nsf_config* cfg);
 int sbi_amd_nsf_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, void* stream);
 
 /* `packed` holds two images: the throughput kernels' (one LDS image per transform) and, for the shapes they take
- * (theta-dim 2..16, x-dim <= 32), the fragment-ordered image of the latency-oriented kernels that calls of at most
+ * (theta-dim 2..16, x-dim <= 32; x-dim <= 64 with hidden_features 65..128), the fragment-ordered image of the latency-oriented kernels that calls of at most
  * 12 288 rows (training passes: 8 192) are routed to (four cooperating wavefronts per 16-row tile, all transforms of the backward pass in one
  * launch: csrc/nsf_coop.h; sbi's default training_batch_size = 200, npe_base.py:301-316, lives here).
  * sbi_amd_nsf_image_kind says which image an n-row call reads (0 throughput, 1 cooperative; `training` != 0 for
  * train_forward / train_backward / loss_fwd_bwd); sbi_amd_nsf_pack_images re-packs only the images named in the
  * bit mask (1 throughput, 2 cooperative; 8 / 4: the explicit U^-1 / L^-1 of the throughput / cooperative image, which
- * only sbi_amd_nsf_sample reads -- hidden_features <= 64: bit 8, above: bit 4) -- a training loop at a fixed batch size
+ * only sbi_amd_nsf_sample reads: an n-row sampling call needs bit 4 (with bit 2) whenever
+ * sbi_amd_nsf_image_kind(cfg, n, 0) == 1 -- small calls of narrow nets and EVERY call at hidden_features > 64 -- and
+ * bit 8 (with bit 1) otherwise) -- a training loop at a fixed batch size
  * needs ONE of bits 1 / 2 per step and never the inverses.  sbi_amd_nsf_pack packs everything. */
 int sbi_amd_nsf_image_kind(const sbi_amd_nsf_config* cfg, int64_t n, int32_t training);
 /* Host-side answer (tests, tuning): waves of 16 rows per workgroup the throughput forward kernel (sampling != 0: the

@@ -21,11 +21,15 @@ HASH_PATH = LIB_PATH.with_suffix(".so.srchash")   # travels with the .so (git-ig
 LOCK_PATH = LIB_PATH.with_suffix(".so.lock")
 
 
+class HipccMissing(RuntimeError):
+    """No hipcc on this machine: a prebuilt library can still be loaded, nothing can be rebuilt."""
+
+
 def hipcc_path() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
             return cand
-    raise RuntimeError("hipcc not found: the sbi_amd HIP extension cannot be built")
+    raise HipccMissing("hipcc not found: the sbi_amd HIP extension cannot be built")
 
 
 def source_hash() -> str:

@@ -180,15 +180,21 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if build_if_missing:
         try:
             _build.build()      # no-op when the library matches the sources on disk (content hash, file-locked)
-        except RuntimeError as e:
-            # a machine with a prebuilt library but no hipcc (or no `.srchash` next to it) must stay usable: fall back
-            # on the ABI-version check below instead of refusing to load
-            if not path.exists() or "hipcc not found" not in str(e):
+        except _build.HipccMissing as e:
+            # a machine with a prebuilt library but no hipcc must stay usable -- but only with a library that was built
+            # from THESE sources: kernel / packed-image layouts change without an ABI-version bump, so the stored
+            # content hash is compared whenever it exists, and a library without one is loaded with a loud warning
+            if not path.exists():
                 raise
             import warnings
 
-            warnings.warn(f"sbi_amd: {path.name} could not be checked against the sources ({e}); loading it as is "
-                          "(the ABI version is still verified)", stacklevel=2)
+            if _build.HASH_PATH.exists():
+                if _build.HASH_PATH.read_text().strip() != _build.source_hash():
+                    raise RuntimeError(f"{path} was built from different sources than the ones on disk and cannot be "
+                                       f"rebuilt here ({e}); refusing to load a stale kernel library") from e
+            else:
+                warnings.warn(f"sbi_amd: {path.name} has no source hash next to it and cannot be checked against the "
+                              f"sources ({e}); loading it as is (only the ABI version is verified)", stacklevel=2)
     elif _build.needs_build():
         raise RuntimeError(f"{path} is stale (built from different sources); rebuild it with "
                            "`python -c 'import __graft_entry__ as g; g.build()'`")

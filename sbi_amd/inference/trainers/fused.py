@@ -21,6 +21,7 @@ from torch import Tensor
 
 from sbi_amd import _lib
 from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow, train_backward, train_forward
+from sbi_amd.utils.collectives import all_reduce_sum
 
 
 class FusedTrainStep:
@@ -68,6 +69,14 @@ class FusedTrainStep:
         self.exp_avg_sq.copy_(snap["exp_avg_sq"])
         self.step_count = int(snap["step"])
 
+    def restore(self, snap: dict) -> None:
+        """Weights AND optimizer state of a snapshot.  The write goes behind autograd's back (`.data`), so the tensor
+        version the packed-weight cache is keyed on does not move: drop the cache, or log_prob / sample after a
+        recovered NaN epoch would keep running on the poisoned image."""
+        self.net.flat_params.data.copy_(snap["params"])
+        self.restore_optimizer(snap)
+        self.net.__dict__.pop("_packed_cache", None)
+
     def _workspace(self, n: int) -> Tensor:
         need = self.net.train_workspace_floats(n)
         if self.workspace is None or self.workspace.numel() < need:
@@ -96,7 +105,7 @@ class FusedTrainStep:
         x = self._embedded(x)
         losses, _ = self.net.train_pass(theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
         if self.distributed:
-            self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(self.dist, self.grad, self.group)
         return losses
 
     @torch.no_grad()
@@ -133,7 +142,7 @@ class FusedTrainStep:
             w[0] += m
         train_backward(self.net, x, A * B, (w / gb).reshape(-1).contiguous(), self.grad, ws)
         if self.distributed:
-            self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(self.dist, self.grad, self.group)
         return -lpp
 
     def atomic_step(self, theta: Tensor, x: Tensor, masks: Tensor, prior, num_atoms: int,
@@ -201,7 +210,7 @@ class FusedFMPEStep(FusedTrainStep):
         losses = fm_loss_fwd_bwd(self.net, theta, x, times, noise, row_weight, 1.0 / gb, self.grad,
                                  workspace=self._workspace(n))
         if self.distributed:
-            self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(self.dist, self.grad, self.group)
         return losses
 
     def atomic_loss_and_grad(self, *a, **k):

@@ -33,6 +33,7 @@ from sbi_amd.neural_nets.estimators.base import ConditionalDensityEstimator
 from sbi_amd.neural_nets.estimators.nsf_flow import NSFFlow
 from sbi_amd.neural_nets.factory import posterior_nn
 from sbi_amd.neural_nets.net_builders.estimator_configs import NSFConfig, ZukoNSFConfig
+from sbi_amd.utils.collectives import all_reduce_sum
 from sbi_amd.utils.sbiutils import handle_invalid_x, warn_on_invalid_x
 from sbi_amd.utils.torchutils import check_if_prior_on_device, process_device
 
@@ -409,7 +410,7 @@ class PosteriorEstimatorTrainer:
                 (losses.sum() / global_batch).backward()
                 if d is not None:
                     for p in params:
-                        d.all_reduce(p.grad, op=d.ReduceOp.SUM)
+                        all_reduce_sum(d, p.grad)
                 if cfg.clip_max_norm is not None:
                     torch.nn.utils.clip_grad_norm_(params, max_norm=cfg.clip_max_norm)
                 self.optimizer.step()
@@ -427,7 +428,9 @@ class PosteriorEstimatorTrainer:
         # it takes the batch's source rows from the same sampler (`indices`) and gathers with them; the autograd path
         # keeps the argsort permutations.
         sampler = None
-        if fused:
+        # (structured x in front of a frozen / parameter-free embedding net -- (N, c, h, w) images through nn.Flatten or
+        # a frozen CNN -- keeps the index path: the gather kernel moves flat fp32 rows)
+        if fused and x_d.dim() == 2 and theta_d.dim() == 2 and x_d.dtype == theta_d.dtype == torch.float32:
             from sbi_amd.utils.shuffle import ShuffledGather
 
             sg_seed = int(self._bcast(torch.randint(0, 2**62, (1,), dtype=torch.int64)).item())
@@ -469,7 +472,7 @@ class PosteriorEstimatorTrainer:
                 idx = my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv])
                 sums[1] += batch_losses(idx, False, Bv).sum()
             if d is not None:
-                d.all_reduce(sums, op=d.ReduceOp.SUM)
+                all_reduce_sum(d, sums)
             if pipelined:
                 rec["host"] = torch.empty(2, dtype=sums.dtype, pin_memory=True)
                 rec["host"].copy_(sums, non_blocking=True)
@@ -489,8 +492,7 @@ class PosteriorEstimatorTrainer:
                     # stepped on this epoch's (and possibly the speculative epoch's) non-finite gradients: put the
                     # weights and optimizer state of the last finite epoch back before giving up
                     torch.cuda.synchronize(self._device)
-                    self._stepper.net.flat_params.data.copy_(last_good["snap"]["params"])
-                    self._stepper.restore_optimizer(last_good["snap"])
+                    self._stepper.restore(last_good["snap"])
                 raise AssertionError("NaN/Inf present in NPE loss.")
             if "snap" in rec:
                 last_good["snap"] = rec["snap"]

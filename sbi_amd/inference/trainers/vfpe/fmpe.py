@@ -22,6 +22,7 @@ from torch import Tensor
 
 from sbi_amd.inference.trainers.npe.npe import PosteriorEstimatorTrainer, TrainConfig
 from sbi_amd.neural_nets.estimators.flowmatching_estimator import FlowMatchingEstimator
+from sbi_amd.utils.collectives import all_reduce_sum
 
 
 def posterior_flow_nn(model: str = "mlp", z_score_theta: Optional[str] = "independent",
@@ -169,7 +170,7 @@ class FMPE(PosteriorEstimatorTrainer):
                     ((losses * rw).sum() / B if rw is not None else losses.sum() / B).backward()
                     if d is not None:
                         for p_ in params:
-                            d.all_reduce(p_.grad, op=d.ReduceOp.SUM)
+                            all_reduce_sum(d, p_.grad)
                     if cfg.clip_max_norm is not None:
                         torch.nn.utils.clip_grad_norm_(params, max_norm=cfg.clip_max_norm)
                     self.optimizer.step()
@@ -188,7 +189,7 @@ class FMPE(PosteriorEstimatorTrainer):
                         losses = losses * calibration_kernel(xx)
                     sums[1] += losses.sum()
             if d is not None:
-                d.all_reduce(sums, op=d.ReduceOp.SUM)
+                all_reduce_sum(d, sums)
             host = sums.cpu()
             if not torch.isfinite(host).all():
                 raise AssertionError("NaN/Inf present in FMPE loss.")

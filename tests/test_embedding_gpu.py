@@ -153,6 +153,28 @@ def test_fused_step_applies_a_frozen_embedding_net():
     assert abs(tr - va) < 1.0, f"training ({tr}) and validation ({va}) losses disagree: x was not embedded"
 
 
+def test_fused_path_with_structured_x_and_a_parameter_free_embedding():
+    """x of shape (N, c, h, w) in front of `nn.Flatten` trains on the fused path; the device
+    sampler only gathers flat rows, so this shape keeps the index path of the epoch loop (it used to raise
+    'ShuffledGather expects theta (N, D) and x (N, C)')."""
+    torch.manual_seed(0)
+    n, D = 600, 3
+    theta = torch.randn(n, D)
+    x = (theta.repeat(1, 4) + 0.3 * torch.randn(n, 12)).reshape(n, 1, 3, 4)
+    prior = MultivariateNormal(torch.zeros(D, device="cuda"), torch.eye(D, device="cuda"))
+    inf = NPE(prior=prior, density_estimator=NSFConfig(embedding_net=nn.Flatten()), device="cuda",
+              show_progress_bars=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est = inf.append_simulations(theta, x).train(training_batch_size=100, max_num_epochs=4)
+    assert inf._stepper is not None, "a parameter-free embedding should train on the fused path"
+    assert est.condition_shape == torch.Size([1, 3, 4])
+    tr, va = inf.summary["training_loss"], inf.summary["validation_loss"]
+    assert len(tr) == 5 and tr[-1] < tr[0] and abs(tr[-1] - va[-1]) < 1.0
+    lp = est.log_prob(theta[:7].cuda().unsqueeze(0), x[:7].cuda())
+    assert lp.shape == (1, 7) and torch.isfinite(lp).all()
+
+
 def test_mcmc_fused_potential_embeds_the_observation():
     """MCMCPosterior's fused potential must evaluate the flow on the EMBEDDED x_o."""
     from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
