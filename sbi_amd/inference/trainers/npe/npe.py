@@ -558,6 +558,8 @@ class PosteriorEstimatorTrainer:
             print(f"\n Neural network successfully converged after {self.epoch} epochs.")
         self._summary["epochs_trained"].append(self.epoch)
         self._summary["best_validation_loss"].append(self._best_val_loss)
+        if rank == 0:
+            self._summarize(self._round)
         if cfg.show_train_summary and rank == 0:
             print(self._describe_round())
         net.zero_grad(set_to_none=True)
@@ -591,6 +593,23 @@ class PosteriorEstimatorTrainer:
             self._load_state(net, self._best_model_state_dict)
             converged = True
         return converged
+
+    def _summarize(self, round_: int) -> None:
+        """Write the round's statistics to the experiment tracker the caller passed as `tracker=` (protocol
+        sbi/sbi_types.py:73-91; calls, tags and step numbering of trainers/base.py:1317-1385).  Without one nothing is
+        written: the reference's default -- a TensorBoard directory under sbi-logs/ -- belongs to its logging
+        subsystem, which is outside this path."""
+        t = self._tracker
+        if t is None:
+            return
+        sm = self._summary
+        t.log_metric(name="epochs_trained", value=sm["epochs_trained"][-1], step=round_ + 1)
+        t.log_metric(name="best_validation_loss", value=sm["best_validation_loss"][-1], step=round_ + 1)
+        offset = int(sum(sm["epochs_trained"][:-1]))
+        for tag in ("validation_loss", "training_loss", "epoch_durations_sec"):
+            for i, v in enumerate(sm[tag][offset:]):
+                t.log_metric(name=tag, value=v, step=int(offset + i))
+        t.flush()
 
     def _describe_round(self) -> str:
         s = self._summary

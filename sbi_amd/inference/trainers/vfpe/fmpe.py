@@ -218,6 +218,8 @@ class FMPE(PosteriorEstimatorTrainer):
             print(f"\n Neural network successfully converged after {self.epoch} epochs.")
         self._summary["epochs_trained"].append(self.epoch)
         self._summary["best_validation_loss"].append(self._best_val_loss)
+        if rank == 0:
+            self._summarize(0)      # FMPE is single-round (fmpe.py:128-145)
         return deepcopy(net)
 
     def _converged(self, epoch: int, stop_after_epochs: int) -> bool:

@@ -113,6 +113,42 @@ def test_sample_1m_draws_direct_posterior():
     assert s.shape == (1_000_000, 10) and bool(prior.support.check(s).all())
 
 
+@pytest.mark.parametrize("sample_with", ["direct", "rejection", "mcmc"])
+def test_device_posterior_survives_pickling_with_identical_seeded_samples(sample_with):
+    """tests/save_and_load_test.py:23-45 on a cuda posterior: `manual_seed(0); sample((3,))` before and after a pickle
+    round trip give the same three draws (MCMC redraws a fresh chain by design, #1291: shape only), and pickling does
+    not replace attributes of the posterior it serialised."""
+    import pickle
+    import warnings
+
+    from sbi_amd.inference import NPE
+    from tests.helpers import linear_gaussian_data
+
+    D = 3
+    theta, x = linear_gaussian_data(600, D, D)
+    prior = BoxUniform(-3.0 * torch.ones(D), 3.0 * torch.ones(D), device="cuda")
+    torch.manual_seed(1)
+    inf = NPE(prior=prior, density_estimator="nsf", device="cuda", show_progress_bars=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inf.append_simulations(theta, x).train(training_batch_size=100, max_num_epochs=3)
+        kw = dict(mcmc_parameters=dict(num_chains=4, warmup_steps=5, thin=1)) if sample_with == "mcmc" else {}
+        post = inf.build_posterior(sample_with=sample_with, **kw).set_default_x(torch.zeros(1, D))
+    torch.manual_seed(0)
+    expected = post.sample((3,), show_progress_bars=False)
+    attributes = {name: id(value) for name, value in vars(post).items()}
+    reloaded = pickle.loads(pickle.dumps(post))
+    assert {name: id(value) for name, value in vars(post).items()} == attributes, \
+        "pickling replaced attributes on the posterior it serialized"
+    torch.manual_seed(0)
+    samples = reloaded.sample((3,), show_progress_bars=False)
+    assert samples.shape == (3, D) and samples.is_cuda
+    if sample_with != "mcmc":
+        assert torch.equal(samples, expected), (samples, expected)
+    if sample_with == "direct":
+        assert torch.equal(post.log_prob(expected), reloaded.log_prob(expected))
+
+
 def test_reference_ci_scenario_nsf_npe_c_dim4_wall_time():
     """tests/linearGaussian_snpe_test.py:156-200 with density_estimator="nsf", NPE_C: theta-dim 4, 2 500
     simulations, batch 100, train to convergence, 1 000 posterior samples, C2ST near chance.  The reference's CI

@@ -10,7 +10,7 @@ check both fp32 implementations against an fp64 evaluation of the oracle.
 import pytest
 import torch
 
-from tests.helpers import matched_pair, make_inputs
+from tests.helpers import matched_pair, make_inputs, row_parity
 from tests.parity_log import record
 
 pytestmark = pytest.mark.gpu
@@ -28,6 +28,8 @@ def kernel_family(request):
     _lib.load().sbi_amd_nsf_set_coop_max_rows(prev)
 
 ATOL, RTOL = 1e-5, 1e-5
+ROW_EXCEED_FRAC = 0.01      # rows allowed beyond |d_i| <= 1e-5 (1 + |ref_i|) ...
+ROW_HARD_CAP = 4.0          # ... and none beyond this multiple of its own bound
 
 CONFIGS = [
     dict(D=10, C=10),                                   # BASELINE cfg2 shape
@@ -36,6 +38,7 @@ CONFIGS = [
     dict(D=3, C=5, hidden_features=32, num_transforms=3, num_bins=8, num_blocks=1),
     dict(D=5, C=3, hidden_features=64, num_transforms=4, num_bins=5),
     dict(D=10, C=10, z_score_theta="none", z_score_x="none"),
+    dict(D=4, C=7, z_score_theta="structured", z_score_x="structured"),   # one scalar mean / std (sbiutils.py:376-415)
     dict(D=6, C=12, num_bins=16, num_transforms=2),
     dict(D=7, C=4, num_bins=4, hidden_features=20, tail_bound=5.0),
     dict(D=1, C=3),                                     # ContextSplineMap conditioner (flow.py:401-408)
@@ -79,6 +82,18 @@ def test_log_prob_matches_oracle(cfg):
     err = (got - ref).abs()
     print(f"in-distribution: max|hip-oracle32|={err.max().item():.3e} max|ref|={ref.abs().max().item():.1f}")
     assert err.max() <= ATOL + RTOL * ref.abs().max(), f"max err {err.max()}"
+    # row by row (a batch-max tolerance hides a bad ROW): |d_i| <= 1e-5 (1 + |ref_i|) against the
+    # fp32 oracle on all but ROW_EXCEED_FRAC of the rows, no row beyond ROW_HARD_CAP of its own bound, and the same
+    # against the oracle's fp64 evaluation; the eager fp32 oracle is held to the same yardstick for the record
+    rp, rp64, ro64 = row_parity(got, ref), row_parity(got, ref64), row_parity(ref, ref64)
+    print(f"per-row vs oracle32: worst {rp['worst_scaled']:.2f} x bound (|d|={rp['worst_abs']:.2e} at ref "
+          f"{rp['worst_ref']:.2f}), beyond bound {rp['exceed_frac']:.3%}, beyond abs 1e-5 {rp['abs_exceed_frac']:.2%}; "
+          f"vs f64: worst {rp64['worst_scaled']:.2f}, beyond {rp64['exceed_frac']:.3%}; oracle32 vs f64: worst "
+          f"{ro64['worst_scaled']:.2f}, beyond {ro64['exceed_frac']:.3%}, beyond abs 1e-5 {ro64['abs_exceed_frac']:.2%}")
+    record("log_prob_rows", _ids(cfg), **{f"hip_vs_o32.{k}": v for k, v in rp.items()},
+           **{f"hip_vs_f64.{k}": v for k, v in rp64.items()}, **{f"o32_vs_f64.{k}": v for k, v in ro64.items()})
+    assert rp["exceed_frac"] <= ROW_EXCEED_FRAC and rp["worst_scaled"] <= ROW_HARD_CAP, rp
+    assert rp64["exceed_frac"] <= ROW_EXCEED_FRAC and rp64["worst_scaled"] <= ROW_HARD_CAP, rp64
     _assert_as_accurate_as_fp32_reference(got, ref, ref64, "in-distribution log_prob", ("log_prob", _ids(cfg)))
     # (b) stress rows: deep tails, |log p| up to several hundred
     theta, x = make_inputs(4096, cfg["D"], cfg["C"])

@@ -10,7 +10,7 @@ Every test records its measured distances in the parity artifact (tests/parity_l
 import pytest
 import torch
 
-from tests.helpers import matched_pair
+from tests.helpers import matched_pair, row_parity
 from tests.parity_log import record
 
 pytestmark = pytest.mark.gpu
@@ -67,6 +67,15 @@ def test_log_prob_65536_matches_oracle(mode):
     assert torch.isfinite(got).all()
     assert e_o <= 1e-5 + 1e-5 * ref.abs().max().item()
     assert e_hip <= 2.0 * e_ref + 1e-5
+    # row by row: |d_i| <= 1e-5 (1 + |ref_i|) on all but 1 % of the 65 536 rows, no row beyond 4 x its bound
+    rp, rp64, ro64 = row_parity(got, ref), row_parity(got, ref64), row_parity(ref, ref64)
+    record("log_prob_65536_rows", mode, **{f"hip_vs_o32.{k}": v for k, v in rp.items()},
+           **{f"hip_vs_f64.{k}": v for k, v in rp64.items()}, **{f"o32_vs_f64.{k}": v for k, v in ro64.items()})
+    print(f"{mode} per-row: hip vs o32 worst {rp['worst_scaled']:.2f} x bound, beyond {rp['exceed_frac']:.3%}; hip vs "
+          f"f64 worst {rp64['worst_scaled']:.2f}, beyond {rp64['exceed_frac']:.3%}; o32 vs f64 worst "
+          f"{ro64['worst_scaled']:.2f}, beyond {ro64['exceed_frac']:.3%}")
+    assert rp["exceed_frac"] <= 0.01 and rp["worst_scaled"] <= 4.0, rp
+    assert rp64["exceed_frac"] <= 0.01 and rp64["worst_scaled"] <= 4.0, rp64
 
 
 def test_sample_from_noise_65536_matches_oracle():
