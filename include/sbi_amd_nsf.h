@@ -172,6 +172,28 @@ int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, flo
                            int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
                            float max_norm, float* scratch, void* stream);
 
+/* Table-driven re-pack (csrc/step_tail.hip).  A training step ends with the weight image of the next step's kernels
+ * being rebuilt from the flat parameters -- what nflows redoes inside every forward call (LULinear._create_lower_upper
+ * and the .t() views, nflows transforms/lu.py) and sbi_amd_nsf_pack_images does in 11 - 13 us by re-deriving where
+ * every parameter goes.  That never changes between steps:
+ *   sbi_amd_nsf_build_step_map(cfg, images, params, packed, map, workspace, stream)   -- ONCE per network
+ *     images: 1 (throughput image), 2 (cooperative image) or 3 -- what sbi_amd_nsf_image_kind says the training
+ *     batches read; map: sbi_amd_nsf_step_map_ints(cfg) int32; workspace: sbi_amd_nsf_step_map_workspace_floats(cfg)
+ *     floats (scratch, free afterwards).  The table (image position -> parameter | softplus flag, constant, or a
+ *     transform's logabsdet) is MEASURED by running the pack kernels on probe vectors and verified bit for bit
+ *     against them on a random vector before it is returned (SBI_AMD_E_UNSUPPORTED otherwise: keep using
+ *     sbi_amd_nsf_pack_images).  `packed` is fully packed from `params` on return.  Synchronises the stream.
+ *   sbi_amd_nsf_table_pack(cfg, params, packed, map, stream)                          -- per optimizer step
+ *     rewrites the parameter-dependent positions of the table's image(s): bit-identical to
+ *     sbi_amd_nsf_pack_images(cfg, params, packed, images) on that buffer.  The other image and the explicit LU
+ *     inverses are NOT touched (stale after a parameter update: sbi_amd_nsf_pack_images before a call that reads them). */
+int64_t sbi_amd_nsf_step_map_ints(const sbi_amd_nsf_config* cfg);
+int64_t sbi_amd_nsf_step_map_workspace_floats(const sbi_amd_nsf_config* cfg);
+int sbi_amd_nsf_build_step_map(const sbi_amd_nsf_config* cfg, int32_t images, const float* params, float* packed,
+                               int32_t* map, float* workspace, void* stream);
+int sbi_amd_nsf_table_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, const int32_t* map,
+                           void* stream);
+
 /* One tick of the vectorised slice sampler for all chains (the loop body of SliceSamplerVectorized.run,
  * sbi/samplers/mcmc/slice_numpy.py:353-587): consumes the log-probabilities of `next_param` (what the batched
  * log_prob kernel just produced), advances every chain's BEGIN/LOWER/UPPER/SAMPLE_SLICE state, writes the next
@@ -198,7 +220,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 111
+#define SBI_AMD_NSF_ABI_VERSION 112
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

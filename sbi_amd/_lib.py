@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 111    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 112    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -99,6 +99,11 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
          c_void_p, c_void_p],
     ),
+    "sbi_amd_nsf_step_map_ints": (c_int64, [POINTER(NSFConfigC)]),
+    "sbi_amd_nsf_step_map_workspace_floats": (c_int64, [POINTER(NSFConfigC)]),
+    "sbi_amd_nsf_build_step_map": (
+        c_int, [POINTER(NSFConfigC), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sbi_amd_nsf_table_pack": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p]),
     "sbi_amd_shuffled_gather": (
         c_int,
         [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_int64, c_int64, c_void_p, c_void_p,

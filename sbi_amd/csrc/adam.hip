@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "../../include/sbi_amd_nsf.h"
+#include "adam_math.h"
 
 #define ADAM_NWG 128
 #define ADAM_THREADS 256
@@ -38,27 +39,18 @@ adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restric
             float max_norm, int npart, float* __restrict__ scratch) {
   __shared__ float s_coef;
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < npart; ++i) s += scratch[1 + i];
-    float norm = sqrtf(s);
-    float coef = 1.f;
-    if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);   // clip_grad_norm_
-    s_coef = coef;
+    float norm;
+    s_coef = adam_clip_coef(scratch + 1, npart, max_norm, &norm);
     if (blockIdx.x == 0) scratch[0] = norm;
   }
   __syncthreads();
-  const float coef = s_coef;
-  const float step_size = lr / bc1;
+  const AdamK k = {s_coef, beta1, beta2, eps, lr / bc1, bc2_sqrt};
   for (long long i = (long long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < count;
        i += (long long)gridDim.x * ADAM_THREADS) {
-    float gi = g[i] * coef;
-    float mi = m[i];
-    mi = mi + (1.f - beta1) * (gi - mi);            // exp_avg.lerp_(grad, 1 - beta1)
-    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    float mi = m[i], vi = v[i];
+    p[i] = adam_apply_one(p[i], g[i], mi, vi, k);     // (roundings pinned: adam_math.h)
     m[i] = mi;
     v[i] = vi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
   }
 }
 

@@ -248,6 +248,14 @@ __device__ __forceinline__ void gemm_breg(const float* __restrict__ lds, const L
 // floats -- same accuracy class as libm's expf / a correctly rounded divide, a
 // fraction of the instructions.
 __device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_rcp_f32 + one Newton step (two FMAs): within half an ulp of the correctly rounded quotient the eager reference
+// computes.  Used where a reciprocal feeds a CANCELLING expression -- the bin's slope h / w inside the inverse's
+// quadratic, the softmax normaliser that places every knot -- so that a saturated bin (slope 1e3) does not amplify the
+// hardware reciprocal's last ulp into several spacings of the spline input (tests/test_spline_adversarial_gpu.py).
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.f), r);
+}
 __device__ __forceinline__ float exp_f(float x) {
   const float L2E = 1.4426950408889634f, L2E_LO = 1.9259629911e-8f;   // log2(e) = hi + lo
   const float t = x * L2E;
@@ -515,7 +523,7 @@ __device__ __forceinline__ void spline_side(const float* __restrict__ q, const P
     s += S.e[k];
     y(K + k);
   }
-  S.inv_s = rcp_f(s);
+  S.inv_s = rcp_nr(s);
   const float n_ = (part ? pl.one_minus_kh : pl.one_minus_kw) * S.inv_s;
   const float mn = part ? pl.min_h : pl.min_w;
   // knots: cumsum -> pad -> affine to [-B,B] -> overwrite ends
@@ -601,7 +609,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   spline_select<K, INV, Y, VAR>(p, x, pl, part, S, o, static_cast<Y&&>(yield));
   const float w_i = o.cw_n - o.cw_i;
   const float h_i = o.ch_n - o.ch_i;
-  const float rw_i = rcp_f(w_i);
+  const float rw_i = rcp_nr(w_i);
   const float delta = h_i * rw_i;
   float yo, lo;
   if (!INV) {
@@ -609,7 +617,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
     const float tt = th * (1.f - th);
     const float num = h_i * (delta * (th * th) + o.d_i * tt);
     const float den = delta + ((o.d_i + o.d_n - 2.f * delta) * tt);
-    yo = o.ch_i + num * rcp_f(den);
+    yo = o.ch_i + num * rcp_nr(den);
     const float omt = 1.f - th;
     const float dnum = (delta * delta) * (o.d_n * (th * th) + 2.f * delta * tt + o.d_i * (omt * omt));
     lo = log_f(dnum) - 2.f * log_f(den);
@@ -619,8 +627,14 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
     const float a = xc * s + h_i * (delta - o.d_i);
     const float b = h_i * o.d_i - xc * s;
     const float c = -delta * xc;
-    const float disc = b * b - 4.f * a * c;
-    const float root = (2.f * c) * rcp_f(-b - sqrtf(disc));
+    // In exact arithmetic disc >= 0 and root in [0, 1].  In a saturated bin (slope ~1e3 against ~1e-3 next door) the
+    // fp32 discriminant cancels to a few ulps of b^2 either side of zero and the eager reference itself returns NaN
+    // there (nflows asserts disc >= 0) -- on WHICH rows depends on the last-bit rounding of the knots.  The kernel
+    // clamps both instead: well-conditioned rows are untouched bit for bit, the others stay finite (root in [0, 1]
+    // makes den >= delta / 2 + (d_i + d_n) / 4 > 0 and dnum > 0), so a sampler never hands NaN downstream
+    // (tests/test_spline_adversarial_gpu.py).
+    const float disc = fmaxf(b * b - 4.f * a * c, 0.f);
+    const float root = fminf(fmaxf((2.f * c) * rcp_nr(-b - sqrtf(disc)), 0.f), 1.f);
     yo = root * w_i + o.cw_i;
     const float tt = root * (1.f - root);
     const float den = delta + s * tt;

@@ -101,6 +101,7 @@ class FusedTrainStep:
         """Per-row losses (device tensor); leaves d(mean loss)/d(params) in ``self.grad``
         (summed over ranks when distributed)."""
         n = theta.shape[0]
+        self._last_rows = n
         gb = global_batch if global_batch is not None else n * self.world
         x = self._embedded(x)
         losses, _ = self.net.train_pass(theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
@@ -124,6 +125,7 @@ class FusedTrainStep:
         B = theta.shape[0]
         x = self._embedded(x)
         A = clamp_num_atoms(num_atoms, B)
+        self._last_rows = A * B
         gb = global_batch if global_batch is not None else B * self.world
         if choices is None:
             choices = sample_contrasting_indices(B, A, theta.device)
@@ -151,12 +153,64 @@ class FusedTrainStep:
         self.apply()
         return losses
 
+    # -- step tail (csrc/step_tail.hip): the re-pack of the image the next step reads, from a gather table built once
+    def _tail(self):
+        """(images mask, packed buffer, gather table) for the table-driven re-pack, or None: not an NSF net, rows of the
+        last pass unknown, switched off (SBI_AMD_FUSED_TAIL=0), or the table could not be built for this shape."""
+        import os
+
+        from sbi_amd.neural_nets.estimators.nsf_flow import NSFNet, packed_weights
+
+        rows = getattr(self, "_last_rows", None)
+        if type(self.net) is not NSFNet or rows is None or os.environ.get("SBI_AMD_FUSED_TAIL", "1") == "0":
+            return None
+        lib = _lib.load()
+        cfg = self.net.hyper.c_config()
+        kind = lib.sbi_amd_nsf_image_kind(cfg, int(rows), 1)
+        if kind < 0:
+            return None
+        mask = 2 if kind == 1 else 1
+        packed = packed_weights(self.net, rows=int(rows), training=True)
+        maps = self.__dict__.setdefault("_step_maps", {})
+        key = (mask, packed.data_ptr(), self.net.flat_params.data_ptr())
+        ent = maps.get(key)
+        if ent is None:
+            dev = packed.device
+            n_map = lib.sbi_amd_nsf_step_map_ints(cfg)
+            n_ws = lib.sbi_amd_nsf_step_map_workspace_floats(cfg)
+            if n_map < 0 or n_ws < 0:
+                ent = False
+            else:
+                mp = torch.zeros(int(n_map), dtype=torch.int32, device=dev)
+                ws = torch.empty(int(n_ws), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    rc = lib.sbi_amd_nsf_build_step_map(cfg, mask, _lib.ptr(self.net.flat_params.data),
+                                                        _lib.ptr(packed), _lib.ptr(mp), _lib.ptr(ws),
+                                                        _lib.current_stream(dev))
+                if rc == _lib.E_UNSUPPORTED:
+                    import warnings
+
+                    warnings.warn("sbi_amd: the re-pack table could not be built for this network; every step "
+                                  "re-packs with sbi_amd_nsf_pack_images", stacklevel=2)
+                    ent = False
+                else:
+                    _lib.check(rc, "nsf_build_step_map")
+                    ent = mp
+                del ws
+            maps.clear()            # one (image, buffer) at a time: a moved / re-allocated buffer drops the old table
+            maps[key] = ent
+        if ent is False:
+            return None
+        return mask, packed, ent
+
     @torch.no_grad()
     def apply(self) -> None:
-        """Fused clip_grad_norm_ + Adam on the flat buffers."""
+        """Fused clip_grad_norm_ + Adam on the flat buffers, then the table-driven re-pack of the image the next
+        pass reads (csrc/step_tail.hip) when a table exists for this network."""
         lib = _lib.load()
         p = self.net.flat_params
         dev = p.device
+        tail = self._tail()
         self.step_count += 1
         with torch.cuda.device(dev):
             rc = lib.sbi_amd_adam_clip_step(
@@ -165,6 +219,17 @@ class FusedTrainStep:
                 _lib.ptr(self.scratch), _lib.current_stream(dev),
             )
         _lib.check(rc, "adam_clip_step")
+        if tail is not None:
+            mask, packed, mp = tail
+            with torch.cuda.device(dev):
+                rc = lib.sbi_amd_nsf_table_pack(self.net.hyper.c_config(), _lib.ptr(p.data), _lib.ptr(packed),
+                                                _lib.ptr(mp), _lib.current_stream(dev))
+            _lib.check(rc, "nsf_table_pack")
+            # the image named by `mask` holds the new parameters; every other image (and the explicit LU inverses) is
+            # stale: packed_weights re-packs those on demand
+            self.net.__dict__["_packed_cache"] = ((p.data_ptr(), p._version, str(p.device)), packed)
+            self.net.__dict__["_packed_images"] = mask
+            return
         # parameters changed in place behind autograd's back: invalidate the packed image (the buffer itself is kept:
         # its alignment gaps are zero and stay zero, a fresh torch.zeros per step is a launch for nothing)
         cache = self.net.__dict__.get("_packed_cache")

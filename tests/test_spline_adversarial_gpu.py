@@ -34,7 +34,15 @@ gpu = pytest.mark.gpu
 B = 3.0
 H = 50
 MIN_W = 1e-3
-HIP_VS_REF = 3.0           # kernels: inside the bound, or at most this many times the eager fp32 oracle's worst row
+# kernels: inside the bound, or at most this many times the eager fp32 oracle's worst row.  Where the bound is left at
+# all (the inverse in a bin of slope 1e3: a bin height of 6e-3 is the difference of two knots of magnitude ~1, i.e. known
+# to 4e-5 relative in ANY fp32 evaluation), the two fp32 realisations scatter around the fp64 value independently:
+# over the 184 (case, quantity) pairs of the first GPU run (profiles/parity_r4.json, `spline_adversarial`) the ratio
+# kernel / eager has median 0.99, the kernel is up to 25 x CLOSER (D1-K5 saturated_alternating, inverse log-det: 0.5 x
+# the bound against the eager oracle's 12.1 x) and up to 4.7 x further out (D2-K8 one_hot_wide_bin).  So the per-case
+# cap is a guard against gross error, and the statement about equal quality is the geometric mean over a test's cases.
+HIP_VS_REF = 8.0
+HIP_VS_REF_GEOMEAN = 1.5   # geometric mean of kernel / eager over the (case, quantity) pairs of one (theta-dim, K)
 REF_SANITY_CAP = 256.0     # the eager fp32 oracle's own worst row, in units of the per-row bound (CPU test)
 
 
@@ -188,6 +196,7 @@ def _dev(t, on_device):
 def _run_cases(D, K, on_device):
     c_ulps = 4 + K / 2
     delta = c_ulps * float(np.spacing(np.float32(B)))
+    log_ratios = []
     for name, params in _logit_sets(K, seed=K).items():
         oracle, est = _build(D, K, params, on_device)
         rec = {}
@@ -283,8 +292,15 @@ def _run_cases(D, K, on_device):
             o = float(worst_ref[what].max())
             assert o == o and o <= REF_SANITY_CAP, f"{name}: the eager fp32 oracle itself is {o:.1f} x the bound ({what})"
             if on_device:
+                if max(float(r.max()), o) > 0.05:     # (both far inside the bound: the ratio is rounding noise)
+                    log_ratios.append(np.log(max(float(r.max()), 1e-3) / max(o, 1e-3)))
                 # within the bound -- or, where the eager fp32 reference itself leaves it (the inverse's quadratic
-                # formula cancels in a saturated bin, whatever the input), no more than twice as far out as IT gets
+                # formula cancels in a saturated bin, whatever the input), no more than HIP_VS_REF x as far out as IT gets
                 assert float(r.max()) <= max(1.0, HIP_VS_REF * o), (
                     f"{name}: {what} at row {i} is {float(r.max()):.2f} x its bound [1e-5 (1 + |ref|) + the "
                     f"{c_ulps}-spacing input sensitivity]; the eager fp32 oracle's worst row: {o:.2f} x")
+    if on_device and log_ratios:
+        gm = float(np.exp(np.mean(log_ratios)))
+        record("spline_adversarial", f"D{D}-K{K}-geomean_kernel_over_eager", pairs=len(log_ratios), geomean=gm)
+        assert gm <= HIP_VS_REF_GEOMEAN, (f"theta-dim {D}, {K} bins: over {len(log_ratios)} (case, quantity) pairs the "
+                                          f"kernels' worst rows are {gm:.2f} x the eager fp32 oracle's (geometric mean)")
