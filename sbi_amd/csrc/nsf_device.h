@@ -687,20 +687,26 @@ __device__ __forceinline__ void lu_forward(const float* __restrict__ lds, const 
                                            const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
   const int D = pl.D;
   const int LUS = D <= 16 ? 16 : D;
-  if (D <= 16) {   // lane group g computes the contiguous dims 4g .. 4g+3: matrix rows as float4 reads
-    float v[16], o[4];
-    row_to_regs16(zs + id.j * pl.ZW, D, v);
-    dense_mv16c<false>(lds + S.l_U, v, id.g, o);
+  if (D <= 16) {
+    // two chained 16 x 16 mat-vecs on the matrix pipe (was: 128 VALU FMAs per lane group, 32 ds_read_b128 and an LDS
+    // round trip through `us`).  K-step s covers k = 4 g + s, so a lane's four A values are ONE 16-byte read of row j,
+    // and the D fragment of U z (reg r of lane (j, g) = dim 4 g + r of row j) is the B operand of L u unchanged.
+    // (U, L zero padded to 16 x 16; the state rows are followed by finite scratch: no bounds checks.)
+    const f4 au = *(const f4*)(lds + S.l_U + id.j * 16 + 4 * id.g);
+    const f4 al = *(const f4*)(lds + S.l_L + id.j * 16 + 4 * id.g);
+    float bz[4];
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-      if (4 * id.g + ii < D) us[id.j * pl.ZW + 4 * id.g + ii] = o[ii];
-    wave_lds_fence();
-    row_to_regs16(us + id.j * pl.ZW, D, v);
-    dense_mv16c<false>(lds + S.l_L, v, id.g, o);
-    wave_lds_fence();
+    for (int s4 = 0; s4 < 4; ++s4) bz[s4] = zs[id.j * pl.ZW + 4 * id.g + s4];
+    f4 u = {0.f, 0.f, 0.f, 0.f}, y;
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-      if (4 * id.g + ii < D) zs[id.j * pl.ZW + 4 * id.g + ii] = o[ii] + lds[S.l_lub + 4 * id.g + ii];
+    for (int r = 0; r < 4; ++r) y[r] = 4 * id.g + r < D ? lds[S.l_lub + 4 * id.g + r] : 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) u = MFMA16(au[s4], bz[s4], u);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) y = MFMA16(al[s4], u[s4], y);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * id.g + r < D) zs[id.j * pl.ZW + 4 * id.g + r] = y[r];
     wave_lds_fence();
     return;
   }
@@ -722,21 +728,23 @@ __device__ __forceinline__ void lu_inverse(const float* __restrict__ lds, const 
                                            const LaneId& id, float* __restrict__ zs, float* __restrict__ us) {
   const int D = pl.D;
   const int LUS = D <= 16 ? 16 : D;
-  if (S.l_Ui >= 0) {   // D <= 16: z = U^-1 (L^-1 (y - b)) with the inverses the pack kernel prepared
-    float v[16], o[4];
+  if (S.l_Ui >= 0) {   // D <= 16: z = U^-1 (L^-1 (y - b)) with the inverses the pack kernel prepared, as in lu_forward
+    const f4 ali = *(const f4*)(lds + S.l_Li + id.j * 16 + 4 * id.g);
+    const f4 aui = *(const f4*)(lds + S.l_Ui + id.j * 16 + 4 * id.g);
+    float bv[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = zs[id.j * pl.ZW + k] - (k < D ? lds[S.l_lub + k] : 0.f);
-    dense_mv16c<false>(lds + S.l_Li, v, id.g, o);
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int k = 4 * id.g + s4;
+      bv[s4] = zs[id.j * pl.ZW + k] - (k < D ? lds[S.l_lub + k] : 0.f);
+    }
+    f4 t = {0.f, 0.f, 0.f, 0.f}, z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-      if (4 * id.g + ii < D) us[id.j * pl.ZW + 4 * id.g + ii] = o[ii];
-    wave_lds_fence();
-    row_to_regs16(us + id.j * pl.ZW, D, v);
-    dense_mv16c<false>(lds + S.l_Ui, v, id.g, o);
-    wave_lds_fence();
+    for (int s4 = 0; s4 < 4; ++s4) t = MFMA16(ali[s4], bv[s4], t);
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-      if (4 * id.g + ii < D) zs[id.j * pl.ZW + 4 * id.g + ii] = o[ii];
+    for (int s4 = 0; s4 < 4; ++s4) z = MFMA16(aui[s4], t[s4], z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * id.g + r < D) zs[id.j * pl.ZW + 4 * id.g + r] = z[r];
     wave_lds_fence();
     return;
   }

@@ -383,17 +383,18 @@ __device__ __forceinline__ void ctx_grad_update(const float* __restrict__ lds, c
     }
 }
 
-// final_layer output for the backward chunk -> this wave's rows of the shared A tile
-template <int PT, int KSH>
-__device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ lds, float* __restrict__ arow,
-                                                    const NsfPlan& pl, const TrainPlan& tp, const ShapeDesc& S,
-                                                    const LaneId& id, const f4 (&h)[NSF_HT], int d0) {
-  constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
+// final_layer output for the backward chunk -> this wave's rows of the shared A tile.  NACT = live dim slots of the
+// chunk (an odd number of transformed dims leaves the last chunk half empty: its dead slot is neither computed --
+// 26 of the 52 MFMAs at the defaults -- nor stored; the row wave zero-fills that slot's rows itself).
+template <int PT, int KSH, int NACT>
+__device__ __forceinline__ void final_layer_chunk_T_n(const float* __restrict__ lds, float* __restrict__ arow,
+                                                      const NsfPlan& pl, const TrainPlan& tp, const ShapeDesc& S,
+                                                      const LaneId& id, const f4 (&h)[NSF_HT], int d0) {
   const LinDesc& L = S.lin[S.fin];
-  f4 acc[DCHB][PT];
-  int ro[DCHB][PT];
+  f4 acc[NACT][PT];
+  int ro[NACT][PT];
 #pragma unroll
-  for (int sl = 0; sl < DCHB; ++sl) {
+  for (int sl = 0; sl < NACT; ++sl) {
     const int dd = d0 + sl;
     const bool on = dd < S.d_tr;
 #pragma unroll
@@ -406,35 +407,45 @@ __device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ ld
     }
   }
   constexpr int LA = TR_LA;
-  float a[LA + 1][DCHB][PT];
+  float a[LA + 1][NACT][PT];
 #pragma unroll
   for (int u = 0; u < LA; ++u)
 #pragma unroll
-    for (int sl = 0; sl < DCHB; ++sl)
+    for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) a[u][sl][pt] = lds[ro[sl][pt] + 4 * u];
 #pragma unroll
   for (int s = 0; s < KSH; ++s) {
     if (s + LA < KSH) {
 #pragma unroll
-      for (int sl = 0; sl < DCHB; ++sl)
+      for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) a[(s + LA) % (LA + 1)][sl][pt] = lds[ro[sl][pt] + 4 * (s + LA)];
     }
     const float bv = h[s >> 2][s & 3];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int sl = 0; sl < DCHB; ++sl)
+    for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) acc[sl][pt] = MFMA16(a[s % (LA + 1)][sl][pt], bv, acc[sl][pt]);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int sl = 0; sl < DCHB; ++sl)
+  for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) arow[id.j * tp.SA + sl * TR_SLOT(PT) + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+}
+template <int PT, int KSH>
+__device__ __forceinline__ void final_layer_chunk_T(const float* __restrict__ lds, float* __restrict__ arow,
+                                                    const NsfPlan& pl, const TrainPlan& tp, const ShapeDesc& S,
+                                                    const LaneId& id, const f4 (&h)[NSF_HT], int d0) {
+  constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);
+  if (DCHB == 2 && d0 + 1 >= S.d_tr)      // wave-uniform (a compile-time constant in the static-plan instantiations)
+    final_layer_chunk_T_n<PT, KSH, 1>(lds, arow, pl, tp, S, id, h, d0);
+  else
+    final_layer_chunk_T_n<PT, KSH, DCHB>(lds, arow, pl, tp, S, id, h, d0);
 }
 
 // RQ spline forward + reverse-mode gradient for one (row, dim) task on a lane pair (see
@@ -799,19 +810,31 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       if (cm) {   // no LULinear for theta-dim 1: the transform output IS the layer output
         for (int k = id.g; k < D; k += 4) gys[id.j * pl.ZW + k] = gzs[id.j * pl.ZW + k];
       } else if (!(pl_.ablate & 64)) {
-        float v[16], o[4];
-        row_to_regs16(gzs + id.j * pl.ZW, D, v);
-        dense_mv16c<true>(ldsF + S.l_L, v, id.g, gus_r);
+        // two chained 16 x 16 mat-vecs on the matrix pipe (was: two VALU mat-vecs with an LDS round trip between them,
+        // ~3 k cycles of the prologue while the partner grad wave waits at K0): D fragment reg r of lane (j, g) is dim
+        // 4 g + r of row j, and a K-step that covers k = 4 g + s takes that register as its B operand unchanged.
+        //   g_u[i] = sum_k L[k][i] g_z[k]     K-step s: k = 4 s + g,  A = L[4 s + g][i],  B = g_z[row j][4 s + g]
+        //   g_y[i] = sum_k U[k][i] g_u[k]     K-step s: k = 4 g + s,  A = U[4 g + s][i],  B = g_u fragment reg s
+        // (L, U are zero padded to 16 x 16 and the state rows are followed by finite scratch: no bounds checks)
+        const float* Lm = ldsF + S.l_L;
+        const float* Um = ldsF + S.l_U;
+        f4 gu = zero4, gy = zero4;
+        float al[4], bz[4], au[4];
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-          if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = gus_r[ii];
-        wave_lds_fence();
-        row_to_regs16(gys + id.j * pl.ZW, D, v);
-        dense_mv16c<true>(ldsF + S.l_U, v, id.g, o);
-        wave_lds_fence();
+        for (int s4 = 0; s4 < 4; ++s4) {
+          al[s4] = Lm[(4 * s4 + id.g) * 16 + id.j];
+          bz[s4] = gzs[id.j * pl.ZW + 4 * s4 + id.g];
+          au[s4] = Um[(4 * id.g + s4) * 16 + id.j];
+        }
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-          if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = o[ii];   // identity dims pass through
+        for (int s4 = 0; s4 < 4; ++s4) gu = MFMA16(al[s4], bz[s4], gu);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) gy = MFMA16(au[s4], gu[s4], gy);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          gus_r[ii] = gu[ii];
+          if (4 * id.g + ii < D) gys[id.j * pl.ZW + 4 * id.g + ii] = gy[ii];   // identity dims pass through
+        }
       }
       wave_lds_fence();
       // wave-tiles past the last row were never stashed by the forward pass: read the last real one instead
@@ -859,10 +882,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         ast_load(ast, 1 + 4 * (NB - 1), bt1);
       }
       float us_r[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!cm && !(pl_.ablate & 64)) {
-        float v[16];
-        row_to_regs16(zs + id.j * pl.ZW, D, v);
-        dense_mv16c<false>(ldsF + S.l_U, v, id.g, us_r);
+      if (!cm && !(pl_.ablate & 64)) {     // u[i] = sum_k U[i][k] y[k] on the matrix pipe: K-step s covers k = 4 s + g
+        const float* Um = ldsF + S.l_U;
+        float au[4], by[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          au[s4] = Um[id.j * 16 + 4 * s4 + id.g];
+          by[s4] = zs[id.j * pl.ZW + 4 * s4 + id.g];
+        }
+        f4 uv = zero4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) uv = MFMA16(au[s4], by[s4], uv);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) us_r[ii] = uv[ii];
       }
       TS(8);
       __syncthreads();                             // H: g_h = Wf^T g_p of this wave's rows is in AX
@@ -1068,6 +1100,19 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           if (k >= 1) {
             const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
             // m-tile gw = 16 spline-parameter columns of dim slot gw / PT (the second slot starts one float late)
+            if (!HB && DCHB == 2 && k == nch && (S.d_tr & 1)) {
+              // last chunk of an odd number of dims: only dim slot 0 is live (PT parameter tiles).  Instead of two
+              // waves multiplying the dead slot's zeros, the four waves split the live tiles' n-tiles: wave gw takes
+              // parameter tile gw % PT, n-tiles [PT (gw / PT), PT (gw / PT) + PT)  (accF[.][0 .. PT), see the write-out)
+              f4 (&af)[4] = accF[k - 1 < NCH ? k - 1 : 0];
+              f4 part[PT < 3 ? PT : 1];
+#pragma unroll
+              for (int i = 0; i < (PT < 3 ? PT : 1); ++i) part[i] = af[i];
+              dw_gemm<(PT < 3 ? PT : 1), TR_SA, TR_SB, true>(lds + oa, Bt, 16 * (gw % PT), 16 * PT * (gw / PT), id, part,
+                                                             PT < 3 ? PT : 1, pl_.ablate, nullptr);
+#pragma unroll
+              for (int i = 0; i < (PT < 3 ? PT : 1); ++i) af[i] = part[i];
+            } else
             dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw + (gw / PT < DCHB ? gw / PT : 0), 0, id,
                                            accF[k - 1 < NCH ? k - 1 : 0], 4, pl_.ablate,
                                            HB ? &accFb[k - 1 < NCH ? k - 1 : 0] : nullptr);
@@ -1100,9 +1145,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           __syncthreads();                         // X1
           TS(21 + 8 * b);
           dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl_.ablate, HB ? &acc2b[b] : nullptr);
-          dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl_.ablate);
           TS(22 + 8 * b);
           __syncthreads();                         // X2
+          // d Wc under the row waves' re-staging of AY / B (the matrix pipe used to idle between X2 and X3): its
+          // operands -- g_c in AX, the static input tile Bs -- are not rewritten before X4 / the initial layer's Y1
+          dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl_.ablate);
           __syncthreads();                         // X3
           TS(24 + 8 * b);
           dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[b], 4, pl_.ablate, HB ? &acc1b[b] : nullptr);
@@ -1148,6 +1195,22 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
   #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c < nch) {
+        if (!HB && DCHB == 2 && c == nch - 1 && (S.d_tr & 1)) {     // the split last chunk (see the chunk steps)
+          const int dd = c * DCHB, pt = gw % PT;
+  #pragma unroll
+          for (int i = 0; i < (PT < 3 ? PT : 1); ++i)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p = 16 * pt + 4 * id.g + r;
+              const int in = 16 * (PT * (gw / PT) + i) + id.j;
+              if (p < pl.P) {
+                const int out = dd * pl.P + p;
+                if (in < LF.in) part[LF.g_w + out * LF.in + in] = accF[c][i][r];
+                else if (in == LF.in) part[LF.g_b + out] = accF[c][i][r];
+              }
+            }
+          continue;
+        }
         const int dd = c * DCHB + gw / PT;
         const int pt = gw % PT;
         if (gw < DCHB * PT && dd < S.d_tr) {
