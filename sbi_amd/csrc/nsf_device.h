@@ -282,7 +282,7 @@ __device__ __forceinline__ float softplus_bf(float x) {
 // ast_store / ast_load already includes 4 * lane); slots: 0 h_0 | per block b: 1+4b t1 (pre-relu),
 // 2+4b t2, 3+4b sigmoid(gate), 4+4b h_{b+1}.  The backward kernel reloads them instead of
 // recomputing the conditioner (trading ~0.75 GB/step of HBM traffic for 480 MFMAs per 16 rows).
-#define NSF_AST_SLOTS(NB) ((NB) > 0 ? 1 + 4 * (NB) : 2)   // ctx_mlp (NB == 0): h1, h2
+#define NSF_AST_SLOTS(NB) (1 + 4 * (NB))   // residual-net conditioner with NB blocks (ctx_mlp: nsf_ast_slots(pl), nsf_plan.h)
 __device__ __forceinline__ void ast_store(float* __restrict__ ast, int slot, const f4 (&v)[NSF_HT]) {
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt) {
@@ -305,20 +305,23 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
   acc_init_bias(lds, S.lin[0], id, h);
   gemm_blds(lds, S.lin[0], id, cin_row, h);
   if (pl.ctx_mlp) {
-    // ContextSplineMap (flow.py:1419-1478): h = relu(W_h relu(W_in c + b_in) + b_h)
+    // ContextSplineMap (flow.py:1419-1478): h_1 = relu(W_in c + b_in), h_{i+1} = relu(W_h h_i + b_h) for i = 1 ... reps
+    // (hidden_layers_spline_context applications of ONE Linear: the reference repeats the same module object)
     f4 u[NSF_HT];
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.f);
     if (ast) ast_store(ast, 0, h);
-    acc_init_bias(lds, S.lin[1], id, u);
-    gemm_breg<KSH>(lds, S.lin[1], id, h, u);
+    for (int i = 0; i < pl.ctx_reps; ++i) {
+      acc_init_bias(lds, S.lin[1], id, u);
+      gemm_breg<KSH>(lds, S.lin[1], id, h, u);
 #pragma unroll
-    for (int mt = 0; mt < NSF_HT; ++mt)
+      for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(u[mt][r], 0.f);
-    if (ast) ast_store(ast, 1, h);
+        for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(u[mt][r], 0.f);
+      if (ast) ast_store(ast, 1 + i, h);
+    }
     return;
   }
   if (ast) ast_store(ast, 0, h);

@@ -144,7 +144,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
     if (!INV && astash) {
       const long long nt16 = (n + 15) / 16;
       const long long tile16 = (long long)blockIdx.x * nw + wave;
-      if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * NSF_AST_SLOTS(pl.NB)) * 1024 + 4 * id.lane;
+      if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * nsf_ast_slots(pl)) * 1024 + 4 * id.lane;
     }
     if (!(pl_.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }

@@ -48,6 +48,7 @@ struct NsfPlan {
   int D, C, H, K, T, NB, P, PT;   // P = 3K-1, PT = ceil(P/16)
   int ctx_mlp;                    // D == 1: sbi's ContextSplineMap conditioner (flow.py:1419-1478): params from
                                   // the context only (C->H relu, H->H relu, H->P), mask [1], no LULinear
+  int ctx_reps;                   // ctx_mlp: applications of the one shared hidden layer (hidden_layers_spline_context)
   int KSH;                        // hidden-layer K-steps the kernel template is instantiated for (13 or 16; 32: H > 64)
   float B, min_w, min_h, min_d, lu_eps, sqrt_h, inv_sqrt_h;
   float one_minus_kw, one_minus_kh;   // 1 - min_w*K, 1 - min_h*K
@@ -74,6 +75,8 @@ int nsf_build_plan(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* pl);
 int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int* nw_out, bool wide = false);
 // Packed weight image: T consecutive LDS images (img_floats each), written by
 // nsf_pack_kernel from the flat parameters; kernels stage a layer with a float4 copy.
+// activation-stash slots per (transform, 16-row tile): h_0 | per block t1 t2 sigmoid(gate) h; ctx_mlp: h_1 ... h_{reps+1}
+static inline int nsf_ast_slots(const NsfPlan& pl) { return pl.ctx_mlp ? 1 + pl.ctx_reps : 1 + 4 * pl.NB; }
 static inline int64_t nsf_packed_floats(const NsfPlan& pl) { return (int64_t)pl.T * pl.img_floats; }
 static inline int64_t nsf_lds_bytes(const NsfPlan& pl, int nw) {
   return 4ll * ((int64_t)pl.lds_w_floats + (int64_t)nw * pl.sc_total);

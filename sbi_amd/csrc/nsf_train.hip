@@ -109,7 +109,7 @@ static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int6
   *o_part = o; o += (int64_t)pl.T * tp.grid * tp.PLP;
   o = (o + 3) / 4 * 4;
   *o_ast = o;   // activation stash: T x ceil(n/16) wave-tiles x slots x 1024 floats
-  o += (int64_t)pl.T * ((n + 15) / 16) * NSF_AST_SLOTS(pl.NB) * 1024;
+  o += (int64_t)pl.T * ((n + 15) / 16) * nsf_ast_slots(pl) * 1024;
   o += 2048;   // debug timeline (SBI_AMD_TIMELINE): last 1024 int64 of the workspace
   return o;
 }

@@ -644,6 +644,7 @@ __device__ __forceinline__ void write_bias(float* __restrict__ part, const LinDe
 }
 
 // ------------------------------------------------------------------ backward kernel
+__device__ __forceinline__ constexpr int cm_reps(const NsfPlan& pl) { return pl.ctx_reps > 0 ? pl.ctx_reps : 1; }
 // Wave specialisation, one workgroup = 64-row tile:
 //   waves 0-3 ("row" waves): 16 rows each.  Loads, LULinear backward, the spline forward + reverse
 //     mode (VALU), the row-wise backward through the residual blocks (transposed-weight MFMA GEMMs);
@@ -684,7 +685,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
   const LaneId id = make_lane();
   constexpr bool cm = (NBT == 0);             // theta-dim 1: context-only MLP conditioner, no LULinear
   constexpr int NB = cm ? 1 : NBT;            // ctx_mlp: one hidden H x H gradient tile set
-  constexpr int SLOTS = NSF_AST_SLOTS(NBT);
+  const int SLOTS = nsf_ast_slots(pl);           // (a compile-time constant in the static-plan instantiations)
+  const int reps = cm_reps(pl);                  // ctx_mlp: applications of the shared hidden layer (>= 1)
   const int par = cm ? 0 : (SP != 0 ? SP - 1 : (t & 1));
   const ShapeDesc& S = pl.shape[par];
   const int D = pl.D, C = pl.C;
@@ -873,9 +875,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       }
       // ---- step nch (the grad waves finish d Wf / Wf^T g of the last chunk): fetch the last block's
       // temporaries and do the LULinear forward piece its parameter gradients need, u = U y
-      if (cm) {
-        ast_load(ast, 0, hpre[0]);
-        ast_load(ast, 1, hpre[1]);
+      if (cm) {     // the last application's input and output: h_reps, h_{reps+1} (stash slots reps - 1, reps)
+        ast_load(ast, reps - 1, hpre[0]);
+        ast_load(ast, reps, hpre[1]);
       } else {
         ast_load(ast, 2 + 4 * (NB - 1), bt2);
         ast_load(ast, 3 + 4 * (NB - 1), bsg);
@@ -916,23 +918,33 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       }
 
       if (cm) {
-        // ---- ctx_mlp: h2 = relu(W_h h1 + b_h): one hidden layer to walk back through
+        // ---- ctx_mlp: h_{i+1} = relu(W_h h_i + b_h), i = reps ... 1: the SAME hidden layer walked back `reps` times
+        // (hidden_layers_spline_context; its weight gradient accumulates over the applications in the grad waves)
         f4 ga[NSF_HT], gb[NSF_HT];
+        for (int i = reps; i >= 1; --i) {
+          if (i < reps) {           // (the first iteration's operands were requested before the H barrier)
+            ast_load(ast, i - 1, hpre[0]);
+            ast_load(ast, i, hpre[1]);
+            __syncthreads();        // X0: the previous application's d W_h has consumed the tiles
+          }
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[1][mt][r] > 0.f ? gh[mt][r] : 0.f;
+          stage_D(lds + o_AY, SA, trow, id, ga, false);
+          stage_DB(Bt, SB, trow, id, hpre[0], true);
+          if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
+          __syncthreads();                           // X1
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
+          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[1], id, ga, gb, pl_.ablate);
+#pragma unroll
+          for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = gb[mt];     // gradient wrt h_i (post-relu)
+        }
 #pragma unroll
         for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ga[mt][r] = hpre[1][mt][r] > 0.f ? gh[mt][r] : 0.f;
-        stage_D(lds + o_AY, SA, trow, id, ga, false);
-        stage_DB(Bt, SB, trow, id, hpre[0], true);
-        if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;
-        __syncthreads();                           // X1
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-        gemm_T_breg<KSH, NSF_HT>(lds, S.lin[1], id, ga, gb, pl_.ablate);
-#pragma unroll
-        for (int mt = 0; mt < NSF_HT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gh[mt][r] = hpre[0][mt][r] > 0.f ? gb[mt][r] : 0.f;
+          for (int r = 0; r < 4; ++r) gh[mt][r] = hpre[0][mt][r] > 0.f ? gh[mt][r] : 0.f;   // through h_1 = relu(...)
       } else {
         // ---- residual blocks, last -> first
 #pragma unroll
@@ -1068,7 +1080,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
       const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
                          4 * id0.lane;
-      ast_load(ast, cm ? 1 : 4 * NB, hl);
+      ast_load(ast, cm ? reps : 4 * NB, hl);
     };
     fetch_hl(blockIdx.x);
     for (int tile = blockIdx.x; tile < tp_.ntiles; tile += gridDim.x) {
@@ -1137,8 +1149,11 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         }
       }
       if (cm) {
-        __syncthreads();                           // X1
-        dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, pl_.ablate, HB ? &acc1b[0] : nullptr);
+        for (int i = reps; i >= 1; --i) {
+          if (i < reps) __syncthreads();           // X0
+          __syncthreads();                         // X1
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, pl_.ablate, HB ? &acc1b[0] : nullptr);
+        }
       } else {
   #pragma unroll
         for (int b = NB - 1; b >= 0; --b) {
