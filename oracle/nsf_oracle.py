@@ -467,6 +467,7 @@ class NSFOracle(nn.Module):
     def __init__(
         self, batch_theta: Tensor, batch_x: Tensor, z_score_theta="independent", z_score_x="independent",
         hidden_features=50, num_transforms=5, num_bins=10, tail_bound=3.0, num_blocks=2,
+        hidden_layers_spline_context=1,
     ):
         super().__init__()
         D = batch_theta[0].numel()
@@ -479,7 +480,8 @@ class NSFOracle(nn.Module):
                 transforms.append(
                     PiecewiseRationalQuadraticCouplingTransform(
                         torch.tensor([1], dtype=torch.uint8), C, hidden_features, num_blocks, num_bins=num_bins,
-                        tail_bound=tail_bound, context_spline_map=True))
+                        tail_bound=tail_bound, context_spline_map=True,
+                        hidden_layers_spline_context=hidden_layers_spline_context))
                 continue
             mask = create_alternating_binary_mask(D, even=(i % 2 == 0))
             transforms.append(

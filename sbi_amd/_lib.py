@@ -35,7 +35,7 @@ class NSFConfigC(Structure):
     _fields_ = [
         ("D", c_int32), ("C", c_int32), ("H", c_int32), ("K", c_int32), ("T", c_int32), ("NB", c_int32),
         ("tail_bound", c_float), ("min_bin_width", c_float), ("min_bin_height", c_float),
-        ("min_derivative", c_float), ("lu_eps", c_float),
+        ("min_derivative", c_float), ("lu_eps", c_float), ("ctx_layers", c_int32),
     ]
 
 

@@ -76,7 +76,7 @@ int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int
 // Packed weight image: T consecutive LDS images (img_floats each), written by
 // nsf_pack_kernel from the flat parameters; kernels stage a layer with a float4 copy.
 // activation-stash slots per (transform, 16-row tile): h_0 | per block t1 t2 sigmoid(gate) h; ctx_mlp: h_1 ... h_{reps+1}
-static inline int nsf_ast_slots(const NsfPlan& pl) { return pl.ctx_mlp ? 1 + pl.ctx_reps : 1 + 4 * pl.NB; }
+constexpr int nsf_ast_slots(const NsfPlan& pl) { return pl.ctx_mlp ? 1 + pl.ctx_reps : 1 + 4 * pl.NB; }
 static inline int64_t nsf_packed_floats(const NsfPlan& pl) { return (int64_t)pl.T * pl.img_floats; }
 static inline int64_t nsf_lds_bytes(const NsfPlan& pl, int nw) {
   return 4ll * ((int64_t)pl.lds_w_floats + (int64_t)nw * pl.sc_total);

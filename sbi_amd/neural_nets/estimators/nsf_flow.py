@@ -44,11 +44,13 @@ class NSFHyper:
     min_bin_height: float = 1e-3
     min_derivative: float = 1e-3
     lu_eps: float = 1e-3
+    hidden_layers_spline_context: int = 1   # theta-dim 1 only: applications of ContextSplineMap's ONE hidden Linear
 
     def c_config(self) -> _lib.NSFConfigC:
         return _lib.NSFConfigC(
             self.D, self.C, self.hidden_features, self.num_bins, self.num_transforms, self.num_blocks,
             self.tail_bound, self.min_bin_width, self.min_bin_height, self.min_derivative, self.lu_eps,
+            int(self.hidden_layers_spline_context) if self.D == 1 else 0,
         )
 
     # -- layout of the flat buffer (must agree with csrc/nsf_plan.cpp) -----------
@@ -69,10 +71,13 @@ class NSFHyper:
     def layer_entries(self, t: int) -> List[Tuple[str, Tuple[int, ...]]]:
         """(nflows sub-key, shape) in flat order for transform t."""
         H, C, P = self.hidden_features, self.C, 3 * self.num_bins - 1
-        if self.ctx_mlp:   # nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) -> indices 0, 2, 4
+        if self.ctx_mlp:
+            # nn.Sequential(Linear, ReLU, [Linear, ReLU] * n, Linear): the SAME hidden Linear object sits at indices
+            # 2, 4, ..., 2 n (flow.py:1456-1462); it is stored once (under index 2), the output layer is index 2 + 2 n
             pre = "transform_net.spline_predictor."
+            fin = 2 + 2 * self.hidden_layers_spline_context
             return [(pre + "0.weight", (H, C)), (pre + "0.bias", (H,)), (pre + "2.weight", (H, H)),
-                    (pre + "2.bias", (H,)), (pre + "4.weight", (P, H)), (pre + "4.bias", (P,))]
+                    (pre + "2.bias", (H,)), (pre + f"{fin}.weight", (P, H)), (pre + f"{fin}.bias", (P,))]
         out = [("transform_net.initial_layer.weight", (H, self.d_id(t) + C)),
                ("transform_net.initial_layer.bias", (H,))]
         for b in range(self.num_blocks):
@@ -133,7 +138,7 @@ class NSFNet(nn.Module):
                 pre = "transform_net.spline_predictor."
                 mods[pre + "0"] = nn.Linear(h.C, h.hidden_features)
                 mods[pre + "2"] = nn.Linear(h.hidden_features, h.hidden_features)
-                mods[pre + "4"] = nn.Linear(h.hidden_features, 3 * h.num_bins - 1)
+                mods[pre + str(2 + 2 * h.hidden_layers_spline_context)] = nn.Linear(h.hidden_features, 3 * h.num_bins - 1)
                 for key, _shape in h.layer_entries(t):
                     mod, attr = key.rsplit(".", 1)
                     chunks.append(getattr(mods[mod], attr).detach().reshape(-1))
@@ -201,6 +206,10 @@ class NSFNet(nn.Module):
             sd[prefix + "_transform._transforms.0._scale"] = self.zstats[h.D : 2 * h.D].clone()
         for key, off, n, shape in self._slices():
             sd[prefix + key] = flat[off : off + n].reshape(shape).clone()
+            if h.ctx_mlp and ".spline_predictor.2." in key:
+                # the reference's state_dict lists the shared hidden Linear under every index it occupies
+                for i in range(2, h.hidden_layers_spline_context + 1):
+                    sd[prefix + key.replace(".spline_predictor.2.", f".spline_predictor.{2 * i}.")] = sd[prefix + key].clone()
         if self.z_score_x:
             sd[prefix + "_embedding_net.0._mean"] = self.zstats[2 * h.D : 2 * h.D + h.C].clone()
             sd[prefix + "_embedding_net.0._std"] = self.zstats[2 * h.D + h.C :].clone()
@@ -213,6 +222,12 @@ class NSFNet(nn.Module):
             src = sd[prefix + key]
             if tuple(src.shape) != tuple(shape):
                 raise ValueError(f"{key}: expected {shape}, got {tuple(src.shape)}")
+            if h.ctx_mlp and ".spline_predictor.2." in key:      # one module under several indices: they must agree
+                for i in range(2, h.hidden_layers_spline_context + 1):
+                    dup = sd.get(prefix + key.replace(".spline_predictor.2.", f".spline_predictor.{2 * i}."))
+                    if dup is not None and not torch.equal(dup, src):
+                        raise ValueError(f"{key}: the checkpoint holds different weights for the repeated hidden layer "
+                                         "(ContextSplineMap shares ONE Linear across hidden_layers_spline_context)")
             self.flat_params[off : off + n].copy_(src.reshape(-1).to(self.flat_params))
         if self.z_score_theta:
             self.zstats[: h.D].copy_(sd[prefix + "_transform._transforms.0._shift"].reshape(-1))

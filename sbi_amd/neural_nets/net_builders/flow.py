@@ -104,15 +104,17 @@ def build_nsf(
     if dropout_probability != 0.0 or use_batch_norm:
         raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
     x_numel = batch_x[0].numel()
-    if x_numel == 1 and hidden_layers_spline_context != 1:
+    if x_numel == 1 and not 1 <= int(hidden_layers_spline_context) <= 4:
         raise NotImplementedError(
             "sbi_amd.build_nsf: the 1-D theta conditioner (ContextSplineMap, flow.py:1419-1478) is implemented "
-            "for hidden_layers_spline_context=1 (the reference default)."
+            "for hidden_layers_spline_context = 1 ... 4 (applications of its one shared hidden layer); "
+            f"got {hidden_layers_spline_context}."
         )
     D, C, zstats, zx, zy, embedding = _flow_inputs(batch_x, batch_y, z_score_x, z_score_y, embedding_net, "build_nsf")
 
     hyper = NSFHyper(D=D, C=C, hidden_features=hidden_features, num_transforms=num_transforms,
-                     num_bins=num_bins, num_blocks=num_blocks, tail_bound=float(tail_bound))
+                     num_bins=num_bins, num_blocks=num_blocks, tail_bound=float(tail_bound),
+                     hidden_layers_spline_context=int(hidden_layers_spline_context) if D == 1 else 1)
     net = NSFNet(hyper, zstats, z_score_theta=zx, z_score_x=zy, dtype=kwargs.get("dtype", torch.float32))
     return NSFFlow(net, input_shape=batch_x[0].shape, condition_shape=batch_y[0].shape, embedding_net=embedding)
 

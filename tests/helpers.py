@@ -21,6 +21,8 @@ def matched_pair(D=10, C=10, n=1000, perturb=0.05, seed=1, device="cuda", **kw):
     okw = dict(hidden_features=kw.get("hidden_features", 50), num_transforms=kw.get("num_transforms", 5),
                num_bins=kw.get("num_bins", 10), num_blocks=kw.get("num_blocks", 2),
                tail_bound=kw.get("tail_bound", 3.0))
+    if "hidden_layers_spline_context" in kw:
+        okw["hidden_layers_spline_context"] = kw["hidden_layers_spline_context"]
     zt = kw.get("z_score_theta", "independent")
     zx = kw.get("z_score_x", "independent")
     torch.manual_seed(seed)

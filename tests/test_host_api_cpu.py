@@ -55,9 +55,11 @@ def test_builder_rejects_what_the_hip_path_does_not_implement():
     theta, x = linear_gaussian_data(50, 4, 7)
     with pytest.raises(ValueError, match="transform_to_unconstrained"):
         build_nsf(theta, x, z_score_x="transform_to_unconstrained")
-    with pytest.raises(NotImplementedError):
-        build_nsf(theta[:, :1], x, hidden_layers_spline_context=2)
+    for bad in (0, 5):          # no hidden layer at all / more than four applications: not built
+        with pytest.raises(NotImplementedError):
+            build_nsf(theta[:, :1], x, hidden_layers_spline_context=bad)
     assert build_nsf(theta[:, :1], x).net.hyper.ctx_mlp
+    assert build_nsf(theta, x, hidden_layers_spline_context=3).net.hyper.hidden_layers_spline_context == 1   # theta-dim > 1: unused
     emb = build_nsf(theta, x, embedding_net=torch.nn.Linear(7, 3))       # embedded features feed the kernels
     assert emb.net.hyper.C == 3 and emb.condition_shape == torch.Size([7])
     assert not emb.net.z_score_x and isinstance(emb.embedding_net[0], torch.nn.Module)   # Standardize -> Linear
@@ -341,3 +343,31 @@ def test_tracker_receives_the_rounds_statistics():
     second = rec.metrics[n1:]
     assert [m[2] for m in second if m[0] == "validation_loss"] == list(range(e0, len(s["validation_loss"])))
     assert rec.flushes == 2
+
+
+def test_context_spline_map_with_a_repeated_hidden_layer_exchanges_weights_with_the_reference_layout():
+    """hidden_layers_spline_context = n (flow.py:346, 1456-1462): the reference puts the SAME Linear object at indices
+    2, 4, ..., 2 n of `spline_predictor`, so its state_dict lists that one tensor n times and the output layer moves to
+    index 2 + 2 n.  The flat buffer stores it once; the exchange emits / accepts every alias and refuses aliases that
+    disagree (a checkpoint of a different architecture)."""
+    from oracle.nsf_oracle import NSFOracle
+
+    theta, x = linear_gaussian_data(60, 1, 3)
+    torch.manual_seed(4)
+    oracle = NSFOracle(theta, x, num_transforms=2, hidden_layers_spline_context=3)
+    est = build_nsf(theta, x, num_transforms=2, hidden_layers_spline_context=3)
+    assert est.net.hyper.param_count() == build_nsf(theta, x, num_transforms=2).net.hyper.param_count()   # shared weights
+    sd_ref = oracle.state_dict()
+    pre = "net._transform._transforms.1.transform_net.spline_predictor."
+    assert {k for k in sd_ref if k.startswith(pre)} == {pre + f"{i}.{w}" for i in (0, 2, 4, 6, 8) for w in ("weight", "bias")}
+    est.net.load_nflows_state_dict(sd_ref)
+    sd = est.net.nflows_state_dict()
+    missing, unexpected = oracle.load_state_dict(sd, strict=False)    # same parameter keys, aliases included
+    assert not unexpected and all(k.endswith("_features") for k in missing)   # (only the coupling index buffers)
+    for k, v in sd_ref.items():
+        if not k.endswith("_features"):
+            assert torch.equal(sd[k], v), k
+    broken = dict(sd_ref)
+    broken[pre + "4.weight"] = broken[pre + "4.weight"] + 1.0
+    with pytest.raises(ValueError, match="repeated hidden layer"):
+        est.net.load_nflows_state_dict(broken)

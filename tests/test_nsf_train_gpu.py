@@ -41,6 +41,8 @@ CONFIGS = [
     dict(D=4, C=3, num_bins=4, num_transforms=2),
     dict(D=5, C=4, num_bins=16, num_transforms=2),
     dict(D=1, C=3),
+    dict(D=1, C=3, hidden_layers_spline_context=2),     # ContextSplineMap's one hidden Linear applied twice / four times:
+    dict(D=1, C=5, hidden_layers_spline_context=4, num_transforms=2),   # its gradient sums over the applications
     # shapes whose weight image only fits LDS in the backward kernel's overlay mode (final layer + LU and the
     # hidden layers take turns in one region)
     dict(D=12, C=10, num_transforms=2),
