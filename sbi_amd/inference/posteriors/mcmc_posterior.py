@@ -154,6 +154,14 @@ class MCMCPosterior:
         samples = self.theta_transform.inv(transformed)
         return samples.reshape((*torch.Size(sample_shape), -1))
 
+    def __getstate__(self):
+        """`potential_` is the closure the last `sample()` call ran its chains on (the reference keeps a picklable
+        `partial` there, mcmc_posterior.py:145); it is rebuilt by every `sample()` call, so it is simply not part of
+        the pickled state.  The live object is left untouched (tests/save_and_load_test.py:23-45)."""
+        state = dict(self.__dict__)
+        state["potential_"] = None
+        return state
+
     def _fused_potential(self) -> Optional[Callable]:
         """Four launches per tick instead of ~15: when the potential is the NSF estimator's log-prob inside the
         prior support and the parameter transform is one `mcmc_transform` builds (z-scoring of an unbounded
