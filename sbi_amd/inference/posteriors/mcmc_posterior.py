@@ -160,6 +160,7 @@ class MCMCPosterior:
         the pickled state.  The live object is left untouched (tests/save_and_load_test.py:23-45)."""
         state = dict(self.__dict__)
         state["potential_"] = None
+        state["_posterior_sampler"] = None      # holds the same closure as its log_prob_fn (diagnostics only)
         return state
 
     def _fused_potential(self) -> Optional[Callable]:

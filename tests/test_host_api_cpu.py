@@ -371,3 +371,21 @@ def test_context_spline_map_with_a_repeated_hidden_layer_exchanges_weights_with_
     broken[pre + "4.weight"] = broken[pre + "4.weight"] + 1.0
     with pytest.raises(ValueError, match="repeated hidden layer"):
         est.net.load_nflows_state_dict(broken)
+
+
+def test_mcmc_posterior_pickles_after_it_has_sampled():
+    """`sample()` leaves the chains' potential closure on the posterior (`potential_`, and inside `_posterior_sampler`):
+    neither is part of the pickled state, and pickling does not touch the live object (tests/save_and_load_test.py:23-45;
+    the device test is tests/test_npe_gpu.py::test_device_posterior_survives_pickling_...[mcmc])."""
+    import pickle
+
+    from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+
+    post = MCMCPosterior.__new__(MCMCPosterior)
+    closure = lambda u: u          # noqa: E731  (what sample() stores: a local function)
+    post.__dict__.update(dict(potential_=closure, _posterior_sampler=type("S", (), {})(), method="slice_np_vectorized"))
+    post._posterior_sampler.log_prob_fn = closure
+    before = {k: id(v) for k, v in vars(post).items()}
+    clone = pickle.loads(pickle.dumps(post))
+    assert {k: id(v) for k, v in vars(post).items()} == before
+    assert clone.potential_ is None and clone._posterior_sampler is None and clone.method == "slice_np_vectorized"
