@@ -39,30 +39,25 @@ __host__ __device__ __forceinline__ uint32_t shf_prp(uint32_t i, uint32_t n, int
   return v;
 }
 
-// One thread per OUTPUT ELEMENT (blockIdx.y: 0 = the `a` rows, 1 = the `b` rows): the stores of a wavefront are 256
-// contiguous bytes and the d consecutive lanes of a row read one contiguous source row.  (A thread per ROW copying its
-// d floats one by one wrote 64 lanes x 4 bytes at a stride of d floats per instruction: 9.4 us for 65 536 rows of
-// 10 + 10 floats, 1 % of the headline step; the permutation is cheap enough to re-evaluate per element.)
 __global__ void __launch_bounds__(256)
 shuffled_gather_kernel(const float* __restrict__ a, int da, const float* __restrict__ b, int db,
                        const long long* __restrict__ base_idx, unsigned n_perm, int hb, unsigned long long key,
                        long long offset, long long count, float* __restrict__ a_out, float* __restrict__ b_out,
                        long long* __restrict__ idx_out) {
-  const bool second = blockIdx.y != 0;
-  const float* __restrict__ src_tab = second ? b : a;
-  float* __restrict__ out = second ? b_out : a_out;
-  const int d = second ? db : da;
-  // the rows' index list rides on the first plane that exists
-  const bool write_idx = idx_out && (second ? (a_out == nullptr && b_out != nullptr) : (a_out != nullptr || b_out == nullptr));
-  if (!out && !write_idx) return;
-  const long long total = count * (out ? d : 1);
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long i = out ? e / d : e;
-    const int k = out ? (int)(e - i * d) : 0;
-    const unsigned p = shf_prp((unsigned)(offset + i), n_perm, hb, key);
-    const long long src = base_idx ? base_idx[p] : (long long)p;
-    if (write_idx && k == 0) idx_out[i] = src;
-    if (out) out[e] = src_tab[src * d + k];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const unsigned p = shf_prp((unsigned)(offset + i), n_perm, hb, key);
+  const long long src = base_idx ? base_idx[p] : (long long)p;
+  if (idx_out) idx_out[i] = src;
+  if (a_out) {
+    const float* s = a + src * da;
+    float* d = a_out + i * da;
+    for (int k = 0; k < da; ++k) d[k] = s[k];
+  }
+  if (b_out) {
+    const float* s = b + src * db;
+    float* d = b_out + i * db;
+    for (int k = 0; k < db; ++k) d[k] = s[k];
   }
 }
 
@@ -76,10 +71,7 @@ extern "C" int sbi_amd_shuffled_gather(const float* a, int32_t da, const float* 
   int bits = 2;
   while (bits < 32 && (1ll << bits) < n_perm) ++bits;
   const int hb = (bits + 1) / 2;
-  const int dmax = (a_out ? da : 1) > (b_out ? db : 1) ? (a_out ? da : 1) : (b_out ? db : 1);
-  long long wgs = (count * dmax + 255) / 256;
-  if (wgs > 65535 * 16) wgs = 65535 * 16;      // grid-stride beyond that
-  hipLaunchKernelGGL(shuffled_gather_kernel, dim3((unsigned)wgs, 2), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(shuffled_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      a, da, b, db, (const long long*)base_idx, (unsigned)n_perm, hb, (unsigned long long)key,
                      (long long)offset, (long long)count, a_out, b_out, (long long*)idx_out);
   return (int)hipGetLastError();
