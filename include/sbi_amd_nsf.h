@@ -175,6 +175,19 @@ int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, flo
                            int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
                            float max_norm, float* scratch, void* stream);
 
+/* clip_grad_norm_ needs |grad|^2; the training pass's gradient reduction leaves it as partial sums in its workspace (a
+ * rider of the reduction kernel: each workgroup squares what it writes), which saves the separate pass over the gradient:
+ *   parts = sbi_amd_nsf_train_sqnorm_parts(cfg, n, workspace, &n_parts)   after loss_fwd_bwd / train_backward of n rows
+ *     (NULL / 0: that pass leaves none -- the generic training pass -- use sbi_amd_adam_clip_step)
+ *   sbi_amd_adam_clip_step_parts(..., parts, n_parts, scratch, stream)    instead of sbi_amd_adam_clip_step
+ * Only valid while grad_out is what the reduction wrote: a data-parallel all-reduce over MORE THAN ONE rank changes the
+ * gradient, and the norm must then be taken from the reduced gradient (sbi_amd_adam_clip_step). */
+const float* sbi_amd_nsf_train_sqnorm_parts(const sbi_amd_nsf_config* cfg, int64_t n, const float* workspace,
+                                            int64_t* n_parts);
+int sbi_amd_adam_clip_step_parts(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                                 int64_t step, float lr, float beta1, float beta2, float eps, float max_norm,
+                                 const float* sqnorm_parts, int64_t n_parts, float* scratch, void* stream);
+
 /* Table-driven re-pack (csrc/step_tail.hip).  A training step ends with the weight image of the next step's kernels
  * being rebuilt from the flat parameters -- what nflows redoes inside every forward call (LULinear._create_lower_upper
  * and the .t() views, nflows transforms/lu.py) and sbi_amd_nsf_pack_images does in 11 - 13 us by re-deriving where

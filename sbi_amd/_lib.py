@@ -99,6 +99,12 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
          c_void_p, c_void_p],
     ),
+    "sbi_amd_nsf_train_sqnorm_parts": (c_void_p, [POINTER(NSFConfigC), c_int64, c_void_p, POINTER(c_int64)]),
+    "sbi_amd_adam_clip_step_parts": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
+         c_void_p, c_int64, c_void_p, c_void_p],
+    ),
     "sbi_amd_nsf_step_map_ints": (c_int64, [POINTER(NSFConfigC)]),
     "sbi_amd_nsf_step_map_workspace_floats": (c_int64, [POINTER(NSFConfigC)]),
     "sbi_amd_nsf_build_step_map": (

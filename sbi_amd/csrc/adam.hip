@@ -36,15 +36,11 @@ grad_sqnorm_partials(const float* __restrict__ g, long long count, float* __rest
 __global__ void __launch_bounds__(ADAM_THREADS)
 adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
             long long count, float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-            float max_norm, int npart, float* __restrict__ scratch) {
-  __shared__ float s_coef;
-  if (threadIdx.x == 0) {
-    float norm;
-    s_coef = adam_clip_coef(scratch + 1, npart, max_norm, &norm);
-    if (blockIdx.x == 0) scratch[0] = norm;
-  }
-  __syncthreads();
-  const AdamK k = {s_coef, beta1, beta2, eps, lr / bc1, bc2_sqrt};
+            float max_norm, const float* __restrict__ parts, int npart, float* __restrict__ scratch) {
+  float norm;
+  const float coef = adam_clip_coef_block(parts, npart, max_norm, &norm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = norm;
+  const AdamK k = {coef, beta1, beta2, eps, lr / bc1, bc2_sqrt};
   for (long long i = (long long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < count;
        i += (long long)gridDim.x * ADAM_THREADS) {
     float mi = m[i], vi = v[i];
@@ -54,19 +50,45 @@ adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restric
   }
 }
 
-extern "C" int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                      int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
-                                      float max_norm, float* scratch, void* stream) {
-  if (!params || !grad || !exp_avg || !exp_avg_sq || !scratch || count < 0 || step < 1) return SBI_AMD_E_BADARG;
-  if (count == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
+static int adam_launch(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, int64_t step,
+                       float lr, float beta1, float beta2, float eps, float max_norm, const float* parts, int64_t n_parts,
+                       float* scratch, hipStream_t st) {
+  static_assert(ADAM_THREADS == ADAM_BLOCK, "adam_clip_coef_block is written for the update kernel's workgroup size");
   int nwg = (int)((count + ADAM_THREADS * 4 - 1) / (ADAM_THREADS * 4));
   if (nwg > ADAM_NWG) nwg = ADAM_NWG;
   if (nwg < 1) nwg = 1;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(grad_sqnorm_partials, dim3(nwg), dim3(ADAM_THREADS), 0, st, grad, (long long)count, scratch);
+  if (!parts) {     // the caller has no partial sums of squares of `grad`: one more launch makes them
+    hipLaunchKernelGGL(grad_sqnorm_partials, dim3(nwg), dim3(ADAM_THREADS), 0, st, grad, (long long)count, scratch);
+    parts = scratch + 1;
+    n_parts = nwg;
+  }
   hipLaunchKernelGGL(adam_update, dim3(nwg), dim3(ADAM_THREADS), 0, st, params, grad, exp_avg, exp_avg_sq,
-                     (long long)count, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, nwg, scratch);
+                     (long long)count, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, parts, (int)n_parts,
+                     scratch);
   return (int)hipGetLastError();
+}
+
+extern "C" int sbi_amd_adam_clip_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                      int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
+                                      float max_norm, float* scratch, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !scratch || count < 0 || step < 1) return SBI_AMD_E_BADARG;
+  if (count == 0) return 0;
+  return adam_launch(params, grad, exp_avg, exp_avg_sq, count, step, lr, beta1, beta2, eps, max_norm, nullptr, 0, scratch,
+                     (hipStream_t)stream);
+}
+
+// The same step when the caller already holds partial sums of squares of `grad` (their sum = |grad|^2): the training
+// pass's gradient reduction leaves them in its workspace (sbi_amd_nsf_train_sqnorm_parts), which saves the norm launch.
+extern "C" int sbi_amd_adam_clip_step_parts(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                            int64_t count, int64_t step, float lr, float beta1, float beta2, float eps,
+                                            float max_norm, const float* sqnorm_parts, int64_t n_parts, float* scratch,
+                                            void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !scratch || !sqnorm_parts || n_parts < 1 || n_parts > (1 << 24) ||
+      count < 0 || step < 1)
+    return SBI_AMD_E_BADARG;
+  if (count == 0) return 0;
+  return adam_launch(params, grad, exp_avg, exp_avg_sq, count, step, lr, beta1, beta2, eps, max_norm, sqnorm_parts,
+                     n_parts, scratch, (hipStream_t)stream);
 }

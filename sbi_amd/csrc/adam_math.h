@@ -28,12 +28,22 @@ __device__ __forceinline__ float adam_apply_one(float p, float g, float& m, floa
   return __builtin_fmaf(-k.step_size, mi / denom, p);
 }
 
-// clip coefficient from the partial sums of squares (fixed order: deterministic); also returns the norm
-__device__ __forceinline__ float adam_clip_coef(const float* __restrict__ partials, int npart, float max_norm,
-                                                float* norm_out) {
+// clip coefficient from the partial sums of squares, computed by EVERY workgroup of the update kernel the same way
+// (fixed order: thread t sums parts t, t + 256, ...; then a fixed tree): deterministic, identical in all workgroups.
+// blockDim.x must be ADAM_BLOCK.  Also returns the norm.
+#define ADAM_BLOCK 256
+__device__ __forceinline__ float adam_clip_coef_block(const float* __restrict__ partials, int npart, float max_norm,
+                                                      float* norm_out) {
+  __shared__ float red[ADAM_BLOCK];
   float s = 0.f;
-  for (int i = 0; i < npart; ++i) s += partials[i];
-  const float norm = sqrtf(s);
+  for (int i = threadIdx.x; i < npart; i += ADAM_BLOCK) s += partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = ADAM_BLOCK / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const float norm = sqrtf(red[0]);
   *norm_out = norm;
   return max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;   // clip_grad_norm_
 }

@@ -94,6 +94,8 @@ static int co_dispatch_bwd(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, con
   return SBI_AMD_E_UNSUPPORTED;
 }
 
+// workgroups of nsf_coop_reduce_kernel = partial sums of squares it leaves behind the stash
+static inline int64_t co_sq_parts(const NsfPlan& pl, const CoopPlan& cp) { return (int64_t)((cp.PLP / 4 + 63) / 64) * pl.T; }
 // training workspace of the cooperative path: per-transform input state, z_T, log p, partial slabs, stash
 static int64_t co_ws_layout(const NsfPlan& pl, const CoopPlan& cp, int64_t n, int64_t* o_zst, int64_t* o_noise,
                             int64_t* o_logp, int64_t* o_part, int64_t* o_ast) {
@@ -105,12 +107,17 @@ static int64_t co_ws_layout(const NsfPlan& pl, const CoopPlan& cp, int64_t n, in
   *o_part = o; o += (int64_t)pl.T * cp.grid * cp.PLP;
   o = (o + 63) / 64 * 64;
   *o_ast = o; o += (int64_t)pl.T * ((n + 15) / 16) * cp.slots * 256;
+  o += (co_sq_parts(pl, cp) + 3) / 4 * 4;   // partial sums of squares of the reduced gradient (the clip's norm)
   o += 1024;   // debug timelines (SBI_AMD_TIMELINE): the last 512 int64 of the workspace
   return o;
 }
 int64_t coop_workspace_floats(const NsfPlan& pl, const CoopPlan& cp, int64_t n) {
   int64_t a, b, c, d, e;
   return co_ws_layout(pl, cp, n, &a, &b, &c, &d, &e);
+}
+const float* coop_sqnorm_parts(const NsfPlan& pl, const CoopPlan& cp, int64_t n, const float* workspace, int64_t* n_parts) {
+  if (n_parts) *n_parts = co_sq_parts(pl, cp);
+  return workspace + coop_workspace_floats(pl, cp, n) - 1024 - (co_sq_parts(pl, cp) + 3) / 4 * 4;
 }
 
 int coop_log_prob(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
@@ -186,7 +193,8 @@ int coop_train_backward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const 
   }
   hipLaunchKernelGGL(nsf_coop_reduce_kernel, dim3((cp.PLP / 4 + 63) / 64, pl.T), dim3(64 * CO_RED_GROUPS), 0,
                      (hipStream_t)stream, pl, cp, params, (const float*)(workspace + o_part), grad_out,
-                     (const float*)(workspace + o_logp), loss_out, (long long)n);
+                     (const float*)(workspace + o_logp), loss_out, (long long)n,
+                     workspace + ws_total - 1024 - (co_sq_parts(pl, cp) + 3) / 4 * 4);
   return (int)hipGetLastError();
 }
 

@@ -8,6 +8,7 @@ bool coop_shape_ok(const sbi_amd_nsf_config* cfg, NsfPlan* pl, CoopPlan* cp);
 int64_t coop_packed_floats(const sbi_amd_nsf_config* cfg);
 int coop_pack(const sbi_amd_nsf_config* cfg, const float* params, float* cimg, int which, void* stream);
 int64_t coop_workspace_floats(const NsfPlan& pl, const CoopPlan& cp, int64_t n);
+const float* coop_sqnorm_parts(const NsfPlan& pl, const CoopPlan& cp, int64_t n, const float* workspace, int64_t* n_parts);
 int coop_log_prob(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
                   const float* zstats, const float* theta, const float* x, int64_t n, int64_t x_rows, float* logp,
                   float* noise, void* stream);

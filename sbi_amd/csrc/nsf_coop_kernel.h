@@ -186,7 +186,7 @@ nsf_coop_pack_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restric
 __global__ void __launch_bounds__(64 * CO_RED_GROUPS)
 nsf_coop_reduce_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict__ params,
                        const float* __restrict__ partial, float* __restrict__ grad, const float* __restrict__ logp,
-                       float* __restrict__ loss_out, long long n_rows) {
+                       float* __restrict__ loss_out, long long n_rows, float* __restrict__ sq_out) {
   if (loss_out)
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_rows;
          i += (long long)gridDim.x * gridDim.y * blockDim.x)
@@ -245,23 +245,29 @@ nsf_coop_reduce_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restr
     if (lane == 0) red_sgl[grp] = sgl;
   }
   __syncthreads();
-  if (grp == 0 && live) {
-    f4 tot = {0.f, 0.f, 0.f, 0.f};
-    float tsg = 0.f;
+  if (grp == 0) {
+    float sq = 0.f;     // rider: this workgroup's share of |grad|^2 (the clip's norm: no separate pass over grad)
+    if (live) {
+      f4 tot = {0.f, 0.f, 0.f, 0.f};
+      float tsg = 0.f;
 #pragma unroll
-    for (int g = 0; g < CO_RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g]; }
+      for (int g = 0; g < CO_RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g]; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (li[r] < 0) continue;
-      const int idx = pl.g_layer[t] + li[r];
-      float v = tot[r];
-      if (li[r] >= S.g_lu + 2 * ntri && li[r] < S.g_lu + 2 * ntri + D) {
-        const float ud = params[idx];
-        const float uii = softplus_f(ud) + pl.lu_eps;
-        v = (v + tsg / uii) * (1.f / (1.f + expf(-ud)));
+      for (int r = 0; r < 4; ++r) {
+        if (li[r] < 0) continue;
+        const int idx = pl.g_layer[t] + li[r];
+        float v = tot[r];
+        if (li[r] >= S.g_lu + 2 * ntri && li[r] < S.g_lu + 2 * ntri + D) {
+          const float ud = params[idx];
+          const float uii = softplus_f(ud) + pl.lu_eps;
+          v = (v + tsg / uii) * (1.f / (1.f + expf(-ud)));
+        }
+        grad[idx] = v;
+        sq += v * v;
       }
-      grad[idx] = v;
     }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);     // fixed butterfly: deterministic
+    if (lane == 0 && sq_out) sq_out[blockIdx.y * gridDim.x + blockIdx.x] = sq;
   }
 }
 #endif

@@ -17,7 +17,8 @@
 __global__ void __launch_bounds__(64 * RED_GROUPS)
 nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __restrict__ params,
                        const float* __restrict__ partial, float* __restrict__ grad,
-                       const float* __restrict__ logp, float* __restrict__ loss_out, long long n_rows) {
+                       const float* __restrict__ logp, float* __restrict__ loss_out, long long n_rows,
+                       float* __restrict__ sq_out) {
   // rider (saves a launch per step): the per-row loss of the one-call form, loss = -log p
   if (loss_out)
     for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_rows;
@@ -54,23 +55,29 @@ nsf_grad_reduce_kernel(const NsfPlan pl, const TrainPlan tp, const float* __rest
     if (lane == 0) red_sgl[grp] = sgl;
   }
   __syncthreads();
-  if (grp == 0 && live) {
-    f4r tot = {0.f, 0.f, 0.f, 0.f};
-    float tsg = 0.f;
+  if (grp == 0) {
+    float sq = 0.f;     // second rider: this workgroup's share of |grad|^2 (the clip's norm: no separate pass over grad)
+    if (live) {
+      f4r tot = {0.f, 0.f, 0.f, 0.f};
+      float tsg = 0.f;
 #pragma unroll
-    for (int g = 0; g < RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g]; }
+      for (int g = 0; g < RED_GROUPS; ++g) { tot += red[g][lane]; tsg += red_sgl[g]; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (li + r >= S.n_params) continue;
-      const int idx = pl.g_layer[t] + li + r;
-      float v = tot[r];
-      if (!pl.ctx_mlp && li + r >= d0 && li + r < d0 + pl.D) {
-        const float ud = params[idx];
-        const float uii = softplus_f(ud) + pl.lu_eps;
-        v = (v + tsg / uii) * (1.f / (1.f + expf(-ud)));
+      for (int r = 0; r < 4; ++r) {
+        if (li + r >= S.n_params) continue;
+        const int idx = pl.g_layer[t] + li + r;
+        float v = tot[r];
+        if (!pl.ctx_mlp && li + r >= d0 && li + r < d0 + pl.D) {
+          const float ud = params[idx];
+          const float uii = softplus_f(ud) + pl.lu_eps;
+          v = (v + tsg / uii) * (1.f / (1.f + expf(-ud)));
+        }
+        grad[idx] = v;
+        sq += v * v;
       }
-      grad[idx] = v;
     }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);     // fixed butterfly: deterministic
+    if (lane == 0 && sq_out) sq_out[blockIdx.y * gridDim.x + blockIdx.x] = sq;
   }
 }
 
@@ -97,6 +104,8 @@ int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
                        float* z_stash, float* astash, void* stream);
 
+// workgroups of nsf_grad_reduce_kernel = partial sums of squares it leaves behind the activation stash
+static inline int64_t thr_sq_parts(const NsfPlan& pl, const TrainPlan& tp) { return (int64_t)((tp.PLP / 4 + 63) / 64) * pl.T; }
 static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int64_t* o_stash, int64_t* o_noise,
                          int64_t* o_logp, int64_t* o_gza, int64_t* o_gzb, int64_t* o_part, int64_t* o_ast) {
   int64_t o = 0;
@@ -110,6 +119,7 @@ static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int6
   o = (o + 3) / 4 * 4;
   *o_ast = o;   // activation stash: T x ceil(n/16) wave-tiles x slots x 1024 floats
   o += (int64_t)pl.T * ((n + 15) / 16) * nsf_ast_slots(pl) * 1024;
+  o += (thr_sq_parts(pl, tp) + 3) / 4 * 4;   // partial sums of squares of the reduced gradient (the clip's norm)
   o += 2048;   // debug timeline (SBI_AMD_TIMELINE): last 1024 int64 of the workspace
   return o;
 }
@@ -249,8 +259,9 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
     }
     if (rc) return rc;
   }
+  float* sq_out = workspace + ws_total - 2048 - (thr_sq_parts(pl, tp) + 3) / 4 * 4;
   hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((tp.PLP / 4 + 63) / 64, pl.T), dim3(64 * RED_GROUPS), 0, st, pl, tp,
-                     params, partial, grad_out, (const float*)(workspace + o_logp), loss_out, (long long)n);
+                     params, partial, grad_out, (const float*)(workspace + o_logp), loss_out, (long long)n, sq_out);
   return (int)hipGetLastError();
 }
 
@@ -276,4 +287,27 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
   if (rc) return rc;
   return train_backward_impl(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
                              grad_theta_out, grad_x_out, workspace, loss_out, stream);
+}
+
+// Where the gradient reduction of the last training pass of an n-row batch left the partial sums of squares of grad_out
+// (their sum = |grad_out|^2, what clip_grad_norm_ needs: sbi_amd_adam_clip_step_parts), and how many there are.
+// NULL / 0: that pass does not leave any (the generic training pass), the caller runs sbi_amd_adam_clip_step.
+extern "C" const float* sbi_amd_nsf_train_sqnorm_parts(const sbi_amd_nsf_config* cfg, int64_t n, const float* workspace,
+                                                       int64_t* n_parts) {
+  if (n_parts) *n_parts = 0;
+  if (!cfg || !workspace || n < 1) return nullptr;
+  NsfPlan pl;
+  {
+    CoopPlan cp;
+    if (coop_applies(cfg, n, true, &pl, &cp)) return coop_sqnorm_parts(pl, cp, n, workspace, n_parts);
+  }
+  int rc = nsf_build_plan(cfg, TR_NW, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return nullptr;
+  TrainPlan tp;
+  rc = build_train_plan(pl, n, &tp);
+  if (rc || fast_path_refuses(rc)) return nullptr;
+  int64_t a, b, c, d, e, f, g;
+  const int64_t ws_total = ws_layout(pl, tp, n, &a, &b, &c, &d, &e, &f, &g);
+  if (n_parts) *n_parts = thr_sq_parts(pl, tp);
+  return workspace + ws_total - 2048 - (thr_sq_parts(pl, tp) + 3) / 4 * 4;
 }

@@ -105,6 +105,7 @@ class FusedTrainStep:
         gb = global_batch if global_batch is not None else n * self.world
         x = self._embedded(x)
         losses, _ = self.net.train_pass(theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
+        self._grad_from_pass = True          # self.grad is exactly what the pass's reduction kernel wrote
         if self.distributed:
             all_reduce_sum(self.dist, self.grad, self.group)
         return losses
@@ -143,6 +144,7 @@ class FusedTrainStep:
             lpp = m * lp[0] + lpp
             w[0] += m
         train_backward(self.net, x, A * B, (w / gb).reshape(-1).contiguous(), self.grad, ws)
+        self._grad_from_pass = True
         if self.distributed:
             all_reduce_sum(self.dist, self.grad, self.group)
         return -lpp
@@ -203,6 +205,28 @@ class FusedTrainStep:
             return None
         return mask, packed, ent
 
+    def _norm_parts(self):
+        """(pointer, count) of the partial sums of squares of `self.grad` that the last NSF training pass's gradient
+        reduction left in the workspace (csrc/nsf_train.hip, a rider of the reduction kernel), or None: not an NSF net,
+        the pass leaves none (generic training pass), switched off (SBI_AMD_NORM_RIDER=0) -- or MORE THAN ONE rank: the
+        all-reduce changed the gradient, the norm has to be taken from the reduced one (`grad_sqnorm_partials`).  With
+        one rank the all-reduce is the identity, so the 1-rank RCCL run and the group-less run take the same path."""
+        import ctypes
+        import os
+
+        from sbi_amd.neural_nets.estimators.nsf_flow import NSFNet
+
+        rows = getattr(self, "_last_rows", None)
+        if (type(self.net) is not NSFNet or rows is None or self.world != 1 or self.workspace is None
+                or not getattr(self, "_grad_from_pass", False) or os.environ.get("SBI_AMD_NORM_RIDER", "1") == "0"):
+            return None
+        n_parts = ctypes.c_int64(0)
+        ptr = _lib.load().sbi_amd_nsf_train_sqnorm_parts(self.net.hyper.c_config(), int(rows), _lib.ptr(self.workspace),
+                                                         ctypes.byref(n_parts))
+        if not ptr or n_parts.value < 1:
+            return None
+        return ptr, int(n_parts.value)
+
     @torch.no_grad()
     def apply(self) -> None:
         """Fused clip_grad_norm_ + Adam on the flat buffers, then the table-driven re-pack of the image the next
@@ -212,12 +236,21 @@ class FusedTrainStep:
         dev = p.device
         tail = self._tail()
         self.step_count += 1
+        parts = self._norm_parts()
+        self._grad_from_pass = False         # (whoever changes self.grad by hand and calls apply() again gets the norm kernel)
         with torch.cuda.device(dev):
-            rc = lib.sbi_amd_adam_clip_step(
-                _lib.ptr(p.data), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                p.numel(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.clip,
-                _lib.ptr(self.scratch), _lib.current_stream(dev),
-            )
+            if parts is not None:      # |grad|^2 as partial sums the gradient reduction left in the workspace
+                rc = lib.sbi_amd_adam_clip_step_parts(
+                    _lib.ptr(p.data), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                    p.numel(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.clip,
+                    parts[0], parts[1], _lib.ptr(self.scratch), _lib.current_stream(dev),
+                )
+            else:
+                rc = lib.sbi_amd_adam_clip_step(
+                    _lib.ptr(p.data), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                    p.numel(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.clip,
+                    _lib.ptr(self.scratch), _lib.current_stream(dev),
+                )
         _lib.check(rc, "adam_clip_step")
         if tail is not None:
             mask, packed, mp = tail

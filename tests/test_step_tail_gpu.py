@@ -144,3 +144,87 @@ def test_step_map_refuses_what_it_cannot_verify():
         big_eps.lu_eps = 0.5        # the probe could not tell softplus(u) + eps from a copy any more: refused, not guessed
         assert lib.sbi_amd_nsf_build_step_map(big_eps, 1, _lib.ptr(p), _lib.ptr(img), _lib.ptr(mp), _lib.ptr(ws), st) == _lib.E_UNSUPPORTED
         assert lib.sbi_amd_nsf_table_pack(cfg, _lib.ptr(p), _lib.ptr(img), None, st) == _lib.E_BADARG
+
+
+# ---------------------------------------------------------------------------------------------- the norm rider
+@gpu
+@pytest.mark.parametrize("name,rows", [("default", 200), ("default", 8192), ("default", 20000), ("theta-dim-1", 300),
+                                       ("16-bins-hidden-64", 5000), ("wide-hidden-100", 700),
+                                       ("theta-dim-20-generic-pass", 400)])
+def test_gradient_reduction_leaves_the_squared_norm_of_the_gradient(name, rows):
+    """`sbi_amd_nsf_train_sqnorm_parts`: the partial sums the reduction kernels leave in the workspace add up to
+    |grad_out|^2 (what clip_grad_norm_ needs, trainers/base.py:1182-1186), and `sbi_amd_adam_clip_step_parts` takes the
+    step `sbi_amd_adam_clip_step` takes (same clip coefficient up to the association of the sum).  The generic training
+    pass leaves none and says so."""
+    import ctypes
+
+    from sbi_amd.neural_nets.estimators.nsf_flow import NSFNet, loss_fwd_bwd, train_workspace
+    from tests.helpers import linear_gaussian_data
+
+    lib = _lib.load()
+    kw = dict(SHAPES[name])
+    D, C = kw.pop("D"), kw.pop("C")
+    theta, x = linear_gaussian_data(max(rows, 64), D, C)
+    torch.manual_seed(2)
+    est = build_nsf(theta, x, **kw).cuda()
+    net = est.net
+    assert type(net) is NSFNet
+    th, xx = theta[:rows].cuda(), x[:rows].cuda()
+    grad = torch.zeros_like(net.flat_params.data)
+    ws = train_workspace(net, rows, th.device)
+    loss_fwd_bwd(net, th, xx, None, 37.0 / rows, grad, workspace=ws)       # a weight that makes the clip bite
+    n_parts = ctypes.c_int64(-1)
+    ptr = lib.sbi_amd_nsf_train_sqnorm_parts(net.hyper.c_config(), rows, _lib.ptr(ws), ctypes.byref(n_parts))
+    if name == "theta-dim-20-generic-pass":
+        assert not ptr and n_parts.value == 0
+        return
+    assert ptr and n_parts.value >= 1
+    off = (ptr - ws.data_ptr()) // 4
+    parts = ws[off:off + n_parts.value]
+    total = float(parts.double().sum())
+    want = float((grad.double() ** 2).sum())
+    assert abs(total - want) <= 2e-6 * want, (total, want)
+    assert want ** 0.5 > 5.0                                               # the clip IS active in this comparison
+    P = grad.numel()
+    outs = []
+    for use_parts in (True, False):
+        p = net.flat_params.data.clone()
+        m, v, s = torch.zeros_like(p), torch.zeros_like(p), torch.zeros(256, device=p.device)
+        with torch.cuda.device(p.device):
+            st = _lib.current_stream(p.device)
+            for step in (1, 2):
+                if use_parts:
+                    rc = lib.sbi_amd_adam_clip_step_parts(_lib.ptr(p), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), P, step, 5e-4,
+                                                          0.9, 0.999, 1e-8, 5.0, ptr, n_parts.value, _lib.ptr(s), st)
+                else:
+                    rc = lib.sbi_amd_adam_clip_step(_lib.ptr(p), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), P, step, 5e-4, 0.9,
+                                                    0.999, 1e-8, 5.0, _lib.ptr(s), st)
+                assert rc == 0
+        outs.append((p, m, v, float(s[0])))
+    assert abs(outs[0][3] - outs[1][3]) <= 1e-6 * outs[1][3] and abs(outs[1][3] - want ** 0.5) <= 1e-5 * want ** 0.5
+    # the two norms differ in the association of a float32 sum (up to ~1e-6 relative with a thousand partial sums), the
+    # clip coefficient with them, the second moment (quadratic in the scaled gradient) twice as much
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-10)
+
+
+@gpu
+@pytest.mark.parametrize("batch", [200, 20000])
+def test_training_with_the_norm_rider_is_deterministic_and_matches_the_norm_kernel(batch, monkeypatch):
+    torch.manual_seed(0)
+    theta = torch.randn(30000, 10)
+    x = theta + 0.3 * torch.randn(30000, 10)
+    runs = []
+    for flag in ("1", "1", "0"):
+        monkeypatch.setenv("SBI_AMD_NORM_RIDER", flag)
+        torch.manual_seed(1)
+        est = build_nsf(theta, x).cuda()
+        st = FusedTrainStep(est)
+        tb, xb = theta[:batch].cuda(), x[:batch].cuda()
+        losses = torch.stack([st.step(tb, xb).mean() for _ in range(6)])
+        norms = st.grad_norm().clone()
+        runs.append((est.net.flat_params.detach().clone(), losses, norms))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])      # run to run: bit-identical
+    assert torch.allclose(runs[0][0], runs[2][0], rtol=1e-5, atol=1e-7)                     # rider vs norm kernel
+    assert torch.allclose(runs[0][1], runs[2][1], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(runs[0][2], runs[2][2], rtol=1e-6)
