@@ -54,9 +54,14 @@ static int adam_launch(float* params, const float* grad, float* exp_avg, float* 
                        float lr, float beta1, float beta2, float eps, float max_norm, const float* parts, int64_t n_parts,
                        float* scratch, hipStream_t st) {
   static_assert(ADAM_THREADS == ADAM_BLOCK, "adam_clip_coef_block is written for the update kernel's workgroup size");
-  int nwg = (int)((count + ADAM_THREADS * 4 - 1) / (ADAM_THREADS * 4));
+  int nwg = (int)((count + ADAM_THREADS * 4 - 1) / (ADAM_THREADS * 4));     // norm kernel: <= ADAM_NWG partial sums (scratch)
   if (nwg > ADAM_NWG) nwg = ADAM_NWG;
   if (nwg < 1) nwg = 1;
+  // update kernel: one element per thread up to 512 workgroups (the kernel is a latency chain -- load, a dozen dependent
+  // flops, store -- per element a thread owns: 98 025 parameters over 96 workgroups were four such chains in a row)
+  int uwg = (int)((count + ADAM_THREADS - 1) / ADAM_THREADS);
+  if (uwg > 512) uwg = 512;
+  if (uwg < 1) uwg = 1;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   if (!parts) {     // the caller has no partial sums of squares of `grad`: one more launch makes them
@@ -64,7 +69,7 @@ static int adam_launch(float* params, const float* grad, float* exp_avg, float* 
     parts = scratch + 1;
     n_parts = nwg;
   }
-  hipLaunchKernelGGL(adam_update, dim3(nwg), dim3(ADAM_THREADS), 0, st, params, grad, exp_avg, exp_avg_sq,
+  hipLaunchKernelGGL(adam_update, dim3(uwg), dim3(ADAM_THREADS), 0, st, params, grad, exp_avg, exp_avg_sq,
                      (long long)count, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, parts, (int)n_parts,
                      scratch);
   return (int)hipGetLastError();

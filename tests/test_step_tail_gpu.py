@@ -204,8 +204,10 @@ def test_gradient_reduction_leaves_the_squared_norm_of_the_gradient(name, rows):
     assert abs(outs[0][3] - outs[1][3]) <= 1e-6 * outs[1][3] and abs(outs[1][3] - want ** 0.5) <= 1e-5 * want ** 0.5
     # the two norms differ in the association of a float32 sum (up to ~1e-6 relative with a thousand partial sums), the
     # clip coefficient with them, the second moment (quadratic in the scaled gradient) twice as much
-    for a, b in zip(outs[0][:3], outs[1][:3]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-10)
+    # (a parameter that an update of lr = 5e-4 carries across zero has no relative accuracy: absolute, in units of lr)
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=5e-4 * 1e-5)
+    for a, b in zip(outs[0][1:3], outs[1][1:3]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-12)
 
 
 @gpu
