@@ -175,8 +175,10 @@ class FusedTrainStep:
         packed = packed_weights(self.net, rows=int(rows), training=True)
         maps = self.__dict__.setdefault("_step_maps", {})
         key = (mask, packed.data_ptr(), self.net.flat_params.data_ptr())
-        ent = maps.get(key)
-        if ent is None:
+        for stale in [k for k in maps if k[1:] != key[1:]]:      # a moved / re-allocated buffer drops its tables
+            del maps[stale]
+        ent = maps.get(key)                                       # (at most one table per image: batch sizes on both
+        if ent is None:                                           #  sides of the kernel families' threshold keep two)
             dev = packed.device
             n_map = lib.sbi_amd_nsf_step_map_ints(cfg)
             n_ws = lib.sbi_amd_nsf_step_map_workspace_floats(cfg)
@@ -199,7 +201,6 @@ class FusedTrainStep:
                     _lib.check(rc, "nsf_build_step_map")
                     ent = mp
                 del ws
-            maps.clear()            # one (image, buffer) at a time: a moved / re-allocated buffer drops the old table
             maps[key] = ent
         if ent is False:
             return None

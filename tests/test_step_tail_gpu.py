@@ -111,7 +111,7 @@ def test_training_steps_with_and_without_the_table_pack_agree_bit_for_bit(batch,
         tb, xb = theta[:batch].cuda(), x[:batch].cuda()
         losses = [st.step(tb, xb).clone() for _ in range(4)]
         used = st.__dict__.get("_step_maps")
-        assert (used is not None and len(used) == 1) == (flag == "1")
+        assert (used is not None and len(used) == 1) == (flag == "1")      # one table: one image is trained on
         other = 20000 if batch <= 8192 else 200            # the other kernel family's image
         lp_other = est.log_prob(theta[:other].cuda(), x[:other].cuda())
         smp = est.sample_from_noise(torch.randn(64, 10, generator=torch.Generator().manual_seed(5)).cuda(), xb[:64])
