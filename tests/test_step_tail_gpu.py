@@ -230,3 +230,27 @@ def test_training_with_the_norm_rider_is_deterministic_and_matches_the_norm_kern
     assert torch.allclose(runs[0][0], runs[2][0], rtol=1e-5, atol=1e-7)                     # rider vs norm kernel
     assert torch.allclose(runs[0][1], runs[2][1], rtol=1e-5, atol=1e-6)
     assert torch.allclose(runs[0][2], runs[2][2], rtol=1e-6)
+
+
+@gpu
+def test_alternating_batch_sizes_keep_one_table_per_image(monkeypatch):
+    """Steps on both sides of the kernel families' threshold (200 rows: cooperative image, 20 000: throughput image) in
+    turn: two tables live side by side (no rebuild per step), every step re-packs the image it just made stale for the
+    NEXT reader through `packed_weights`, and the run is bit-identical to the one that re-packs with the pack kernels."""
+    torch.manual_seed(0)
+    theta = torch.randn(30000, 10)
+    x = theta + 0.3 * torch.randn(30000, 10)
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SBI_AMD_FUSED_TAIL", flag)
+        torch.manual_seed(1)
+        est = build_nsf(theta, x).cuda()
+        st = FusedTrainStep(est)
+        losses = []
+        for i in range(6):
+            b = 200 if i % 2 == 0 else 20000
+            losses.append(st.step(theta[:b].cuda(), x[:b].cuda()).mean())
+        if flag == "1":
+            assert sorted(k[0] for k in st._step_maps) == [1, 2]
+        runs[flag] = (est.net.flat_params.detach().clone(), torch.stack(losses))
+    assert torch.equal(runs["1"][0], runs["0"][0]) and torch.equal(runs["1"][1], runs["0"][1])
