@@ -39,6 +39,7 @@ def main() -> int:
 
     worst = 0.0
     for cfg in [dict(D=10, C=10), dict(D=2, C=2), dict(D=4, C=7, num_bins=8), dict(D=1, C=3),
+                dict(D=1, C=3, hidden_layers_spline_context=3),     # ContextSplineMap's one hidden Linear applied three times
                 dict(D=5, C=3, hidden_features=32, num_transforms=3),
                 dict(D=10, C=10, hidden_features=100)]:      # (hidden > 64: the wide kernels' oracle case)
         D, C = cfg.pop("D"), cfg.pop("C")
