@@ -62,7 +62,8 @@ typedef struct sbi_amd_nsf_config {
   float lu_eps;       /* LULinear eps, nflows default 1e-3 */
   int32_t ctx_layers; /* theta-dim 1 only (ContextSplineMap, flow.py:1419-1478): hidden_layers_spline_context, the number
                        * of times the ONE shared hidden Linear + ReLU is applied (flow.py:346; 1 ... 4); 0 is read as 1, so a
-                       * zero-initialised trailing field keeps the default; ignored for theta-dim >= 2 */
+                       * zero-initialised trailing field keeps the default; -1: no hidden layer (hidden_layers_spline_context
+                       * = 0: the flat buffer then holds no hidden Linear); ignored for theta-dim >= 2 */
 } sbi_amd_nsf_config;
 
 /* Number of floats in the flat parameter buffer for `cfg` (98 025 for the

@@ -152,7 +152,7 @@ __device__ __forceinline__ void pack_layer(float* __restrict__ img, const float*
     pack_linear(img, gl, S.lin[2 + 3 * b], hb, hb, hb, tid, nthreads);
     pack_linear(img, gl, S.lin[3 + 3 * b], hb, hb, hb, tid, nthreads);
   }
-  if (pl.ctx_mlp) pack_linear(img, gl, S.lin[1], hb, hb, hb, tid, nthreads);
+  if (pl.ctx_mlp && pl.ctx_reps > 0) pack_linear(img, gl, S.lin[1], hb, hb, hb, tid, nthreads);
   pack_linear(img, gl, S.lin[S.fin], S.d_tr * 16 * pl.PT, pl.P, 16 * pl.PT, tid, nthreads);
   if (!pl.ctx_mlp) pack_lu(img, gl, S, pl.D, pl.lu_eps, tid, nthreads);
   else for (int idx = S.l_U + tid; idx < S.l_lub + pl.D + 1; idx += nthreads) img[idx] = 0.f;

@@ -18,8 +18,8 @@ constexpr int nsf_check_cfg(const sbi_amd_nsf_config* c) {
     return SBI_AMD_E_UNSUPPORTED;
   if (c->D > 64 || c->C > 256) return SBI_AMD_E_UNSUPPORTED;
   if (c->min_bin_width * c->K > 1.0f || c->min_bin_height * c->K > 1.0f) return SBI_AMD_E_BADARG;
-  if (c->ctx_layers < 0) return SBI_AMD_E_BADARG;
-  if (c->D == 1 && c->ctx_layers > 4) return SBI_AMD_E_UNSUPPORTED;   // (0 = default 1; no hidden layer at all: not built)
+  if (c->ctx_layers < -1) return SBI_AMD_E_BADARG;                    // -1: no hidden layer at all; 0: the default (1)
+  if (c->D == 1 && c->ctx_layers > 4) return SBI_AMD_E_UNSUPPORTED;
   return 0;
 }
 
@@ -58,7 +58,7 @@ constexpr int nsf_build_layout(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* p
   const int ctx_mlp = (D == 1);
   const int NB = ctx_mlp ? 0 : cfg->NB;   // the context-only conditioner has no residual blocks
   pl->ctx_mlp = ctx_mlp;
-  pl->ctx_reps = ctx_mlp ? (cfg->ctx_layers > 0 ? cfg->ctx_layers : 1) : 0;
+  pl->ctx_reps = ctx_mlp ? (cfg->ctx_layers > 0 ? cfg->ctx_layers : (cfg->ctx_layers < 0 ? 0 : 1)) : 0;
   pl->D = D; pl->C = C; pl->H = H; pl->K = K; pl->T = T; pl->NB = NB;
   pl->P = 3 * K - 1;
   pl->PT = (pl->P + 15) / 16;
@@ -77,7 +77,7 @@ constexpr int nsf_build_layout(const sbi_amd_nsf_config* cfg, int nw, NsfPlan* p
     const int tr_rows = 4 * pl->KSH + 1;   // transposed (backward) K loops walk 4*KSH rows
     nsf_set_lin(&s->lin[0], &g, &l, H, s->in0, hb, 0, tr_rows);
     if (ctx_mlp) {
-      nsf_set_lin(&s->lin[1], &g, &l, H, H, hb, pl->KSH, tr_rows);
+      if (pl->ctx_reps > 0) nsf_set_lin(&s->lin[1], &g, &l, H, H, hb, pl->KSH, tr_rows);   // (none: lin[1] stays empty)
       s->fin = 2;
     } else {
       for (int b = 0; b < NB; ++b) {

@@ -644,7 +644,7 @@ __device__ __forceinline__ void write_bias(float* __restrict__ part, const LinDe
 }
 
 // ------------------------------------------------------------------ backward kernel
-__device__ __forceinline__ constexpr int cm_reps(const NsfPlan& pl) { return pl.ctx_reps > 0 ? pl.ctx_reps : 1; }
+__device__ __forceinline__ constexpr int cm_reps(const NsfPlan& pl) { return pl.ctx_reps; }   // (0: no hidden layer)
 // Wave specialisation, one workgroup = 64-row tile:
 //   waves 0-3 ("row" waves): 16 rows each.  Loads, LULinear backward, the spline forward + reverse
 //     mode (VALU), the row-wise backward through the residual blocks (transposed-weight MFMA GEMMs);
@@ -876,8 +876,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       // ---- step nch (the grad waves finish d Wf / Wf^T g of the last chunk): fetch the last block's
       // temporaries and do the LULinear forward piece its parameter gradients need, u = U y
       if (cm) {     // the last application's input and output: h_reps, h_{reps+1} (stash slots reps - 1, reps)
-        ast_load(ast, reps - 1, hpre[0]);
-        ast_load(ast, reps, hpre[1]);
+        ast_load(ast, reps > 0 ? reps - 1 : 0, hpre[0]);
+        if (reps > 0) ast_load(ast, reps, hpre[1]);
       } else {
         ast_load(ast, 2 + 4 * (NB - 1), bt2);
         ast_load(ast, 3 + 4 * (NB - 1), bsg);

@@ -50,7 +50,7 @@ class NSFHyper:
         return _lib.NSFConfigC(
             self.D, self.C, self.hidden_features, self.num_bins, self.num_transforms, self.num_blocks,
             self.tail_bound, self.min_bin_width, self.min_bin_height, self.min_derivative, self.lu_eps,
-            int(self.hidden_layers_spline_context) if self.D == 1 else 0,
+            (int(self.hidden_layers_spline_context) or -1) if self.D == 1 else 0,     # C side: 0 = default, -1 = none
         )
 
     # -- layout of the flat buffer (must agree with csrc/nsf_plan.cpp) -----------
@@ -76,8 +76,9 @@ class NSFHyper:
             # 2, 4, ..., 2 n (flow.py:1456-1462); it is stored once (under index 2), the output layer is index 2 + 2 n
             pre = "transform_net.spline_predictor."
             fin = 2 + 2 * self.hidden_layers_spline_context
-            return [(pre + "0.weight", (H, C)), (pre + "0.bias", (H,)), (pre + "2.weight", (H, H)),
-                    (pre + "2.bias", (H,)), (pre + f"{fin}.weight", (P, H)), (pre + f"{fin}.bias", (P,))]
+            hidden = [(pre + "2.weight", (H, H)), (pre + "2.bias", (H,))] if self.hidden_layers_spline_context > 0 else []
+            return [(pre + "0.weight", (H, C)), (pre + "0.bias", (H,))] + hidden + \
+                   [(pre + f"{fin}.weight", (P, H)), (pre + f"{fin}.bias", (P,))]
         out = [("transform_net.initial_layer.weight", (H, self.d_id(t) + C)),
                ("transform_net.initial_layer.bias", (H,))]
         for b in range(self.num_blocks):
@@ -137,6 +138,8 @@ class NSFNet(nn.Module):
             if h.ctx_mlp:
                 pre = "transform_net.spline_predictor."
                 mods[pre + "0"] = nn.Linear(h.C, h.hidden_features)
+                # (`[nn.Linear(H, H), nn.ReLU()] * 0` still CONSTRUCTS the Linear -- and draws its initial weights --
+                #  before the empty repetition discards it, flow.py:1457-1460: same generator order here)
                 mods[pre + "2"] = nn.Linear(h.hidden_features, h.hidden_features)
                 mods[pre + str(2 + 2 * h.hidden_layers_spline_context)] = nn.Linear(h.hidden_features, 3 * h.num_bins - 1)
                 for key, _shape in h.layer_entries(t):

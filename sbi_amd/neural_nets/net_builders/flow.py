@@ -104,10 +104,10 @@ def build_nsf(
     if dropout_probability != 0.0 or use_batch_norm:
         raise NotImplementedError("sbi_amd.build_nsf: dropout / batch norm are not implemented in the HIP path")
     x_numel = batch_x[0].numel()
-    if x_numel == 1 and not 1 <= int(hidden_layers_spline_context) <= 4:
+    if x_numel == 1 and not 0 <= int(hidden_layers_spline_context) <= 4:
         raise NotImplementedError(
             "sbi_amd.build_nsf: the 1-D theta conditioner (ContextSplineMap, flow.py:1419-1478) is implemented "
-            "for hidden_layers_spline_context = 1 ... 4 (applications of its one shared hidden layer); "
+            "for hidden_layers_spline_context = 0 ... 4 (applications of its one shared hidden layer); "
             f"got {hidden_layers_spline_context}."
         )
     D, C, zstats, zx, zy, embedding = _flow_inputs(batch_x, batch_y, z_score_x, z_score_y, embedding_net, "build_nsf")

@@ -55,7 +55,7 @@ def test_builder_rejects_what_the_hip_path_does_not_implement():
     theta, x = linear_gaussian_data(50, 4, 7)
     with pytest.raises(ValueError, match="transform_to_unconstrained"):
         build_nsf(theta, x, z_score_x="transform_to_unconstrained")
-    for bad in (0, 5):          # no hidden layer at all / more than four applications: not built
+    for bad in (-1, 5):         # more than four applications of the shared hidden layer: not built
         with pytest.raises(NotImplementedError):
             build_nsf(theta[:, :1], x, hidden_layers_spline_context=bad)
     assert build_nsf(theta[:, :1], x).net.hyper.ctx_mlp

@@ -44,6 +44,7 @@ CONFIGS = [
     dict(D=1, C=3),                                     # ContextSplineMap conditioner (flow.py:401-408)
     dict(D=1, C=7, hidden_features=32, num_transforms=3),
     dict(D=1, C=3, hidden_layers_spline_context=3),     # the ONE hidden Linear applied three times (flow.py:1456-1462)
+    dict(D=1, C=4, hidden_layers_spline_context=0, num_transforms=3),   # ... and not at all
 ]
 
 
@@ -107,7 +108,7 @@ def test_log_prob_matches_oracle(cfg):
     _assert_as_accurate_as_fp32_reference(got, ref, ref64, "stress log_prob", ("log_prob", _ids(cfg)))
 
 
-@pytest.mark.parametrize("cfg", CONFIGS[:5] + CONFIGS[-3:], ids=_ids)
+@pytest.mark.parametrize("cfg", CONFIGS[:5] + CONFIGS[-4:], ids=_ids)
 def test_sample_matches_oracle(cfg):
     """`sample` parity = parity of transform^-1(noise | x) for GIVEN noise (DESIGN.md RNG)."""
     oracle, est, _, x_d = matched_pair(**cfg)

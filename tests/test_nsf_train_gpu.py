@@ -43,6 +43,7 @@ CONFIGS = [
     dict(D=1, C=3),
     dict(D=1, C=3, hidden_layers_spline_context=2),     # ContextSplineMap's one hidden Linear applied twice / four times:
     dict(D=1, C=5, hidden_layers_spline_context=4, num_transforms=2),   # its gradient sums over the applications
+    dict(D=1, C=3, hidden_layers_spline_context=0),     # no hidden layer at all
     # shapes whose weight image only fits LDS in the backward kernel's overlay mode (final layer + LU and the
     # hidden layers take turns in one region)
     dict(D=12, C=10, num_transforms=2),
