@@ -99,7 +99,8 @@ class FusedTrainStep:
     @torch.no_grad()
     def loss_and_grad(self, theta: Tensor, x: Tensor, global_batch: Optional[int] = None) -> Tensor:
         """Per-row losses (device tensor); leaves d(mean loss)/d(params) in ``self.grad``
-        (summed over ranks when distributed)."""
+        (summed over ranks when distributed).  Whoever changes ``self.grad`` between this call and ``apply()`` calls
+        ``grad_modified()`` (the clip's norm otherwise comes from partial sums of the pass's own reduction)."""
         n = theta.shape[0]
         self._last_rows = n
         gb = global_batch if global_batch is not None else n * self.world
@@ -205,6 +206,12 @@ class FusedTrainStep:
         if ent is False:
             return None
         return mask, packed, ent
+
+    def grad_modified(self) -> None:
+        """Tell the stepper that `self.grad` is no longer what the last training pass wrote (the caller scaled it,
+        accumulated into it, ...): the next `apply()` takes |grad|^2 from the gradient itself instead of from the
+        partial sums the pass's reduction kernel left behind."""
+        self._grad_from_pass = False
 
     def _norm_parts(self):
         """(pointer, count) of the partial sums of squares of `self.grad` that the last NSF training pass's gradient

@@ -254,3 +254,23 @@ def test_alternating_batch_sizes_keep_one_table_per_image(monkeypatch):
             assert sorted(k[0] for k in st._step_maps) == [1, 2]
         runs[flag] = (est.net.flat_params.detach().clone(), torch.stack(losses))
     assert torch.equal(runs["1"][0], runs["0"][0]) and torch.equal(runs["1"][1], runs["0"][1])
+
+
+@gpu
+def test_a_gradient_changed_by_hand_gets_its_norm_from_the_gradient_itself():
+    torch.manual_seed(0)
+    theta = torch.randn(4000, 10)
+    x = theta + 0.3 * torch.randn(4000, 10)
+    est = build_nsf(theta, x).cuda()
+    st = FusedTrainStep(est)
+    tb, xb = theta[:512].cuda(), x[:512].cuda()
+    st.loss_and_grad(tb, xb)
+    want = float(st.grad.double().norm())
+    st.apply()
+    assert abs(float(st.grad_norm()) - want) <= 1e-5 * want            # rider: the pass's own partial sums
+    st.loss_and_grad(tb, xb)
+    st.grad.mul_(3.0)
+    st.grad_modified()
+    want3 = float(st.grad.double().norm())
+    st.apply()
+    assert abs(float(st.grad_norm()) - want3) <= 1e-5 * want3          # norm kernel over the modified gradient
