@@ -441,6 +441,8 @@ class PosteriorEstimatorTrainer:
 
             return rank_window(lo, count, rank, world)
 
+        host_ring = []       # filled below once `pipelined` is known (pinned float32 pairs: train / validation loss sums)
+
         def launch_epoch(e: int) -> dict:
             """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here
             waits for the device.  Returns the record `finish_epoch` turns into the epoch's host bookkeeping."""
@@ -474,7 +476,11 @@ class PosteriorEstimatorTrainer:
             if d is not None:
                 all_reduce_sum(d, sums)
             if pipelined:
-                rec["host"] = torch.empty(2, dtype=sums.dtype, pin_memory=True)
+                # one of four pinned read-back buffers allocated once per train() call: at most three epoch records
+                # are alive at a time (finishing, in flight, speculative).  A fresh `torch.empty(pin_memory=True)` per
+                # epoch goes to hipHostMalloc whenever the pinned-block cache has no block whose last use has provably
+                # finished -- a third of a millisecond, on whichever epochs lose that race
+                rec["host"] = host_ring[e % len(host_ring)]
                 rec["host"].copy_(sums, non_blocking=True)
                 rec["event"] = torch.cuda.Event(enable_timing=True)
                 rec["event"].record()
@@ -484,7 +490,16 @@ class PosteriorEstimatorTrainer:
 
         def finish_epoch(rec: dict) -> None:
             if "event" in rec:
-                rec["event"].synchronize()
+                # Poll instead of `synchronize()`: the blocking wait goes to sleep on the completion signal and, on some
+                # hosts of the pool, wakes up several hundred microseconds after it fired -- with one epoch of ~1 ms in
+                # flight behind this one that is enough for the device to run dry (measured through bench.py's npe_train
+                # leg: 1.35 - 1.38 ms per epoch on two boxes, 1.00 on two others, with IDENTICAL per-launch enqueue
+                # times).  The loop spins for at most the remainder of one epoch.  SBI_AMD_EVENT_SPIN=0: the blocking wait.
+                if _os.environ.get("SBI_AMD_EVENT_SPIN", "1") != "0":
+                    while not rec["event"].query():
+                        pass
+                else:
+                    rec["event"].synchronize()
             host = rec["host"]
             if not torch.isfinite(host).all():
                 if "event" in rec and last_good["snap"] is not None:
@@ -521,6 +536,8 @@ class PosteriorEstimatorTrainer:
         #  * `epoch_durations_sec` are device times between events around an epoch's own launches (the host clock
         #    would include the next epoch's enqueue).
         pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"
+        if pipelined:
+            host_ring.extend(torch.empty(2, dtype=torch.float32, pin_memory=True) for _ in range(4))
         last_good = {"snap": None}
         if not pipelined:
             while self.epoch <= cfg.max_num_epochs and not self._converged(self.epoch, cfg.stop_after_epochs):
