@@ -37,85 +37,64 @@ def assert_transform_to_unconstrained_supported(z_score_x: Optional[str], builde
 
 
 def handle_invalid_x(x: Tensor, exclude_invalid_x: bool = True) -> Tuple[Tensor, int, int]:
-    """Rows with NaN / Inf -> (is_valid mask, num_nans, num_infs) (sbiutils.py:491-525)."""
-    batch = x.reshape(x.shape[0], -1)
-    x_is_nan = torch.isnan(batch).any(dim=1)
-    x_is_inf = torch.isinf(batch).any(dim=1)
-    num_nans = int(x_is_nan.sum().item())
-    num_infs = int(x_is_inf.sum().item())
-    if exclude_invalid_x:
-        is_valid = ~x_is_nan & ~x_is_inf
-    else:
-        is_valid = torch.ones(batch.shape[0], dtype=torch.bool, device=x.device)
-    return is_valid, num_nans, num_infs
+    """-> (mask of rows to keep, number of rows with a NaN, number of rows with an Inf); behaviour of
+    sbiutils.py:491-525.  One pass over the flattened rows; both counts leave the device in one read."""
+    rows = x.reshape(len(x), -1)
+    has_nan = rows.isnan().any(1)
+    has_inf = rows.isinf().any(1)
+    counts = torch.stack([has_nan.sum(), has_inf.sum()]).tolist()
+    keep = ~(has_nan | has_inf) if exclude_invalid_x else torch.ones_like(has_nan)
+    return keep, int(counts[0]), int(counts[1])
 
 
 def warn_on_invalid_x(num_nans: int, num_infs: int, exclude_invalid_x: bool) -> None:
-    if num_nans + num_infs > 0:
-        if exclude_invalid_x:
-            logging.warning(
-                f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. They will be excluded "
-                "from training."
-            )
-        else:
-            logging.warning(
-                f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. Training might fail."
-            )
+    if num_nans == 0 and num_infs == 0:
+        return
+    consequence = "They will be excluded from training." if exclude_invalid_x else "Training might fail."
+    logging.warning(f"Found {num_nans} NaN simulations and {num_infs} Inf simulations. {consequence}")
+
+
+def _location_scale(rows: Tensor, structured: bool, floor: float):
+    """Per-dimension (independent) or single (structured: one mean over everything, the average of the per-row
+    standard deviations) location / scale of the finite rows, scale floored at `floor`."""
+    if structured:
+        return rows.mean(), torch.clamp_min(rows.std(dim=1), floor).mean()
+    return rows.mean(dim=0), torch.clamp_min(rows.std(dim=0), floor)
 
 
 def z_standardization(batch_t: Tensor, structured_dims: bool = False, min_std: float = 1e-14):
-    """Mean / std used to z-score theta (sbiutils.py:376-415)."""
-    is_valid_t, *_ = handle_invalid_x(batch_t, True)
-    t = batch_t[is_valid_t]
-    if structured_dims:
-        t_mean = torch.mean(t)
-        sample_std = torch.std(t, dim=1)
-        sample_std[sample_std < min_std] = min_std
-        t_std = torch.mean(sample_std)
-    else:
-        t_mean = torch.mean(t, dim=0)
-        t_std = torch.std(t, dim=0)
-        t_std[t_std < min_std] = min_std
-    return t_mean, t_std
+    """Mean / std used to z-score theta (sbiutils.py:376-415; golden: tests/golden/reference_intree.pt)."""
+    keep = handle_invalid_x(batch_t, True)[0]
+    return _location_scale(batch_t[keep], structured_dims, min_std)
 
 
 def standardizing_stats(batch_t: Tensor, structured_dims: bool = False, min_std: float = 1e-7):
-    """Mean / std of the ``Standardize`` layer prepended to the x embedding
-    (sbiutils.py:431-488, incl. the single-row special case)."""
-    is_valid_t, *_ = handle_invalid_x(batch_t, True)
-    t = batch_t[is_valid_t]
-    t_mean = torch.mean(t) if structured_dims else torch.mean(t, dim=0)
+    """Mean / std of the ``Standardize`` layer in front of the x embedding (sbiutils.py:431-488; a single-row
+    batch gets std 1 and a warning, NaN statistics are refused)."""
+    keep = handle_invalid_x(batch_t, True)[0]
     if len(batch_t) > 1:
-        if structured_dims:
-            sample_std = torch.std(t, dim=1)
-            sample_std[sample_std < min_std] = min_std
-            t_std = torch.mean(sample_std)
-        else:
-            t_std = torch.std(t, dim=0)
-            t_std[t_std < min_std] = min_std
+        t_mean, t_std = _location_scale(batch_t[keep], structured_dims, min_std)
     else:
+        t_mean = _location_scale(batch_t[keep], structured_dims, min_std)[0]
         t_std = torch.ones(1)
-        logging.warning(
-            "Using a one-dimensional batch will instantiate a Standardize transform with (mean, std) "
-            "parameters which are not representative of the data."
-        )
-    if torch.isnan(t_mean).any() or torch.isnan(t_std).any():
-        raise AssertionError(
-            "Training data mean or std for standardizing net must not contain NaNs. In case you are "
-            "encoding missing trials with NaNs, consider setting z_score_x='none' to disable z-scoring."
-        )
+        logging.warning("Using a one-dimensional batch will instantiate a Standardize transform with (mean, std) "
+                        "parameters which are not representative of the data.")
+    if bool(torch.isnan(t_mean).any() | torch.isnan(t_std).any()):
+        raise AssertionError("Training data mean or std for standardizing net must not contain NaNs. In case you "
+                             "are encoding missing trials with NaNs, consider setting z_score_x='none' to disable "
+                             "z-scoring.")
     return t_mean, t_std
 
 
 def within_support(distribution, samples: Tensor) -> Tensor:
-    """Boolean mask of samples inside the prior support (sbiutils.py:729-766)."""
+    """Boolean mask of the rows of `samples` inside `distribution`'s support (sbiutils.py:729-766): the support's
+    own check, reduced over the event dimension when it answers per coordinate; distributions without a usable
+    support fall back to "log_prob is finite"."""
     try:
-        sample_check = distribution.support.check(samples)
-        if sample_check.shape == samples.shape:
-            sample_check = torch.all(sample_check, dim=-1)
-        return sample_check
+        inside = distribution.support.check(samples)
     except (NotImplementedError, AttributeError):
-        return torch.isfinite(distribution.log_prob(samples))
+        return distribution.log_prob(samples).isfinite()
+    return inside.all(dim=-1) if inside.shape == samples.shape else inside
 
 
 def warn_if_outside_prior_support(prior, samples: Tensor) -> None:
@@ -128,114 +107,136 @@ def warn_if_outside_prior_support(prior, samples: Tensor) -> None:
         )
 
 
+class _Standardise:
+    """Builds the affine map used for unbounded priors: location / scale from the prior's moments, or from
+    `n_draws` prior draws when the prior does not publish them."""
+
+    def __init__(self, prior, n_draws: int, device):
+        self.prior, self.n_draws, self.device = prior, n_draws, device
+
+    def moments(self):
+        try:
+            return self.prior.mean.to(self.device), self.prior.stddev.to(self.device)
+        except (NotImplementedError, AttributeError):
+            warnings.warn("The passed prior has no mean or stddev attribute, estimating them from samples to "
+                          "build affine standardizing transform.", stacklevel=3)
+            draws = self.prior.sample(torch.Size((self.n_draws,)))
+            return draws.mean(dim=0).to(self.device), draws.std(dim=0).to(self.device)
+
+    def __call__(self):
+        from torch.distributions.transforms import AffineTransform
+
+        loc, scale = self.moments()
+        return AffineTransform(loc=loc, scale=scale)
+
+
+def _support_or_none(prior):
+    try:
+        return prior.support
+    except (NotImplementedError, AttributeError):
+        warnings.warn("The passed prior has no support property, transform will be constructed from mean and "
+                      "std. If the passed prior is supposed to be bounded consider implementing the "
+                      "prior.support property.", stacklevel=3)
+        return None
+
+
 def mcmc_transform(prior, num_prior_samples_for_zscoring: int = 1000, enable_transform: bool = True,
                    device="cpu", **kwargs):
-    """Transform applied to parameters during MCMC (sbiutils.py:867-980): bounded supports are mapped to
-    unbounded space with `biject_to`, unbounded ones are z-scored with the prior's mean / std.  The returned
-    transform's forward maps constrained -> unconstrained."""
-    import torch.distributions.transforms as torch_tf
+    """The parameter transform MCMC / MAP / rejection sampling work in (behaviour of sbi/utils/sbiutils.py:867-980,
+    pinned by tests/golden/mcmc_reference.pt and tests/test_mcmc_cpu.py).  Decision table:
+
+    ==============================================  =========================================
+    prior                                            constrained -> unconstrained map
+    ==============================================  =========================================
+    `enable_transform=False`                         identity
+    no `.support`, real or discrete support          z-scoring with the prior's mean / std
+    any other (bounded) support                      `biject_to(support)` inverted
+    ==============================================  =========================================
+
+    The result always has event dim 1 and its FORWARD direction maps constrained -> unconstrained."""
     from torch.distributions import biject_to, constraints
+    from torch.distributions.transforms import IndependentTransform, identity_transform
 
+    to_constrained = identity_transform
     if enable_transform:
-        def prior_mean_std_transform():
-            try:
-                prior_mean, prior_std = prior.mean.to(device), prior.stddev.to(device)
-            except (NotImplementedError, AttributeError):
-                warnings.warn("The passed prior has no mean or stddev attribute, estimating them from samples to "
-                              "build affine standardizing transform.", stacklevel=2)
-                th = prior.sample(torch.Size((num_prior_samples_for_zscoring,)))
-                prior_mean, prior_std = th.mean(dim=0).to(device), th.std(dim=0).to(device)
-            return torch_tf.AffineTransform(loc=prior_mean, scale=prior_std)
-
-        try:
-            _ = prior.support
-            has_support = True
-        except (NotImplementedError, AttributeError):
-            warnings.warn("The passed prior has no support property, transform will be constructed from mean and "
-                          "std. If the passed prior is supposed to be bounded consider implementing the "
-                          "prior.support property.", stacklevel=2)
-            has_support = False
-        if has_support:
-            constraint = prior.support.base_constraint if hasattr(prior.support, "base_constraint") else prior.support
-            if getattr(prior.support, "is_discrete", False) or isinstance(constraint, constraints._Real):
-                transform = prior_mean_std_transform()
-            else:
-                transform = biject_to(prior.support)
-        else:
-            transform = prior_mean_std_transform()
-    else:
-        transform = torch_tf.identity_transform
-    if not isinstance(transform, torch_tf.IndependentTransform):
-        transform = torch_tf.IndependentTransform(transform, reinterpreted_batch_ndims=1)
-    check_transform(prior, transform)
-    return transform.inv
+        support = _support_or_none(prior)
+        bounded = False
+        if support is not None:
+            innermost = getattr(support, "base_constraint", support)
+            bounded = not (getattr(support, "is_discrete", False) or isinstance(innermost, constraints._Real))
+        to_constrained = biject_to(support) if bounded else _Standardise(prior, num_prior_samples_for_zscoring, device)()
+    if not isinstance(to_constrained, IndependentTransform):
+        to_constrained = IndependentTransform(to_constrained, reinterpreted_batch_ndims=1)
+    check_transform(prior, to_constrained)
+    return to_constrained.inv
 
 
 def check_transform(prior, transform, atol: float = 1e-3) -> None:
-    """sbiutils.py:983-1003."""
+    """Round trip of two prior points through `transform` (unconstrained -> constrained direction) must keep the
+    shape and reproduce the points (sbiutils.py:983-1003)."""
     try:
-        theta = prior.sample(torch.Size((2,)))
+        probe = prior.sample(torch.Size((2,)))
     except NotImplementedError:
-        theta = prior.mean.repeat(2, *[1] * prior.mean.dim())
-    theta_unconstrained = transform.inv(theta)
-    assert theta_unconstrained.shape == theta.shape, (
-        "Mismatch between transformed and untransformed space. Note that you cannot use a transforms when using a "
-        "MultipleIndependent prior with a Dirichlet prior.")
-    assert torch.allclose(theta, transform(theta_unconstrained), atol=atol), \
-        "Original and re-transformed parameters must be close to each other."
+        probe = torch.stack([prior.mean, prior.mean])
+    back = transform.inv(probe)
+    if back.shape != probe.shape:
+        raise AssertionError("Mismatch between transformed and untransformed space. Note that you cannot use a "
+                             "transforms when using a MultipleIndependent prior with a Dirichlet prior.")
+    if not torch.allclose(probe, transform(back), atol=atol):
+        raise AssertionError("Original and re-transformed parameters must be close to each other.")
+
+
+class _Incumbent:
+    """Best point seen so far, kept in CONSTRAINED coordinates together with its potential value."""
+
+    def __init__(self, theta: Tensor, value: Tensor):
+        self.theta, self.value = theta.detach().clone(), value.detach().clone()
+
+    def offer(self, theta: Tensor, value: Tensor) -> None:
+        if bool(value > self.value):
+            self.theta, self.value = theta.detach().clone(), value.detach().clone()
 
 
 def gradient_ascent(potential_fn: Callable, inits: Tensor, theta_transform=None, num_iter: int = 1_000,
                     num_to_optimize: int = 100, learning_rate: float = 0.01, save_best_every: int = 10,
                     show_progress_bars: bool = False, interruption_note: str = "") -> Tuple[Tensor, Tensor]:
-    """`argmax` and `max` of `potential_fn` by Adam ascent in the unconstrained space of `theta_transform`, started
-    from the `num_to_optimize` best of `inits` (sbi/utils/sbiutils.py:1160-1286: same selection, optimizer, the
-    best-so-far bookkeeping every `save_best_every` iterations, Ctrl-C returns the current best).  With an NSF
-    estimator on a ROCm device every evaluation is one launch of the batched log_prob kernel and every gradient the
-    fused backward pass (d log_prob / d theta)."""
-    import torch.distributions.transforms as torch_tf
-
+    """(argmax, max) of `potential_fn` by Adam ascent (behaviour of sbi/utils/sbiutils.py:1160-1286, pinned by
+    tests/golden/rejection_reference.pt): the `num_to_optimize` highest-potential rows of `inits` are moved to the
+    unconstrained side of `theta_transform` and ascended jointly (the summed potential is the objective, so the rows
+    do not interact); after iterations 0, `save_best_every`, 2 `save_best_every`, ... and after the last one the
+    current front-runner challenges the incumbent.  Ctrl-C returns the incumbent.  One deliberate difference: the
+    incumbent is stored in constrained coordinates throughout, so when no iteration ever beats the best initial
+    point that point is returned as it is (the reference would push it through the inverse transform a second
+    time).  With an NSF estimator on a ROCm device every evaluation is one launch of the batched log_prob kernel and
+    every gradient one fused backward pass (d log_prob / d theta)."""
     if theta_transform is None:
-        theta_transform = torch_tf.IndependentTransform(torch_tf.identity_transform, reinterpreted_batch_ndims=1)
-    init_probs = potential_fn(inits).detach()
-    inits = inits.to(init_probs.device)
-    sort_indices = torch.argsort(init_probs, dim=0)
-    sorted_inits = inits[sort_indices]
-    optimize_inits = sorted_inits[-num_to_optimize:]
-    best_log_prob_iter = torch.max(init_probs)
-    best_theta_iter = sorted_inits[-1]
-    best_theta_overall = best_theta_iter.detach().clone()
-    best_log_prob_overall = best_log_prob_iter.detach().clone()
-    argmax_, max_val = best_theta_overall, best_log_prob_overall
-    # NOTE (as in the reference): `best_theta_overall` starts in constrained space and is replaced by
-    # unconstrained-space points once an iteration improves on it; the return maps it back with `.inv`
-    optimize_inits = theta_transform(optimize_inits).detach().clone()
-    optimize_inits.requires_grad_(True)
-    optimizer = torch.optim.Adam([optimize_inits], lr=learning_rate)
-    iter_ = 0
+        to_constrained = lambda u: u     # noqa: E731
+        to_unconstrained = to_constrained
+    else:
+        to_constrained, to_unconstrained = theta_transform.inv, theta_transform
+
+    start_values = potential_fn(inits).detach()
+    inits = inits.to(start_values.device)
+    ranking = torch.argsort(start_values, dim=0)                   # ascending, as the golden run's tie order
+    incumbent = _Incumbent(inits[ranking[-1]], start_values.max())
+    points = to_unconstrained(inits[ranking[-num_to_optimize:]]).detach().clone().requires_grad_(True)
+    adam = torch.optim.Adam([points], lr=learning_rate)
+    checkpoints = set(range(0, num_iter, save_best_every)) | {num_iter - 1}
+    done = 0
     try:
-        while iter_ < num_iter:
-            optimizer.zero_grad()
-            probs = potential_fn(theta_transform.inv(optimize_inits)).squeeze()
-            (-probs.sum()).backward()
-            optimizer.step()
-            with torch.no_grad():
-                if iter_ % save_best_every == 0 or iter_ == num_iter - 1:
-                    log_probs_of_optimized = potential_fn(theta_transform.inv(optimize_inits))
-                    best_theta_iter = optimize_inits[torch.argmax(log_probs_of_optimized)].unsqueeze(0)
-                    best_log_prob_iter = potential_fn(theta_transform.inv(best_theta_iter))
-                    if best_log_prob_iter > best_log_prob_overall:
-                        best_theta_overall = best_theta_iter.detach().clone()
-                        best_log_prob_overall = best_log_prob_iter.detach().clone()
-                if show_progress_bars:
-                    print("\r", f"Optimizing MAP estimate. Iterations: {iter_ + 1} / {num_iter}. Performance in "
-                          f"iteration {divmod(iter_ + 1, save_best_every)[0] * save_best_every}: "
-                          f"{best_log_prob_iter.item():.2f} (= unnormalized log-prob). Press Ctrl-C to interrupt.",
-                          end="")
-                argmax_ = theta_transform.inv(best_theta_overall)
-                max_val = best_log_prob_overall
-            iter_ += 1
+        for done in range(num_iter):
+            adam.zero_grad()
+            objective = potential_fn(to_constrained(points)).squeeze().sum()
+            (-objective).backward()
+            adam.step()
+            if done in checkpoints:
+                with torch.no_grad():
+                    values = potential_fn(to_constrained(points))
+                    leader = to_constrained(points[torch.argmax(values)].unsqueeze(0))
+                    incumbent.offer(leader, potential_fn(leader))
+            if show_progress_bars:
+                print(f"\rMAP search {done + 1}/{num_iter}: best unnormalized log-prob {float(incumbent.value):.2f} "
+                      "(Ctrl-C stops and keeps it)", end="")
     except KeyboardInterrupt:
-        print(f"Optimization was interrupted after {iter_} iterations. " + interruption_note)
-        return argmax_, max_val
-    return theta_transform.inv(best_theta_overall), max_val
+        print(f"Optimization was interrupted after {done} iterations. " + interruption_note)
+    return incumbent.theta, incumbent.value
