@@ -329,11 +329,11 @@ class MAFRQSFlow(NSFFlow):
             raise NotImplementedError("sbi_amd maf_rqs: trainable embedding nets are not supported (frozen / "
                                       "parameter-free ones are applied in front of the kernels)")
 
-    def _kernel_log_prob(self, theta: Tensor, x: Tensor, want_noise: bool):
-        return maf_log_prob_call(self.net, theta, x, want_noise)
+    def _raw_log_prob(self, net, theta: Tensor, x: Tensor, want_noise: bool):
+        return maf_log_prob_call(net, theta, x, want_noise)
 
-    def _kernel_sample(self, noise: Tensor, x: Tensor, want_ld: bool):
-        return maf_sample_call(self.net, noise, x, want_ld)
+    def _raw_sample(self, net, noise: Tensor, x: Tensor, want_ld: bool):
+        return maf_sample_call(net, noise, x, want_ld)
 
-    def _autograd_log_prob(self, theta: Tensor, x: Tensor) -> Tensor:
-        return _MAFLogProbFn.apply(theta, x, self.net.flat_params, self.net)
+    def _raw_autograd(self, net, theta: Tensor, x: Tensor, flat: Tensor) -> Tensor:
+        return _MAFLogProbFn.apply(theta, x, flat, net)

@@ -473,15 +473,76 @@ class NSFFlow(ConditionalDensityEstimator):
         e = self._embedding_net(condition.reshape(-1, *self.condition_shape).float())
         return e.reshape(*lead, self._cdim)
 
-    # -- kernel hooks (overridden by the maf_rqs estimator, which binds its own C entry points) -----
+    # -- kernel hooks (the maf_rqs / zuko estimators bind their own C entry points in the `_raw_*` three) -----
+    def _raw_log_prob(self, net, theta: Tensor, x: Tensor, want_noise: bool):
+        return _log_prob_call(net, theta, x, want_noise)
+
+    def _raw_sample(self, net, noise: Tensor, x: Tensor, want_ld: bool):
+        return _sample_call(net, noise, x, want_ld)
+
+    def _raw_autograd(self, net, theta: Tensor, x: Tensor, flat: Tensor) -> Tensor:
+        return _NSFLogProbFn.apply(theta, x, flat, net)
+
+    # -- host residency: a CPU-resident estimator answers through the current ROCm device ------------------------
+    def _kernel_net(self):
+        """The net whose buffers the kernels read: `self.net` when it lives on a ROCm device; for a CPU-resident
+        estimator (sbi builds on the CPU and probes `log_prob` there before `.to(device)`:
+        npe_base.py:694-703, user_input_checks.py:767-795) a device mirror of its 392 KB of parameters and z-score
+        buffers, refreshed whenever the host tensors changed.  The arithmetic is the HIP kernels' either way --
+        there is no CPU implementation to fall back to, so without a ROCm device this raises."""
+        fp = self.net.flat_params
+        if fp.is_cuda:
+            self.__dict__.pop("_mirror", None)
+            return self.net
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "sbi_amd: the NSF hot path runs only on a ROCm device (MI355X) and none is visible; a CPU-resident "
+                "estimator is evaluated by staging through the device. There is deliberately no CPU fallback.")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        key = (fp.data_ptr(), fp._version, self.net.zstats._version, dev.index)
+        held = self.__dict__.get("_mirror")
+        if held is None or held[1].flat_params.device != dev:
+            import copy
+
+            held = [None, copy.deepcopy(self.net).to(dev)]
+            held[1].flat_params.requires_grad_(False)
+        if held[0] != key:
+            with torch.no_grad():
+                held[1].flat_params.copy_(fp)          # (bumps the mirror's version: its weight image is re-packed)
+                held[1].zstats.copy_(self.net.zstats)
+            held[0] = key
+        self.__dict__["_mirror"] = held
+        return held[1]
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_mirror", None)                     # device scratch: never pickled / deep-copied
+        return state
+
     def _kernel_log_prob(self, theta: Tensor, x: Tensor, want_noise: bool):
-        return _log_prob_call(self.net, theta, x, want_noise)
+        net = self._kernel_net()
+        if net is self.net:
+            return self._raw_log_prob(net, theta, x, want_noise)
+        dev = net.flat_params.device
+        lp, noise = self._raw_log_prob(net, theta.to(dev), x.to(dev), want_noise)
+        return lp.to(theta.device), (None if noise is None else noise.to(theta.device))
 
     def _kernel_sample(self, noise: Tensor, x: Tensor, want_ld: bool):
-        return _sample_call(self.net, noise, x, want_ld)
+        net = self._kernel_net()
+        if net is self.net:
+            return self._raw_sample(net, noise, x, want_ld)
+        dev = net.flat_params.device
+        theta, ld = self._raw_sample(net, noise.to(dev), x.to(dev), want_ld)
+        return theta.to(noise.device), (None if ld is None else ld.to(noise.device))
 
     def _autograd_log_prob(self, theta: Tensor, x: Tensor) -> Tensor:
-        return _NSFLogProbFn.apply(theta, x, self.net.flat_params, self.net)
+        net = self._kernel_net()
+        if net is self.net:
+            return self._raw_autograd(net, theta, x, self.net.flat_params)
+        # staged: `.to(dev)` is differentiable, so autograd itself carries d loss / d(theta, x, parameters) back to
+        # the host tensors; the kernels read the mirror (same values as `flat`)
+        dev = net.flat_params.device
+        return self._raw_autograd(net, theta.to(dev), x.to(dev), self.net.flat_params.to(dev)).to(theta.device)
 
     # -- helpers ---------------------------------------------------------------------
     def _flatten_pair(self, input: Tensor, condition: Tensor) -> Tuple[Tensor, Tensor, int, int]:

@@ -1,0 +1,149 @@
+"""The reference trainer's own call sequence, replayed literally against `NSFFlow`:
+
+  * `_initialize_neural_network` (sbi/inference/trainers/npe/npe_base.py:694-703): the builder is called with CPU
+    tensors of the training split, then `test_posterior_net_for_multi_d_x` (sbi/utils/user_input_checks.py:767-795)
+    evaluates `net.log_prob(theta[:, :2], condition=x[:2])` ON THE CPU;
+  * `_run_training_loop` (sbi/inference/trainers/base.py:1087-1146): `net.to(device)`, `Adam(parameters)`, per batch
+    `zero_grad / loss().mean().backward() / clip_grad_norm_ / step` (`:1173-1187`), `deepcopy(net.state_dict())` as the
+    best-so-far snapshot and `load_state_dict` of it (`:1275-1281`, `:1128-1131`), `zero_grad(set_to_none=True)`;
+  * `deepcopy(net)` for the posterior (`:609`) and a pickle round trip.
+
+The same loop drives the oracle (plain PyTorch on the CPU, same initial weights, same batches, same optimizer), and
+the weights after N steps are compared.  A CPU-resident estimator is answered by staging through the ROCm device
+(`NSFFlow._kernel_net`): same kernels, no CPU arithmetic.
+"""
+import copy
+import pickle
+
+import pytest
+import torch
+from torch import nn
+from torch.optim import Adam
+
+from oracle.nsf_oracle import NSFOracle
+from sbi_amd.neural_nets.factory import posterior_nn
+from tests.helpers import linear_gaussian_data
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_sequence(build_fn, theta, x, train_idx, device, steps, batch, lr=5e-4, clip=5.0):
+    """What sbi's `NPE.train()` does to a density estimator, statement by statement (names as in the reference)."""
+    neural_net = build_fn(theta[train_idx].to("cpu"), x[train_idx].to("cpu"))
+    th = theta.to("cpu").unsqueeze(0)                        # reshape_to_sample_batch_event
+    xx = x.to("cpu")                                         # reshape_to_batch_event
+    probe = neural_net.log_prob(th[:, :2], condition=xx[:2])     # test_posterior_net_for_multi_d_x
+    assert probe.shape == (1, 2) and probe.device.type == "cpu"
+    neural_net.to(device)
+    parameters = [p for p in neural_net.parameters() if p.requires_grad]
+    optimizer = Adam(parameters, lr=lr)
+    snapshots = []
+    g = torch.Generator().manual_seed(11)
+    for step in range(steps):
+        idx = train_idx[torch.randperm(len(train_idx), generator=g)[:batch]]
+        theta_batch, x_batch = theta[idx].to(device), x[idx].to(device)
+        neural_net.train()
+        optimizer.zero_grad()
+        train_losses = neural_net.loss(theta_batch, x_batch)
+        train_loss = torch.mean(train_losses)
+        train_loss.backward()
+        nn.utils.clip_grad_norm_(neural_net.parameters(), max_norm=clip)
+        optimizer.step()
+        if step == steps // 2:
+            neural_net.eval()
+            snapshots.append(copy.deepcopy(neural_net.state_dict()))
+    neural_net.zero_grad(set_to_none=True)
+    return neural_net, probe, snapshots
+
+
+@pytest.mark.parametrize("D,C,batch", [(2, 2, 200), (10, 10, 4096)])
+def test_reference_trainer_sequence_matches_the_oracle(D, C, batch):
+    steps, n = 12, 6000
+    theta, x = linear_gaussian_data(n, D, C, seed=5)
+    train_idx = torch.randperm(n, generator=torch.Generator().manual_seed(2))[: int(0.9 * n)]
+
+    torch.manual_seed(21)
+    net, probe, snaps = _reference_sequence(posterior_nn("nsf"), theta, x, train_idx, "cuda", steps, batch)
+
+    def build_oracle(th, xx):
+        torch.manual_seed(21)
+        o = NSFOracle(th, xx)
+        # same initial weights as the estimator under test (the product's init order is pinned elsewhere)
+        torch.manual_seed(21)
+        ref = posterior_nn("nsf")(th, xx)
+        res = o.load_state_dict(ref.net.nflows_state_dict(), strict=False)
+        assert not res.unexpected_keys and all(k.endswith("_features") for k in res.missing_keys), res
+        return o
+
+    oracle, oprobe, osnaps = _reference_sequence(build_oracle, theta, x, train_idx, "cpu", steps, batch)
+
+    # the 2-row CPU probe: answered by the kernels through the staging mirror
+    assert torch.allclose(probe, oprobe.detach(), atol=1e-5 * (1 + oprobe.abs().max().item()))
+
+    got = net.net.nflows_state_dict()
+    want = oracle.state_dict()
+    worst, tot, cnt = 0.0, 0.0, 0
+    for k, v in got.items():
+        d = (v.cpu() - want[k]).abs()
+        worst = max(worst, float(d.max()))
+        tot += float(d.sum())
+        cnt += d.numel()
+    # Adam moves every weight by ~lr per step whatever the gradient's size, so a weight whose gradient is ~0 can take
+    # opposite signs in two fp32 evaluations: the bound is a few lr for the worst weight, the MEAN is held tightly
+    assert worst <= 3 * 5e-4, f"worst weight differs by {worst:.2e} after {steps} steps"
+    assert tot / cnt <= 2e-6, f"mean weight difference {tot / cnt:.2e}"
+
+    # best-so-far snapshot: a deep copy of the state_dict taken mid-training restores exactly
+    held = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(snaps[0])
+    for k, v in snaps[0].items():
+        assert torch.equal(net.state_dict()[k], v)
+    th8, x8 = theta[:8].cuda(), x[:8].cuda()
+    lp_snap = net.log_prob(th8.unsqueeze(0), x8)
+    oracle.load_state_dict(osnaps[0])
+    with torch.no_grad():
+        lp_ref = oracle.log_prob(theta[:8].unsqueeze(0), x[:8])
+    assert torch.allclose(lp_snap.cpu(), lp_ref, atol=2e-5 * (1 + lp_ref.abs().max().item()), rtol=0)
+    net.load_state_dict(held)
+
+    # deepcopy(net) for the posterior and a pickle round trip: same answers, independent storage
+    lp = net.log_prob(th8.unsqueeze(0), x8)
+    twin = copy.deepcopy(net)
+    assert torch.equal(twin.log_prob(th8.unsqueeze(0), x8), lp)
+    assert twin.net.flat_params.data_ptr() != net.net.flat_params.data_ptr()
+    revived = pickle.loads(pickle.dumps(net))
+    assert torch.equal(revived.log_prob(th8.unsqueeze(0), x8), lp)
+
+
+def test_cpu_resident_estimator_answers_through_the_device():
+    """log_prob / sample / loss().backward() of an estimator that was never moved: CPU tensors in, CPU tensors out,
+    values equal to the device-resident estimator's bit for bit (same kernels), gradients land on the CPU
+    parameter; the mirror follows in-place updates of the host weights and is dropped from pickles."""
+    theta, x = linear_gaussian_data(2000, 10, 10, seed=7)
+    torch.manual_seed(3)
+    cpu_net = posterior_nn("nsf")(theta, x)
+    dev_net = copy.deepcopy(cpu_net).to("cuda")
+    th, xx = theta[:300], x[:300]
+    with torch.no_grad():
+        a = cpu_net.log_prob(th.unsqueeze(0), xx)
+        b = dev_net.log_prob(th.cuda().unsqueeze(0), xx.cuda())
+    assert a.device.type == "cpu" and torch.equal(a, b.cpu())
+    torch.manual_seed(0)
+    s_cpu = cpu_net.sample((5,), xx[:3])
+    assert s_cpu.device.type == "cpu" and s_cpu.shape == (5, 3, 10)
+    noise = torch.randn(64, 10)
+    assert torch.equal(cpu_net.sample_from_noise(noise, xx[:1]), dev_net.sample_from_noise(noise.cuda(), xx[:1].cuda()).cpu())
+    # autograd to the host parameter
+    cpu_net.loss(th, xx).mean().backward()
+    dev_net.loss(th.cuda(), xx.cuda()).mean().backward()
+    g_cpu, g_dev = cpu_net.net.flat_params.grad, dev_net.net.flat_params.grad
+    assert g_cpu.device.type == "cpu" and torch.equal(g_cpu, g_dev.cpu())
+    # in-place update of the host weights is seen by the next call
+    with torch.no_grad():
+        cpu_net.net.flat_params.add_(0.01)
+        dev_net.net.flat_params.add_(0.01)
+        assert torch.equal(cpu_net.log_prob(th.unsqueeze(0), xx), dev_net.log_prob(th.cuda().unsqueeze(0), xx.cuda()).cpu())
+    assert "_mirror" in cpu_net.__dict__ and "_mirror" not in pickle.loads(pickle.dumps(cpu_net)).__dict__
+    moved = cpu_net.to("cuda")
+    moved.log_prob(th.cuda().unsqueeze(0), xx.cuda())
+    assert "_mirror" not in moved.__dict__
