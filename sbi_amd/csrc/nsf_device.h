@@ -219,6 +219,22 @@ __device__ __forceinline__ void gemm_blds(const float* __restrict__ lds, const L
   }
 }
 
+// the same with an explicit K-step count (broadcast-x kernels: the initial layer over the identity features only;
+// the B row is zero from column d_id on, so the context columns of W meet zeros)
+__device__ __forceinline__ void gemm_blds_steps(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
+                                                const float* __restrict__ brow, int nsteps, f4 (&acc)[NSF_HT]) {
+  int ro[NSF_HT];
+  a_row_offsets(L, id, ro);
+  for (int s = 0; s < nsteps; ++s) {
+    const float bv = brow[4 * s];
+    float av[NSF_HT];
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt) av[mt] = lds[ro[mt] + 4 * s];
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt) acc[mt] = MFMA16(av[mt], bv, acc[mt]);
+  }
+}
+
 // acc += W * B, B operand = the previous layer's D fragments (registers); KSH K-steps,
 // fully unrolled so the LDS reads of step s+1 are in flight under the MFMAs of step s.
 template <int KSH>
@@ -297,13 +313,27 @@ __device__ __forceinline__ void ast_load(const float* __restrict__ ast, int slot
     v[mt] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ast + (slot * 4 + mt) * 256));
 }
 
-template <int KSH>
+// BX (one condition row for the whole launch: every sampler / potential call): everything that depends on the context
+// alone is row-invariant -- W0[:, d_id:] c + b0 and, per block, sigmoid(Wc c + bc) -- and was put into the LDS table
+// `bx` ([0, 64): initial-layer offset, [64 (1 + b), 64 (2 + b)): gate of block b; indexed by feature) once per
+// transform and workgroup (bx_fold_context): the initial layer runs over the identity features only, the gates
+// cost an LDS read instead of 16 MFMAs + 16 sigmoids per lane and block.
+template <int KSH, bool BX = false>
 __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds, const NsfPlan& pl,
                                                    const ShapeDesc& S, const LaneId& id,
                                                    const float* __restrict__ cin_row, f4 (&h)[NSF_HT],
-                                                   float* __restrict__ ast = nullptr) {
-  acc_init_bias(lds, S.lin[0], id, h);
-  gemm_blds(lds, S.lin[0], id, cin_row, h);
+                                                   float* __restrict__ ast = nullptr,
+                                                   const float* __restrict__ bx = nullptr) {
+  if (BX) {
+#pragma unroll
+    for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[mt][r] = bx[16 * mt + 4 * r + id.g];
+    gemm_blds_steps(lds, S.lin[0], id, cin_row, (S.d_id + 3) >> 2, h);
+  } else {
+    acc_init_bias(lds, S.lin[0], id, h);
+    gemm_blds(lds, S.lin[0], id, cin_row, h);
+  }
   if (pl.ctx_mlp) {
     // ContextSplineMap (flow.py:1419-1478): h_1 = relu(W_in c + b_in), h_{i+1} = relu(W_h h_i + b_h) for i = 1 ... reps
     // (hidden_layers_spline_context applications of ONE Linear: the reference repeats the same module object)
@@ -327,15 +357,25 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
   if (ast) ast_store(ast, 0, h);
   for (int b = 0; b < pl.NB; ++b) {
     f4 gate[NSF_HT], t[NSF_HT], u[NSF_HT];
-    acc_init_bias(lds, S.lin[1 + 3 * b], id, gate);
-    gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, gate);
+    if (BX) {
 #pragma unroll
-    for (int mt = 0; mt < NSF_HT; ++mt)
+      for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        t[mt][r] = fmaxf(h[mt][r], 0.f);
-        gate[mt][r] = sigmoid_f(gate[mt][r]);
-      }
+        for (int r = 0; r < 4; ++r) {
+          t[mt][r] = fmaxf(h[mt][r], 0.f);
+          gate[mt][r] = bx[64 * (1 + b) + 16 * mt + 4 * r + id.g];
+        }
+    } else {
+      acc_init_bias(lds, S.lin[1 + 3 * b], id, gate);
+      gemm_blds(lds, S.lin[1 + 3 * b], id, cin_row + S.d_id, gate);
+#pragma unroll
+      for (int mt = 0; mt < NSF_HT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t[mt][r] = fmaxf(h[mt][r], 0.f);
+          gate[mt][r] = sigmoid_f(gate[mt][r]);
+        }
+    }
     acc_init_bias(lds, S.lin[2 + 3 * b], id, u);
     gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, t, u);
     if (ast) { ast_store(ast, 1 + 4 * b, u); ast_store(ast, 3 + 4 * b, gate); }
@@ -774,6 +814,37 @@ __device__ __forceinline__ float lu_logabsdet(const float* __restrict__ lds, con
 
 // conditioner input rows: cin[j] = [ z[identity dims] ; standardized context ; 0 pad ].
 // For C <= 16 the context of lane (j,g) is held in registers: cr[u] = c[g + 4u].
+// broadcast-x kernels: the conditioner input row holds the identity features only, zero up to the K-steps the initial
+// layer runs ((d_id + 3) / 4 of them)
+__device__ __forceinline__ void build_cin_bx(const NsfPlan& pl, const ShapeDesc& S, int parity, const LaneId& id,
+                                             const float* __restrict__ zs, float* __restrict__ cin) {
+  const int kmax = ((S.d_id + 3) >> 2) << 2;
+  for (int k = id.g; k < kmax; k += 4)
+    cin[id.j * pl.CINW + k] = k < S.d_id ? zs[id.j * pl.ZW + 2 * k + (1 - parity)] : 0.f;
+  wave_lds_fence();
+}
+
+// broadcast-x kernels, once per transform and workgroup, between the two barriers of the weight staging: the
+// context-only terms of the conditioner from the transform's packed image in global memory (`img`: L2 resident, read
+// by every workgroup) and the standardized condition row `cstd` (LDS) into the LDS table `bx` (conditioner_hidden).
+__device__ __forceinline__ void bx_fold_context(const float* __restrict__ img, const NsfPlan& pl, const ShapeDesc& S,
+                                                const float* __restrict__ cstd, float* __restrict__ bx,
+                                                int tid, int nthreads) {
+  const int C = pl.C;
+  for (int idx = tid; idx < 64 * (1 + pl.NB); idx += nthreads) {
+    const int which = idx >> 6, f = idx & 63;
+    const LinDesc& L = S.lin[which == 0 ? 0 : 1 + 3 * (which - 1)];
+    float v = which == 0 ? 0.f : 0.5f;          // padding features: what the per-row path computes there
+    if (f < L.out) {
+      const float* __restrict__ w = img + L.l_w + f * L.ldk + (which == 0 ? S.d_id : 0);
+      float a = img[L.l_b + f];
+      for (int c = 0; c < C; ++c) a = fmaf(w[c], cstd[c], a);
+      v = which == 0 ? a : sigmoid_f(a);
+    }
+    bx[idx] = v;
+  }
+}
+
 __device__ __forceinline__ void build_cin(const NsfPlan& pl, const ShapeDesc& S, int parity, const LaneId& id,
                                           const float* __restrict__ zs, const float* __restrict__ cs,
                                           const float (&cr)[4], float* __restrict__ cin) {

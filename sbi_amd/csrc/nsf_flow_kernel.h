@@ -43,7 +43,9 @@ static bool flow_plan_is_static(const NsfPlan& pl, const NsfPlan& st) {
 // Only the sampling direction ever launches 12-wave workgroups (nsf_plan_for_rows(..., wide)); the density direction
 // keeps the 512-thread bound so that its register allocation is not capped at three waves per SIMD.
 // SP = 0: layout from the kernel argument; SP = 8 / 12: the static default layout for 8- / 12-wave workgroups
-template <int K, int KSH, bool INV, int SP = 0>
+// BX: one condition row for the whole launch (x_rows == 1, no training stash): the context-only terms of every
+// transform's conditioner are folded once per workgroup (nsf_device.h, conditioner_hidden<KSH, true>)
+template <int K, int KSH, bool INV, int SP = 0, bool BX = false>
 __global__ void __launch_bounds__(INV ? 768 : 512)
 nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
@@ -75,6 +77,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
+  float* bxt = lds + pl.lds_w_floats + nw * pl.sc_total;   // BX: [64 (1 + NB)] table, then the standardized condition row
+  float* cstd = bxt + 64 * (1 + pl.NB);
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
   float cr[4] = {0.f, 0.f, 0.f, 0.f};   // standardized context of this lane (C <= 16)
   if (pl_.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): start from NaN-filled LDS, so that any read of a
@@ -95,7 +99,9 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       }
       zs[id.j * pl.ZW + d] = v;
     }
-    if (C <= 16) {
+    if (BX) {
+      for (int c = tid; c < C; c += nthreads) cstd[c] = (x[c] - x_mean[c]) / x_std[c];   // published by layer 0's first barrier
+    } else if (C <= 16) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = id.g + 4 * u;
@@ -120,6 +126,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
     TSF(1);
     if (!(pl_.ablate & 16) || li == 0)
       stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
+    if (BX) bx_fold_context(packed + (long long)t * pl.img_floats, pl, S, cstd, bxt, tid, nthreads);
     TSF(2);
     __syncthreads();
     TSF(3);
@@ -132,7 +139,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       lu_inverse(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
-    build_cin(pl, S, par, id, zs, cs, cr, cin);
+    if (BX) build_cin_bx(pl, S, par, id, zs, cin);
+    else build_cin(pl, S, par, id, zs, cs, cr, cin);
     TSF(4);
 
     // The two waves of a SIMD run the same phases in lockstep and the arbiter favours the older one, which
@@ -146,7 +154,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       const long long tile16 = (long long)blockIdx.x * nw + wave;
       if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * nsf_ast_slots(pl)) * 1024 + 4 * id.lane;
     }
-    if (!(pl_.ablate & 4)) conditioner_hidden<KSH>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast);
+    if (!(pl_.ablate & 4)) conditioner_hidden<KSH, BX>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast, bxt);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
     TSF(5);
@@ -266,12 +274,25 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
 
 
 // ---- launch helpers (shared by the forward and inverse translation units)
-template <int K, int KSH, bool INV, int SP = 0>
+// LDS the broadcast-x table needs behind the wave scratch; the specialisation applies when one condition row serves
+// the whole launch, nothing is stashed for a backward pass, the conditioner is the residual net, and it fits
+static inline int64_t nsf_bx_extra_bytes(const NsfPlan& pl) { return 4ll * (64 * (1 + pl.NB) + ((pl.C + 3) & ~3)); }
+static inline bool nsf_bx_applies(const NsfPlan& pl, int nw, int64_t x_rows, const float* z_stash, const float* astash) {
+  return x_rows == 1 && !z_stash && !astash && !pl.ctx_mlp && !(pl.ablate & 0x80000) &&
+         nsf_lds_bytes(pl, nw) + nsf_bx_extra_bytes(pl) <= NSF_LDS_LIMIT_BYTES;
+}
+
+template <int K, int KSH, bool INV, int SP = 0, bool BX = false>
 static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                        const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                        float* z_stash, float* astash, hipStream_t stream) {
-  const int64_t lds_bytes = nsf_lds_bytes(pl, nw);
-  auto kern = nsf_flow_kernel<K, KSH, INV, SP>;
+  if constexpr (!BX) {
+    if (nsf_bx_applies(pl, nw, x_rows, z_stash, astash))
+      return launch_flow<K, KSH, INV, SP, true>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash,
+                                                astash, stream);
+  }
+  const int64_t lds_bytes = nsf_lds_bytes(pl, nw) + (BX ? nsf_bx_extra_bytes(pl) : 0);
+  auto kern = nsf_flow_kernel<K, KSH, INV, SP, BX>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t rows_per_wg = 16 * nw;

@@ -90,6 +90,11 @@ def test_reference_trainer_sequence_matches_the_oracle(D, C, batch):
         cnt += d.numel()
     # Adam moves every weight by ~lr per step whatever the gradient's size, so a weight whose gradient is ~0 can take
     # opposite signs in two fp32 evaluations: the bound is a few lr for the worst weight, the MEAN is held tightly
+    from tests.parity_log import record
+
+    record("reference_trainer_replay", f"D{D}-C{C}-batch{batch}", steps=steps, worst_weight_diff=worst,
+           mean_weight_diff=tot / cnt, probe_abs_diff=(probe - oprobe.detach()).abs().max().item())
+    print(f"replay D={D} batch={batch}: after {steps} Adam steps worst weight diff {worst:.2e}, mean {tot / cnt:.2e}")
     assert worst <= 3 * 5e-4, f"worst weight differs by {worst:.2e} after {steps} steps"
     assert tot / cnt <= 2e-6, f"mean weight difference {tot / cnt:.2e}"
 

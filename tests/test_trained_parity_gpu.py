@@ -158,5 +158,6 @@ def test_trained_training_gradient_matches_autograd(name, rows):
     print(f"{name} grad {rows} rows: max|grad| {scale:.3e}, hip vs f64 {e_h:.2e} ({e_h / scale:.2e} rel), "
           f"o32 vs f64 {e_o:.2e}")
     assert torch.isfinite(g_h).all()
-    # knot-straddling rows (tests/test_parity_full_size_gpu.py) contribute O(1) / rows each: allow a handful
-    assert e_h <= max(3e-4 * scale, 8.0 / rows * 1e-1), (e_h, scale)
+    # no further from fp64 autograd than eager fp32 autograd is (x 2), plus the knot-straddling rows' allowance
+    # (tests/test_parity_full_size_gpu.py: such a row contributes O(1) / rows to an entry)
+    assert e_h <= 2.0 * e_o + max(1e-4 * scale, 0.5 / rows), (e_h, e_o, scale)
