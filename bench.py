@@ -483,6 +483,103 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
         "_cpu_baseline_fn": lambda: fmpe_cpu_baseline(fm, th_f, x_f)}
 
 
+def mcmc_leg(est, x, device, with_cpu=False):
+    """MCMCPosterior (slice_np_vectorized on the device, sbi/samplers/mcmc/slice_numpy.py:353-587) over the
+    NSF potential, one x_o: every tick of every chain's state machine is one launch of `slice_tick_kernel` around one
+    batched log_prob call (x_rows == 1: the broadcast-x kernels)."""
+    from torch.distributions import Independent, Normal
+
+    from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+    from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+    from sbi_amd.utils.sbiutils import mcmc_transform
+
+    prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
+    potential_fn, _ = posterior_estimator_based_potential(est, prior, x_o=None)
+    chains = int(os.environ.get("SBI_AMD_MCMC_CHAINS", "4096"))
+    post = MCMCPosterior(potential_fn, prior, mcmc_transform(prior, device=device), num_chains=chains, thin=1,
+                         warmup_steps=10, init_strategy="resample",
+                         init_strategy_parameters=dict(num_candidate_samples=64), device=str(device))
+    post.set_default_x(x[:1].clone())
+    nd = chains * 10
+    post.sample((nd,), show_progress_bars=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    post.sample((nd,), show_progress_bars=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ticks = post.posterior_sampler.num_ticks
+    out = {"metric": "MCMCPosterior slice_np_vectorized samples/sec", "value": nd / dt,
+           "unit": "samples/s", "n_gpus": 1, "chains": chains, "ticks": ticks,
+           "us_per_tick": dt / ticks * 1e6, "log_prob_evals_per_s": ticks * chains / dt,
+           "config": {"workload": f"{chains} chains x {nd // chains} kept sweeps (+10 warm-up, "
+                                  f"+50 width-tuning sweeps), theta-dim {D}, one x_o"}}
+    if with_cpu:
+        # what bounds the reference's sampler on the host: one potential evaluation of all chains per tick (the oracle's
+        # log_prob at `chains` rows, x_o repeated as nflows does) -- its slice bookkeeping is numpy and comes on top
+        from oracle.nsf_oracle import NSFOracle
+
+        th_c, x_c = make_data(BATCH, "cpu")
+        torch.manual_seed(1)
+        oracle = NSFOracle(th_c, x_c)
+        xb = x_c[:1].expand(chains, C).contiguous()
+        with torch.no_grad():
+            oracle.log_prob(th_c[:chains], xb)
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 4.0 or reps < 2:
+                oracle.log_prob(th_c[:chains], xb)
+                reps += 1
+            dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": chains * reps / dtc, "unit": "log_prob evals/s", "cores": _cpu_cores(),
+                               "kind": "port", "compare_with": "log_prob_evals_per_s",
+                               "sample": f"{reps} oracle log_prob calls of {chains} rows (one tick's potential "
+                                         f"evaluation; the host-side slice bookkeeping is not included) ({dtc:.1f} s)"}
+    return out
+
+
+def atomic_leg(est, theta, x, B, GB, steps, warmup, device, dist, distributed, world, scaling, with_cpu=False):
+    """one multi-round NPE-C step (atomic proposal-posterior loss, sbi/inference/trainers/npe/npe_c.py:356-440,
+    10 atoms) on B pairs: A x B log_prob rows forward + backward on one stash, softmax weights on the device."""
+    from torch.distributions import Independent, Normal
+
+    from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+    prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
+    masks = torch.zeros(B, 1, dtype=torch.bool, device=device)
+    stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
+    A = 10
+    wall, dev_ms = timed(lambda: stepper.atomic_step(theta, x, masks, prior, A), steps, warmup, device, dist)
+    out = {"metric": "NPE-C atomic-loss train (theta,x)-pairs/sec", "value": GB * steps / wall,
+           "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": scaling,
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"multi-round NPE-C step, {A} atoms, batch {B} per GPU = {A * B} log_prob "
+                                  f"rows forward + backward, theta-dim {D}", "parallelism": f"dp{world}"},
+           "roofline": roofline(F_TRAIN, A * B, steps, dev_ms)}
+    if with_cpu:
+        from oracle.nsf_oracle import NSFOracle
+        from sbi_amd.inference.trainers.npe.atomic import log_prob_proposal_posterior_atomic
+
+        th_c, x_c = make_data(BATCH, "cpu")
+        torch.manual_seed(1)
+        oracle = NSFOracle(th_c, x_c)
+        bc = 8192        # bounded sample: 8 192 pairs x 10 atoms per step
+        prior_c = Independent(Normal(torch.zeros(D), (0.1**0.5) * torch.ones(D)), 1)
+        opt = torch.optim.Adam(oracle.parameters(), lr=5e-4)
+        mk = torch.zeros(bc, 1, dtype=torch.bool)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 6.0 or reps < 2:
+            opt.zero_grad()
+            (-log_prob_proposal_posterior_atomic(oracle, prior_c, th_c[:bc], x_c[:bc], mk, A, False)).mean().backward()
+            torch.nn.utils.clip_grad_norm_(oracle.parameters(), 5.0)
+            opt.step()
+            reps += 1
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": bc * reps / dtc, "unit": "pairs/s", "cores": _cpu_cores(), "kind": "port",
+                               "sample": f"{reps} atomic-loss steps of {bc} pairs x {A} atoms through the oracle "
+                                         f"(autograd, clip, Adam) ({dtc:.1f} s)"}
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -640,34 +737,9 @@ def main(argv=None):
                 "ms_per_step": wall_b / bsteps * 1e3, "device_ms_per_step": dev_b / bsteps, "steps": bsteps}
         results["sample"]["acceptance_below_one"] = box_obj
     if args.mode == "mcmc":
-        # MCMCPosterior (slice_np_vectorized on the device) over the NSF potential, one x_o
-        from torch.distributions import Independent, Normal
-
-        from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
-        from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
-        from sbi_amd.utils.sbiutils import mcmc_transform
-
-        prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
-        potential_fn, _ = posterior_estimator_based_potential(est, prior, x_o=None)
-        chains = int(os.environ.get("SBI_AMD_MCMC_CHAINS", "4096"))
-        post = MCMCPosterior(potential_fn, prior, mcmc_transform(prior, device=device), num_chains=chains, thin=1,
-                             warmup_steps=10, init_strategy="resample",
-                             init_strategy_parameters=dict(num_candidate_samples=64), device=str(device))
-        post.set_default_x(x[:1].clone())
-        nd = chains * 10
-        post.sample((nd,), show_progress_bars=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        post.sample((nd,), show_progress_bars=False)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ticks = post.posterior_sampler.num_ticks
+        out = mcmc_leg(est, x, device, with_cpu=(world == 1 and not args.no_cpu_baseline))
         if rank == 0:
-            print(json.dumps({"metric": "MCMCPosterior slice_np_vectorized samples/sec", "value": nd / dt,
-                              "unit": "samples/s", "n_gpus": 1, "chains": chains, "ticks": ticks,
-                              "us_per_tick": dt / ticks * 1e6, "log_prob_evals_per_s": ticks * chains / dt,
-                              "config": {"workload": f"{chains} chains x {nd // chains} kept sweeps (+10 warm-up, "
-                                                     f"+50 width-tuning sweeps), theta-dim {D}, one x_o"}}))
+            print(json.dumps(out))
         return
     if args.mode == "fmpe":
         out = fmpe_leg(args, B, rank, world, device, dist, distributed, GB)
@@ -738,26 +810,10 @@ def main(argv=None):
             dist.destroy_process_group()
         return
     if args.mode == "atomic":
-        # one multi-round NPE-C step (atomic proposal-posterior loss, 10 atoms) on `--batch` pairs
-        from torch.distributions import Independent, Normal
-
-        from sbi_amd.inference.trainers.fused import FusedTrainStep
-
-        prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
-        masks = torch.zeros(B, 1, dtype=torch.bool, device=device)
-        stepper = FusedTrainStep(est, lr=5e-4, clip_max_norm=5.0, distributed=distributed)
-        A = 10
-        wall, dev_ms = timed(lambda: stepper.atomic_step(theta, x, masks, prior, A), args.steps, args.warmup, device,
-                             dist)
+        out = atomic_leg(est, theta, x, B, GB, args.steps, args.warmup, device, dist, distributed, world, args.scaling,
+                         with_cpu=(world == 1 and not args.no_cpu_baseline))
         if rank == 0:
-            print(json.dumps({
-                "metric": "NPE-C atomic-loss train (theta,x)-pairs/sec", "value": GB * args.steps / wall,
-                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"multi-round NPE-C step, {A} atoms, batch {B} per GPU = {A * B} log_prob "
-                                       f"rows forward + backward, theta-dim {D}", "parallelism": f"dp{world}"},
-                "roofline": roofline(F_TRAIN, A * B, args.steps, dev_ms)}))
+            print(json.dumps(out))
         if distributed:
             dist.destroy_process_group()
         return
@@ -825,6 +881,12 @@ def main(argv=None):
                                       "train_value": b * ks / wall_w, "unit": "pairs/s", "log_prob_device_ms": lp_ms / ks}
         small_obj["wide_hidden_100"] = wide_obj
 
+    atomic_obj = mcmc_obj = None
+    if args.mode == "both" and world == 1 and not distributed:
+        # SURVEY 8(f) rows 2 and 3 where the driver sees them: short legs, nested like the other secondary metrics
+        atomic_obj = atomic_leg(est, theta[:8192].contiguous(), x[:8192].contiguous(), 8192, 8192, min(args.steps, 20),
+                                min(args.warmup, 5), device, None, False, 1, "weak", with_cpu=not args.no_cpu_baseline)
+        mcmc_obj = mcmc_leg(est, x, device, with_cpu=not args.no_cpu_baseline)
     npe_obj = npe_train_leg(device, rank, world, args.npe_epochs) if args.mode == "both" else None
     fm_out = fmpe_leg(args, B, rank, world, device, dist, distributed, GB) if args.mode == "both" else None
     if rank == 0:
@@ -882,6 +944,13 @@ def main(argv=None):
             out["rccl_1rank"] = rccl_one_rank_leg(args, r)
         if npe_obj is not None:
             out["npe_train"] = npe_obj
+        if atomic_obj is not None:
+            out["npe_c_atomic"] = {k: atomic_obj[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline",
+                                                              "cpu_baseline") if k in atomic_obj}
+            out["npe_c_atomic"]["workload"] = atomic_obj["config"]["workload"]
+        if mcmc_obj is not None:
+            out["mcmc"] = {k: v for k, v in mcmc_obj.items() if k not in ("n_gpus", "config")}
+            out["mcmc"]["workload"] = mcmc_obj["config"]["workload"]
         if fm_out is not None:
             out["fmpe_train"] = {k: fm_out[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline",
                                                         "host", "posterior_sample")}

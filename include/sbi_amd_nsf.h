@@ -168,6 +168,23 @@ int sbi_amd_shuffled_gather(const float* a, int32_t da, const float* b, int32_t 
                             int64_t n_perm, uint64_t key, int64_t offset, int64_t count, float* a_out, float* b_out,
                             int64_t* idx_out, void* stream);
 
+/* Epochs as HIP graphs (trainers/base.py:1150-1225 is a Python loop over DataLoader batches).  A captured
+ * launch must not depend on anything the host changes from epoch to epoch; two things in a training step do -- the
+ * sampler's per-epoch key and Adam's step count.  Both move to device memory:
+ *   clock      int64[2]: [0] epoch number, [1] optimizer steps taken      bias_corr  float[2]: 1 - beta1^step, sqrt(1 - beta2^step)
+ *   sbi_amd_train_clock_tick(clock, bias_corr, 0, ...)   epoch += 1                       (one thread; end of an epoch)
+ *   sbi_amd_train_clock_tick(clock, bias_corr, 1, beta1, beta2, stream)   step += 1, bias corrections (before the update)
+ *   sbi_amd_shuffled_gather_clock(..., seed, &clock[0], ...)              key = splitmix64(seed, epoch) in the kernel:
+ *                                                                         same orders as sbi_amd_shuffled_gather
+ *   sbi_amd_adam_clip_step_clock(..., bias_corr, ...)                     sqnorm_parts NULL: norm kernel first */
+int sbi_amd_train_clock_tick(int64_t* clock, float* bias_corr, int32_t which, float beta1, float beta2, void* stream);
+int sbi_amd_shuffled_gather_clock(const float* a, int32_t da, const float* b, int32_t db, const int64_t* base_idx,
+                                  int64_t n_perm, uint64_t seed, const int64_t* epoch_dev, int64_t offset,
+                                  int64_t count, float* a_out, float* b_out, int64_t* idx_out, void* stream);
+int sbi_amd_adam_clip_step_clock(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                                 const float* bias_corr, float lr, float beta1, float beta2, float eps, float max_norm,
+                                 const float* sqnorm_parts, int64_t n_parts, float* scratch, void* stream);
+
 /* Fused global-norm clip + Adam on the flat buffer: replaces
  * clip_grad_norm_(max_norm) + torch.optim.Adam.step (trainers/base.py:1181-1187,
  * :1097).  `step` is the 1-based step count; max_norm <= 0 disables clipping.
@@ -237,7 +254,7 @@ int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, c
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 112
+#define SBI_AMD_NSF_ABI_VERSION 113
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

@@ -641,6 +641,47 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
   o.d_n = part ? d_mine : d_oth;
 }
 
+// ---- the selected bin re-derived beyond fp32 (density direction, nflows parametrisation) ----------------------------
+// Where log p loses its digits (tools/diag/spline_precision.py): not in the conditioner GEMMs
+// (2e-7 of the 6e-6 rms error against an fp64 evaluation) and not in the order of the final sums (fp64 summation of
+// the fp32 terms: 9.3 % -> 8.9 % of rows beyond 1e-5), but in the spline's own normalisation: the softmax denominator,
+// the (1 - K min) p + min affine map, the knot cumsum and the bin width / height taken back as a DIFFERENCE of two
+// rounded knots each carry ~1e-7 relative error into w and h, the log-derivative holds log((h / w)^2 ...), and 25
+// spline evaluations add up.  The reference's eager fp32 arithmetic has the same error (and is what the oracle
+// restates); an implementation is free to do better.  So: the bin is still FOUND on the fp32 knots (same bin as the
+// backward pass, which recomputes them the same way), then its width, its left knot and x - knot are re-derived with
+// the denominator and the prefix sum held in fp64 -- ~6 fp64-rate instructions per logit and side, a dozen per task.
+// NSF_PRECISE_SPLINE=0 compiles it out (-DNSF_PRECISE_SPLINE=0 in SBI_AMD_EXTRA_HIPCC_FLAGS); SBI_AMD_ABLATE bit
+// 0x100000 skips it at run time (A/B on one build).
+#ifndef NSF_PRECISE_SPLINE
+#define NSF_PRECISE_SPLINE 1
+#endif
+__device__ __forceinline__ double rcp_d(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+// this side's selected bin: extent (width or height) and left knot, both in fp64, from the side's K exps
+template <int K, class PL>
+__device__ __forceinline__ void precise_bin(const SplineSide<K>& S, int idx, const PL& pl, int part, double& extent,
+                                            double& knot) {
+  double sd = 0.0, pd = 0.0;
+  float e_i = S.e[0];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool hit = (k == idx);
+    pd = hit ? sd : pd;             // prefix sum of the bins left of the selected one
+    e_i = hit ? S.e[k] : e_i;
+    sd += (double)S.e[k];
+  }
+  const double mn = (double)(part ? pl.min_h : pl.min_w);
+  const double n = (1.0 - mn * (double)K) * rcp_d(sd);
+  const double twoB = 2.0 * (double)pl.B;
+  extent = twoB * fma((double)e_i, n, mn);
+  knot = fma(fma(pd, n, mn * (double)idx), twoB, -(double)pl.B);
+  if (idx == K - 1) extent = (double)pl.B - knot;     // nflows overwrites the last knot with B
+}
+
 // forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
 // receive y and ld.
 template <int K, bool INV, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
@@ -650,17 +691,33 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   spline_side<K, Y, VAR>(p + part * K, pl, part, S, static_cast<Y&&>(yield));
   SplineSel o;
   spline_select<K, INV, Y, VAR>(p, x, pl, part, S, o, static_cast<Y&&>(yield));
-  const float w_i = o.cw_n - o.cw_i;
-  const float h_i = o.ch_n - o.ch_i;
+  float w_i = o.cw_n - o.cw_i;
+  float h_i = o.ch_n - o.ch_i;
+  float xm = x - o.cw_i;          // distance of the input from the bin's left knot
+  float ch_lo = 0.f;              // low word of the bin's bottom knot
+  if (NSF_PRECISE_SPLINE && !INV && VAR == 0 && !(pl.ablate & 0x100000)) {   // (SBI_AMD_ABLATE bit 0x100000: A/B at run time)
+    double ext, knot;
+    precise_bin<K>(S, o.idx, pl, part, ext, knot);
+    // part 0 holds the width side, part 1 the height side: each rounds its own three scalars, then they swap
+    const float ext_f = (float)ext;
+    const float a_f = part ? (float)knot : (float)((double)x - knot);          // heights: knot (hi) | widths: x - knot
+    const float b_f = part ? (float)(knot - (double)(float)knot) : 0.f;        // heights: knot (lo)
+    const float ext_o = xchg32(ext_f), a_o = xchg32(a_f), b_o = xchg32(b_f);
+    w_i = part ? ext_o : ext_f;
+    h_i = part ? ext_f : ext_o;
+    xm = part ? a_o : a_f;
+    o.ch_i = part ? a_f : a_o;
+    ch_lo = part ? b_f : b_o;
+  }
   const float rw_i = rcp_nr(w_i);
   const float delta = h_i * rw_i;
   float yo, lo;
   if (!INV) {
-    const float th = (x - o.cw_i) * rw_i;
+    const float th = xm * rw_i;
     const float tt = th * (1.f - th);
     const float num = h_i * (delta * (th * th) + o.d_i * tt);
     const float den = delta + ((o.d_i + o.d_n - 2.f * delta) * tt);
-    yo = o.ch_i + num * rcp_nr(den);
+    yo = o.ch_i + (num * rcp_nr(den) + ch_lo);
     const float omt = 1.f - th;
     const float dnum = (delta * delta) * (o.d_n * (th * th) + 2.f * delta * tt + o.d_i * (omt * omt));
     lo = log_f(dnum) - 2.f * log_f(den);

@@ -144,20 +144,29 @@ def test_trained_training_gradient_matches_autograd(name, rows):
     theta, x = theta[:rows], x[:rows]
     flat64 = torch.zeros(est.net.flat_params.numel(), dtype=torch.float64)
     flat32 = torch.zeros_like(flat64)
+    gth64 = []
     for i in range(0, rows, CHUNK):       # gradients of a mean are additive over chunks
         sl = slice(i, i + CHUNK)
         w = torch.full((min(CHUNK, rows - i),), 1.0 / rows)
-        flat64 += oracle_training_grad(oracle, est, theta[sl], x[sl], w=w, double=True)[1]
+        _, f64, g64, _ = oracle_training_grad(oracle, est, theta[sl], x[sl], w=w, double=True)
+        flat64 += f64
+        gth64.append(g64 * rows)          # row n: d loss_n / d theta_n
         flat32 += oracle_training_grad(oracle, est, theta[sl], x[sl], w=w, double=False)[1].double()
-    _, g_h, _, _ = hip_training_pass(est, theta, x)
+    gth64 = torch.cat(gth64)
+    _, g_h, gth_h, _ = hip_training_pass(est, theta, x)
     scale = flat64.abs().max().item()
     e_h = (g_h.double() - flat64).abs().max().item()
     e_o = (flat32 - flat64).abs().max().item()
+    # rows whose d loss / d theta disagrees with fp64: spline inputs within an fp32 ulp of a knot, where the C1 spline's
+    # parameter gradient is two-valued (tests/test_parity_full_size_gpu.py verifies that reading on the matched pair);
+    # each contributes O(1) / rows to entries of the flat gradient
+    row_err = (gth_h.double() * rows - gth64).abs().max(dim=1).values / gth64.abs().max().item()
+    n_out = int((row_err > 1e-3).sum())
     record("trained_parity", f"{name}:grad:{rows}", max_abs_grad=scale, abs_err_hip_vs_f64=e_h, abs_err_o32_vs_f64=e_o,
-           rel_err_hip_vs_f64=e_h / scale, rel_err_o32_vs_f64=e_o / scale)
+           rel_err_hip_vs_f64=e_h / scale, rel_err_o32_vs_f64=e_o / scale, knot_straddling_rows=n_out)
     print(f"{name} grad {rows} rows: max|grad| {scale:.3e}, hip vs f64 {e_h:.2e} ({e_h / scale:.2e} rel), "
-          f"o32 vs f64 {e_o:.2e}")
+          f"o32 vs f64 {e_o:.2e}; rows off in d loss / d theta: {n_out}")
     assert torch.isfinite(g_h).all()
-    # no further from fp64 autograd than eager fp32 autograd is (x 2), plus the knot-straddling rows' allowance
-    # (tests/test_parity_full_size_gpu.py: such a row contributes O(1) / rows to an entry)
-    assert e_h <= 2.0 * e_o + max(1e-4 * scale, 0.5 / rows), (e_h, e_o, scale)
+    assert n_out <= 8
+    # no further from fp64 autograd than eager fp32 autograd is (x 2), plus O(1) / rows per knot-straddling row
+    assert e_h <= 2.0 * e_o + 1e-4 * scale + n_out * 4.0 / rows, (e_h, e_o, scale, n_out)
