@@ -15,7 +15,7 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 112    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 113    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
@@ -114,6 +114,17 @@ _SIGNATURES = {
         c_int,
         [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_int64, c_int64, c_void_p, c_void_p,
          c_void_p, c_void_p],
+    ),
+    "sbi_amd_shuffled_gather_clock": (
+        c_int,
+        [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_void_p, c_int64, c_int64, c_void_p,
+         c_void_p, c_void_p, c_void_p],
+    ),
+    "sbi_amd_train_clock_tick": (c_int, [c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
+    "sbi_amd_adam_clip_step_clock": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float,
+         c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "sbi_amd_mcmc_slice_tick": (
         c_int,

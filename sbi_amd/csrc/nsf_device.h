@@ -651,14 +651,12 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
 // restates); an implementation is free to do better.  So: the bin is still FOUND on the fp32 knots (same bin as the
 // backward pass, which recomputes them the same way), then its width, its left knot and x - knot are re-derived with
 // the denominator and the prefix sum held in fp64 -- ~6 fp64-rate instructions per logit and side, a dozen per task.
-// NSF_PRECISE_SPLINE=0 compiles it out (-DNSF_PRECISE_SPLINE=0 in SBI_AMD_EXTRA_HIPCC_FLAGS); SBI_AMD_ABLATE bit
-// 0x100000 skips it at run time (A/B on one build).
+// NSF_PRECISE_SPLINE=0 compiles it out (A/B: SBI_AMD_EXTRA_HIPCC_FLAGS=-DNSF_PRECISE_SPLINE=0 rebuilds the library).
 #ifndef NSF_PRECISE_SPLINE
 #define NSF_PRECISE_SPLINE 1
 #endif
 __device__ __forceinline__ double rcp_d(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(r, fma(-x, r, 1.0), r);
+  const double r = __builtin_amdgcn_rcp(x);     // v_rcp_f64: >= 2^-20; one Newton step squares the error (1e-12: plenty)
   return fma(r, fma(-x, r, 1.0), r);
 }
 // this side's selected bin: extent (width or height) and left knot, both in fp64, from the side's K exps
@@ -695,7 +693,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   float h_i = o.ch_n - o.ch_i;
   float xm = x - o.cw_i;          // distance of the input from the bin's left knot
   float ch_lo = 0.f;              // low word of the bin's bottom knot
-  if (NSF_PRECISE_SPLINE && !INV && VAR == 0 && !(pl.ablate & 0x100000)) {   // (SBI_AMD_ABLATE bit 0x100000: A/B at run time)
+  if (NSF_PRECISE_SPLINE && !INV && VAR == 0) {   // (compile time: the fp32 knot selects of spline_select then fold away)
     double ext, knot;
     precise_bin<K>(S, o.idx, pl, part, ext, knot);
     // part 0 holds the width side, part 1 the height side: each rounds its own three scalars, then they swap
@@ -713,7 +711,9 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   const float delta = h_i * rw_i;
   float yo, lo;
   if (!INV) {
-    const float th = xm * rw_i;
+    // (the bin was found on the fp32 knots: against the re-derived knot the input can sit an ulp outside [0, 1], and
+    //  in a saturated bin -- slope 1e3 between slopes 1e-3 -- that turns the derivative's numerator negative)
+    const float th = NSF_PRECISE_SPLINE ? __builtin_amdgcn_fmed3f(xm * rw_i, 0.f, 1.f) : xm * rw_i;
     const float tt = th * (1.f - th);
     const float num = h_i * (delta * (th * th) + o.d_i * tt);
     const float den = delta + ((o.d_i + o.d_n - 2.f * delta) * tt);

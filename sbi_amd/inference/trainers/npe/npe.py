@@ -441,12 +441,74 @@ class PosteriorEstimatorTrainer:
 
             return rank_window(lo, count, rank, world)
 
-        host_ring = []       # filled below once `pipelined` is known (pinned float32 pairs: train / validation loss sums)
+        host_ring = []       # filled below when `pipelined` (pinned float32 pairs: train / validation loss sums)
+        pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"      # (why: see the loop below)
+        from sbi_amd import _lib as _lib_mod
+
+        # Epochs as HIP graphs: after one eager epoch (which sizes the workspace, builds the re-pack table and
+        # leaves the allocator warm) the epoch's device work -- per batch: gather, forward, T backward launches,
+        # reduction, clip + Adam, re-pack; then the validation pass and the loss sums -- is captured ONCE and replayed
+        # with one host call per epoch.  Nothing in it depends on the host: the sampler's epoch number and Adam's step
+        # count live in device memory (`FusedTrainStep.clock`, ticked by the graph itself).  What stays outside the
+        # graph: the snapshot of the weights / optimizer state (every in-flight epoch record needs its own copy), the
+        # read-back of the two loss sums and the events.  Not captured (the eager loop runs): the atomic loss and
+        # validation orders that need fresh random numbers, more than one rank, index-path data.
+        # SBI_AMD_GRAPH_EPOCH=0 switches it off (A/B).
+        graphable = (pipelined and sampler is not None and not atomic and d is None and n_val_batches * Bv == n_val
+                     and _os.environ.get("SBI_AMD_GRAPH_EPOCH", "1") != "0")
+        gstate = {"graph": None, "sums": None, "warm": False, "failed": False}
+
+        def epoch_body() -> Tensor:
+            """One epoch's device work with no host-dependent launch argument (capturable)."""
+            sums_ = torch.zeros(2, device=self._device)
+            net.train()
+            for b in range(n_train_batches):
+                th, xx = sampler.batch_clock(self._stepper.clock, *my_range(b * B, B))
+                sums_[0] += self._stepper.step(th, xx, global_batch=B).sum()
+            net.eval()
+            for b in range(n_val_batches):
+                sums_[1] += batch_losses(val_idx[b * Bv : (b + 1) * Bv], False, Bv).sum()
+            rc = _lib_mod.load().sbi_amd_train_clock_tick(_lib_mod.ptr(self._stepper.clock), None, 0, 0.0, 0.0,
+                                                          _lib_mod.current_stream(torch.device(self._device)))
+            _lib_mod.check(rc, "train_clock_tick")
+            return sums_
+
+        def capture_epoch(e: int) -> bool:
+            self._stepper.sync_clock(epoch=e)
+            torch.cuda.synchronize(self._device)
+            g = torch.cuda.CUDAGraph()
+            self._stepper._clock_mode = True
+            try:
+                with torch.cuda.graph(g):
+                    gstate["sums"] = epoch_body()
+                gstate["graph"] = g
+                return True
+            except Exception as exc:      # noqa: BLE001 -- any capture failure: keep training on the eager loop
+                warnings.warn(f"sbi_amd: the epoch could not be captured as a HIP graph ({exc!r}); NPE.train() "
+                              "continues on the eager loop", stacklevel=2)
+                gstate["failed"] = True
+                return False
+            finally:
+                self._stepper._clock_mode = False
 
         def launch_epoch(e: int) -> dict:
             """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here
             waits for the device.  Returns the record `finish_epoch` turns into the epoch's host bookkeeping."""
             rec = {"epoch": e, "t0": time.time()}
+            if graphable and gstate["warm"] and not gstate["failed"] and (gstate["graph"] is not None or capture_epoch(e)):
+                rec["ev0"] = torch.cuda.Event(enable_timing=True)
+                rec["ev0"].record()
+                gstate["graph"].replay()
+                self._graph_epochs = getattr(self, "_graph_epochs", 0) + 1
+                self._stepper.step_count += n_train_batches       # (the device clock counted them itself)
+                rec["snap"] = self._stepper.snapshot()
+                rec["host"] = host_ring[e % len(host_ring)]
+                rec["host"].copy_(gstate["sums"], non_blocking=True)
+                rec["event"] = torch.cuda.Event(enable_timing=True)
+                rec["event"].record()
+                rec["graph"] = True
+                return rec
+            gstate["warm"] = True
             if pipelined:      # the epoch's own device time (the host clock would also count the NEXT epoch's enqueue)
                 rec["ev0"] = torch.cuda.Event(enable_timing=True)
                 rec["ev0"].record()
@@ -535,7 +597,6 @@ class PosteriorEstimatorTrainer:
         #    are put back to the last epoch whose losses were finite before the AssertionError is raised;
         #  * `epoch_durations_sec` are device times between events around an epoch's own launches (the host clock
         #    would include the next epoch's enqueue).
-        pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"
         if pipelined:
             host_ring.extend(torch.empty(2, dtype=torch.float32, pin_memory=True) for _ in range(4))
         last_good = {"snap": None}
@@ -579,6 +640,10 @@ class PosteriorEstimatorTrainer:
             self._summarize(self._round)
         if cfg.show_train_summary and rank == 0:
             print(self._describe_round())
+        if gstate["graph"] is not None:
+            # replays moved the weights behind the host-side cache bookkeeping of the packed images: start clean
+            getattr(net, "net", net).__dict__.pop("_packed_cache", None)
+            gstate["graph"] = gstate["sums"] = None
         net.zero_grad(set_to_none=True)
         return deepcopy(net)
 
