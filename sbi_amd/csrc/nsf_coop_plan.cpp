@@ -4,28 +4,41 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 static int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 
 // measured cross-overs against the throughput kernels: log_prob and the sampling direction win up to
 // 12 288 rows; the training pass up to 8 192 rows (256 two-tile backward workgroups = one round; beyond, the throughput
 // backward kernel's persistent workgroups are faster)
-static int64_t g_coop_max_rows = -1, g_coop_train_rows = -1;
+// (atomics: the setter is a process-wide tuning / test hook and may race with calls on other threads; every call reads
+//  the threshold ONCE, and a training pass whose two halves would disagree is refused: nsf_train.hip, ws_family_*)
+static std::atomic<int64_t> g_coop_max_rows{-1}, g_coop_train_rows{-1};
 int64_t coop_max_rows() {
-  if (g_coop_max_rows < 0) {
+  int64_t v = g_coop_max_rows.load();
+  if (v < 0) {
     const char* a = getenv("SBI_AMD_COOP_MAX_ROWS");
-    g_coop_max_rows = a ? atoll(a) : 12288;
-    g_coop_train_rows = a ? g_coop_max_rows : 8192;      // (the environment variable and the setter move both)
+    v = a ? atoll(a) : 12288;
+    int64_t expect = -1;
+    if (g_coop_max_rows.compare_exchange_strong(expect, v))
+      g_coop_train_rows.store(a ? v : 8192);      // (the environment variable and the setter move both)
+    else
+      v = expect;
   }
-  return g_coop_max_rows;
+  return v;
 }
 int64_t coop_train_rows() {
   coop_max_rows();
-  return g_coop_train_rows;
+  int64_t t;
+  while ((t = g_coop_train_rows.load()) < 0) {}     // (the initialising thread is between its two stores)
+  return t;
 }
 // tuning / test hook: route calls of <= `rows` rows to the cooperative kernels (0: never); returns the previous value
 extern "C" int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows) {
   const int64_t prev = coop_max_rows();
-  g_coop_max_rows = g_coop_train_rows = rows < 0 ? 0 : rows;
+  const int64_t v = rows < 0 ? 0 : rows;
+  g_coop_train_rows.store(v);
+  g_coop_max_rows.store(v);
   return prev;
 }
 

@@ -162,6 +162,26 @@ extern template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, int, const
                               const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
                               long long*, hipStream_t);
 
+// Which kernel family laid out a workspace: the two halves of a training pass take the decision independently from
+// (cfg, n) and a process-wide threshold (sbi_amd_nsf_set_coop_max_rows); a backward pass that would read a stash the
+// OTHER family wrote (the threshold moved in between) is refused instead of walking a foreign layout.
+#include <mutex>
+#include <unordered_map>
+enum { WS_FAM_THROUGHPUT = 0, WS_FAM_COOP = 1, WS_FAM_GENERIC = 2 };
+static std::mutex g_ws_mu;
+static std::unordered_map<const void*, std::pair<int, int64_t>> g_ws_family;
+static void ws_family_record(const void* ws, int fam, int64_t n) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (g_ws_family.size() > 256) g_ws_family.clear();     // (workspaces are few and long-lived; bound it anyway)
+  g_ws_family[ws] = {fam, n};
+}
+// true: this workspace was last written by a forward pass of a different family / row count
+static bool ws_family_mismatch(const void* ws, int fam, int64_t n) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto it = g_ws_family.find(ws);
+  return it != g_ws_family.end() && (it->second.first != fam || it->second.second != n);
+}
+
 // forward half of the training pass: log p of every row + the per-transform state / activation stash
 extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
                                          const float* theta, const float* x, int64_t n, int64_t x_rows,
@@ -170,9 +190,11 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
   NsfPlan pl;
   {
     CoopPlan cp;
-    if (coop_applies(cfg, n, true, &pl, &cp))
+    if (coop_applies(cfg, n, true, &pl, &cp)) {
+      ws_family_record(workspace, WS_FAM_COOP, n);
       return coop_train_forward(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, theta, x, n, x_rows, logp_out,
                                 workspace, stream);
+    }
   }
   // (an E_LDS here speaks about the FORWARD kernel's 4-wave layout; the backward kernel has its own budget, checked
   // by build_train_plan, and the training forward picks its workgroup size in nsf_plan_for_rows)
@@ -181,10 +203,12 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
   TrainPlan tp;
   rc = build_train_plan(pl, n, &tp);
   if (fast_path_refuses(rc)) {
+    ws_family_record(workspace, WS_FAM_GENERIC, n);
     const int rg = nsf_g_train_forward(cfg, packed, zstats, theta, x, n, x_rows, logp_out, workspace, stream);
     return fast_path_refuses(rg) ? rc : rg;
   }
   if (rc) return rc;
+  ws_family_record(workspace, WS_FAM_THROUGHPUT, n);
   int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
   ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
   rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, workspace + o_logp, workspace + o_noise,
@@ -212,9 +236,11 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
     // small batches: ONE cooperative backward launch over all transforms, then the same fixed-order slab reduction.
     // (The workspace was laid out by the cooperative forward: both halves take the same decision from (cfg, n).)
     CoopPlan cp;
-    if (coop_applies(cfg, n, true, &pl, &cp))
+    if (coop_applies(cfg, n, true, &pl, &cp)) {
+      if (ws_family_mismatch(workspace, WS_FAM_COOP, n)) return SBI_AMD_E_BADARG;
       return coop_train_backward(cfg, pl, cp, params, packed + nsf_packed_floats(pl), zstats, x, n, x_rows, row_weight,
                                  uniform_weight, grad_out, grad_theta_out, grad_x_out, loss_out, workspace, stream);
+    }
   }
   // (an E_LDS here speaks about the FORWARD kernel's 4-wave layout; the backward kernel has its own budget, checked
   // by build_train_plan, and the training forward picks its workgroup size in nsf_plan_for_rows)
@@ -222,6 +248,7 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
   if (rc && rc != SBI_AMD_E_LDS) return rc;
   TrainPlan tp;
   rc = build_train_plan(pl, n, &tp);
+  if (ws_family_mismatch(workspace, fast_path_refuses(rc) ? WS_FAM_GENERIC : WS_FAM_THROUGHPUT, n)) return SBI_AMD_E_BADARG;
   if (fast_path_refuses(rc)) {
     if (grad_x_out) return rc;   // d loss / d embedded x comes from the wave-specialised kernel only
     if (loss_out) {

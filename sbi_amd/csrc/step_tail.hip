@@ -24,6 +24,7 @@
 // slower at 8 192 rows (partial lines written from eight L2s); profiles/r4_step_tail.txt.  The gather form writes
 // whole lines.)
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <math.h>
 #include <stdlib.h>
 #include "nsf_coop_host.h"
@@ -165,9 +166,32 @@ extern "C" int64_t sbi_amd_nsf_step_map_workspace_floats(const sbi_amd_nsf_confi
 // a fixed batch size re-packs per step).  Synchronises `stream` (one-time set-up).  `packed` must be the image buffer
 // the steps will use: it is fully packed from `params` here (constants included), so that sbi_amd_nsf_table_pack only
 // ever has to rewrite parameter-dependent positions.
+// Tables this process built: map pointer -> the configuration it was built (and verified) for.  sbi_amd_nsf_table_pack
+// launches a kernel that trusts the table's header and gather indices, so it only accepts a table registered here for
+// the SAME configuration (a table of another network, a buffer that was never built or whose build failed: E_BADARG).
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_map_mu;
+static std::unordered_map<const void*, sbi_amd_nsf_config> g_maps;
+static void st_register(const void* map, const sbi_amd_nsf_config* cfg) {
+  std::lock_guard<std::mutex> lk(g_map_mu);
+  if (g_maps.size() > 1024) g_maps.clear();
+  g_maps[map] = *cfg;
+}
+static void st_unregister(const void* map) {
+  std::lock_guard<std::mutex> lk(g_map_mu);
+  g_maps.erase(map);
+}
+static bool st_registered_for(const void* map, const sbi_amd_nsf_config* cfg) {
+  std::lock_guard<std::mutex> lk(g_map_mu);
+  auto it = g_maps.find(map);
+  return it != g_maps.end() && memcmp(&it->second, cfg, sizeof(*cfg)) == 0;
+}
+
 extern "C" int sbi_amd_nsf_build_step_map(const sbi_amd_nsf_config* cfg, int32_t images, const float* params,
                                           float* packed, int32_t* map, float* workspace, void* stream) {
   if (!cfg || !params || !packed || !map || !workspace || !(images & 3) || (images & ~3)) return SBI_AMD_E_BADARG;
+  st_unregister(map);        // (registered again only when the build below completes)
   if (!(cfg->lu_eps >= 0.f && cfg->lu_eps < 0.25f)) return SBI_AMD_E_UNSUPPORTED;   // the probe rounds softplus + eps
   NsfPlan pl;
   CoopPlan cp;
@@ -241,7 +265,9 @@ extern "C" int sbi_amd_nsf_build_step_map(const sbi_amd_nsf_config* cfg, int32_t
   // ---- the caller's image: everything (constants included) from the caller's parameters
   rc = sbi_amd_nsf_pack_images(cfg, params, packed, images, stream);
   if (rc) return rc;
-  return hipStreamSynchronize(st) == hipSuccess ? 0 : (int)hipGetLastError();
+  if (hipStreamSynchronize(st) != hipSuccess) return (int)hipGetLastError();
+  st_register(map, cfg);
+  return 0;
 }
 
 // Re-pack of the image(s) the table was built for, from the current `params`: bit-identical to
@@ -251,6 +277,8 @@ extern "C" int sbi_amd_nsf_table_pack(const sbi_amd_nsf_config* cfg, const float
   if (!cfg || !params || !packed || !map) return SBI_AMD_E_BADARG;
   const int64_t n = st_table_ints(cfg);
   if (n <= 0) return n < 0 ? (int)n : 0;
+  if (!st_registered_for(map, cfg)) return SBI_AMD_E_BADARG;   // not a table sbi_amd_nsf_build_step_map completed for cfg
+  // (the kernel takes the number of logabsdet workgroups from the table's header, h[5] = theta-dim or 0: same rule)
   const int extra = (cfg->D > 1) ? (cfg->T + 3) / 4 : 0;      // theta-dim 1 has no LULinear (ContextSplineMap)
   hipLaunchKernelGGL(nsf_table_pack_kernel, dim3(st_main_wgs((int)n) + extra), dim3(ST_THREADS), 0,
                      (hipStream_t)stream, params, packed, (const int*)map, cfg->lu_eps);

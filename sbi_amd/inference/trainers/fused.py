@@ -125,10 +125,18 @@ class FusedTrainStep:
         gb = global_batch if global_batch is not None else n * self.world
         x = self._embedded(x)
         losses, _ = self.net.train_pass(theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
-        self._grad_from_pass = True          # self.grad is exactly what the pass's reduction kernel wrote
         if self.distributed:
             all_reduce_sum(self.dist, self.grad, self.group)
+        self._mark_grad_from_pass()
         return losses
+
+    def _mark_grad_from_pass(self) -> None:
+        """self.grad is exactly what the pass's reduction kernel wrote: `apply()` may take |grad|^2 from the partial sums
+        that kernel left behind.  The tensor's version counter is remembered, so ANY later in-place torch operation on
+        `self.grad` (scaling, accumulation, ...) silently withdraws that permission -- `grad_modified()` is only needed
+        by callers that write through a raw pointer."""
+        self._grad_from_pass = True
+        self._grad_version = self.grad._version
 
     @torch.no_grad()
     def atomic_loss_and_grad(self, theta: Tensor, x: Tensor, masks: Tensor, prior, num_atoms: int,
@@ -164,9 +172,9 @@ class FusedTrainStep:
             lpp = m * lp[0] + lpp
             w[0] += m
         train_backward(self.net, x, A * B, (w / gb).reshape(-1).contiguous(), self.grad, ws)
-        self._grad_from_pass = True
         if self.distributed:
             all_reduce_sum(self.dist, self.grad, self.group)
+        self._mark_grad_from_pass()
         return -lpp
 
     def atomic_step(self, theta: Tensor, x: Tensor, masks: Tensor, prior, num_atoms: int,
@@ -245,7 +253,8 @@ class FusedTrainStep:
 
         rows = getattr(self, "_last_rows", None)
         if (type(self.net) is not NSFNet or rows is None or self.world != 1 or self.workspace is None
-                or not getattr(self, "_grad_from_pass", False) or os.environ.get("SBI_AMD_NORM_RIDER", "1") == "0"):
+                or not getattr(self, "_grad_from_pass", False) or self.grad._version != getattr(self, "_grad_version", -1)
+                or os.environ.get("SBI_AMD_NORM_RIDER", "1") == "0"):
             return None
         n_parts = ctypes.c_int64(0)
         ptr = _lib.load().sbi_amd_nsf_train_sqnorm_parts(self.net.hyper.c_config(), int(rows), _lib.ptr(self.workspace),

@@ -253,7 +253,10 @@ class PosteriorEstimatorTrainer:
     def _bcast(self, t: Tensor) -> Tensor:
         d = self._dist()
         if d is not None:
-            backend_dev = self._device if d.get_backend() == "nccl" else "cpu"
+            from sbi_amd.utils.collectives import _direct
+
+            buf = t.to(self._device)
+            backend_dev = self._device if (buf.device.type == "cuda" and _direct(d, buf)) else "cpu"
             buf = t.to(backend_dev)
             d.broadcast(buf, src=0)
             t = buf.to(t.device)
@@ -557,9 +560,17 @@ class PosteriorEstimatorTrainer:
                 # flight behind this one that is enough for the device to run dry (measured through bench.py's npe_train
                 # leg: 1.35 - 1.38 ms per epoch on two boxes, 1.00 on two others, with IDENTICAL per-launch enqueue
                 # times).  The loop spins for at most the remainder of one epoch.  SBI_AMD_EVENT_SPIN=0: the blocking wait.
+                # The spin is BOUNDED (it holds the GIL and a core): a few multiples of the previous epoch's device time,
+                # at least 2 ms and at most 50 ms, then the blocking wait takes over -- long epochs (where the wake-up
+                # latency is noise) and a hung device end up sleeping, not spinning.  SBI_AMD_EVENT_SPIN=0: never spin.
                 if _os.environ.get("SBI_AMD_EVENT_SPIN", "1") != "0":
+                    durs = self._summary["epoch_durations_sec"]
+                    budget = min(0.05, max(0.002, 4.0 * durs[-1])) if durs else 0.002
+                    t_spin = time.perf_counter()
                     while not rec["event"].query():
-                        pass
+                        if time.perf_counter() - t_spin > budget:
+                            rec["event"].synchronize()
+                            break
                 else:
                     rec["event"].synchronize()
             host = rec["host"]

@@ -15,11 +15,28 @@ import torch
 from torch import Tensor
 
 
+_warned_staged = False
+
+
 def _direct(dist, t: Tensor, group=None) -> bool:
-    """True when the group's backend reduces / broadcasts `t` where it lives."""
+    """True when the group's backend reduces / broadcasts `t` where it lives.  Decided by capability: a device tensor
+    is staged through the host only for a backend known to lack device support (pure `gloo`); `nccl`, the composite
+    `cpu:gloo,cuda:nccl` a bare `init_process_group()` creates, and anything unknown get the tensor as it is.  The
+    staged path costs two synchronising copies per call, so it announces itself once."""
+    global _warned_staged
     if t.device.type == "cpu":
         return True
-    return dist.get_backend(group) == "nccl"
+    backend = str(dist.get_backend(group)).lower()
+    if "nccl" in backend or backend not in ("gloo", "cpu:gloo"):
+        return True
+    if not _warned_staged:
+        import warnings
+
+        warnings.warn("sbi_amd: the process group's backend is gloo: device buffers are staged through the host for every "
+                      "collective (two synchronising copies per call); use backend 'nccl' (RCCL) for data-parallel "
+                      "training on ROCm devices", stacklevel=3)
+        _warned_staged = True
+    return False
 
 
 def all_reduce_sum(dist, t: Tensor, group=None) -> Tensor:

@@ -76,6 +76,11 @@ def test_log_prob_65536_matches_oracle(mode):
           f"{ro64['worst_scaled']:.2f}, beyond {ro64['exceed_frac']:.3%}")
     assert rp["exceed_frac"] <= 0.01 and rp["worst_scaled"] <= 4.0, rp
     assert rp64["exceed_frac"] <= 0.01 and rp64["worst_scaled"] <= 4.0, rp64
+    # north_star's "within 1e-5" read ABSOLUTELY, against the fp64 evaluation: >= 99 % of the 65 536 rows (round 5: the
+    # spline's selected bin is re-derived with the softmax denominator / prefix sum in fp64, csrc/nsf_device.h
+    # precise_bin; measured 0.2 % beyond -- the eager fp32 oracle itself: 9 %, which is also what bounds hip vs o32)
+    assert rp64["abs_exceed_frac"] <= 0.01, rp64
+    assert rp64["abs_exceed_frac"] <= 0.5 * ro64["abs_exceed_frac"] + 1e-3, (rp64, ro64)   # strictly closer than eager fp32
 
 
 def test_sample_from_noise_65536_matches_oracle():

@@ -108,6 +108,8 @@ def test_trained_log_prob_matches_oracle(name, mode, family):
     assert rp64["exceed_frac"] <= 0.01 and rp64["worst_scaled"] <= 4.0, rp64
     # no further from the fp64 evaluation than the eager fp32 oracle is
     assert rp64["max_abs"] <= 2.0 * ro64["max_abs"] + 1e-5
+    # |hip - fp64| <= 1e-5 ABSOLUTE on >= 99 % of the rows (measured: <= 0.4 %, the eager fp32 oracle 1 - 7 %)
+    assert rp64["abs_exceed_frac"] <= 0.01, rp64
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
