@@ -299,18 +299,38 @@ __device__ __forceinline__ float softplus_bf(float x) {
 // 2+4b t2, 3+4b sigmoid(gate), 4+4b h_{b+1}.  The backward kernel reloads them instead of
 // recomputing the conditioner (trading ~0.75 GB/step of HBM traffic for 480 MFMAs per 16 rows).
 #define NSF_AST_SLOTS(NB) (1 + 4 * (NB))   // residual-net conditioner with NB blocks (ctx_mlp: nsf_ast_slots(pl), nsf_plan.h)
+// hidden <= 52 (KSH == 13, sbi's default 50): of the fourth m-tile only register 0 is real (features 48 + g; features
+// 52 ... 63 are padding: zero, or sigmoid(0) for the gate, and nothing downstream depends on them) -- it is stored as
+// ONE float per lane (256 B per wave) behind three full tiles: a slot is 832 floats instead of 1 024, -19 % of the
+// stash's write (forward) and read (backward) traffic.  The tile stride (slots x 1 024 floats) is unchanged: the saved
+// bytes are gaps at the end of every tile's block.
+template <int KSH>
+__device__ __forceinline__ constexpr int ast_slot_floats() { return KSH == 13 ? 3 * 256 + 64 : 4 * 256; }
+template <int KSH>
 __device__ __forceinline__ void ast_store(float* __restrict__ ast, int slot, const f4 (&v)[NSF_HT]) {
+  float* base = ast + slot * ast_slot_floats<KSH>();
 #pragma unroll
   for (int mt = 0; mt < NSF_HT; ++mt) {
     // streaming (written once by the forward, read once by the backward): keep it out of L2, which the
     // packed weight image lives in (measured -5 % step time)
-    __builtin_nontemporal_store(v[mt], reinterpret_cast<f4*>(ast + (slot * 4 + mt) * 256));
+    if (KSH == 13 && mt == NSF_HT - 1)
+      __builtin_nontemporal_store(v[mt][0], base + mt * 256 - 3 * (int)(threadIdx.x & 63));   // (ast includes 4 * lane)
+    else
+      __builtin_nontemporal_store(v[mt], reinterpret_cast<f4*>(base + mt * 256));
   }
 }
+template <int KSH>
 __device__ __forceinline__ void ast_load(const float* __restrict__ ast, int slot, f4 (&v)[NSF_HT]) {
+  const float* base = ast + slot * ast_slot_floats<KSH>();
 #pragma unroll
-  for (int mt = 0; mt < NSF_HT; ++mt)
-    v[mt] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ast + (slot * 4 + mt) * 256));
+  for (int mt = 0; mt < NSF_HT; ++mt) {
+    if (KSH == 13 && mt == NSF_HT - 1) {
+      const float r0 = __builtin_nontemporal_load(base + mt * 256 - 3 * (int)(threadIdx.x & 63));
+      v[mt] = f4{r0, 0.f, 0.f, 0.f};
+    } else {
+      v[mt] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + mt * 256));
+    }
+  }
 }
 
 // BX (one condition row for the whole launch: every sampler / potential call): everything that depends on the context
@@ -342,7 +362,7 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.f);
-    if (ast) ast_store(ast, 0, h);
+    if (ast) ast_store<KSH>(ast, 0, h);
     for (int i = 0; i < pl.ctx_reps; ++i) {
       acc_init_bias(lds, S.lin[1], id, u);
       gemm_breg<KSH>(lds, S.lin[1], id, h, u);
@@ -350,11 +370,11 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
       for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(u[mt][r], 0.f);
-      if (ast) ast_store(ast, 1 + i, h);
+      if (ast) ast_store<KSH>(ast, 1 + i, h);
     }
     return;
   }
-  if (ast) ast_store(ast, 0, h);
+  if (ast) ast_store<KSH>(ast, 0, h);
   for (int b = 0; b < pl.NB; ++b) {
     f4 gate[NSF_HT], t[NSF_HT], u[NSF_HT];
     if (BX) {
@@ -378,19 +398,19 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
     }
     acc_init_bias(lds, S.lin[2 + 3 * b], id, u);
     gemm_breg<KSH>(lds, S.lin[2 + 3 * b], id, t, u);
-    if (ast) { ast_store(ast, 1 + 4 * b, u); ast_store(ast, 3 + 4 * b, gate); }
+    if (ast) { ast_store<KSH>(ast, 1 + 4 * b, u); ast_store<KSH>(ast, 3 + 4 * b, gate); }
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[mt][r] = fmaxf(u[mt][r], 0.f);
     acc_init_bias(lds, S.lin[3 + 3 * b], id, t);
     gemm_breg<KSH>(lds, S.lin[3 + 3 * b], id, u, t);
-    if (ast) ast_store(ast, 2 + 4 * b, t);
+    if (ast) ast_store<KSH>(ast, 2 + 4 * b, t);
 #pragma unroll
     for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[mt][r] += t[mt][r] * gate[mt][r];
-    if (ast) ast_store(ast, 4 + 4 * b, h);
+    if (ast) ast_store<KSH>(ast, 4 + 4 * b, h);
   }
 }
 

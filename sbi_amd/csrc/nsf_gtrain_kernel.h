@@ -139,7 +139,7 @@ nsf_gbwd_kernel(const NsfPlan pl, const GTrainPlan gp, const GBwdArgs a) {
   for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = {0.f, 0.f, 0.f, 0.f};
   {
     f4 hl[NSF_HT];
-    ast_load(ast, 4 * NB, hl);
+    ast_load<KSH>(ast, 4 * NB, hl);
     gt_store_rows(a.ACT, gp.act_w, row, valid, id, hl, false);
     const LinDesc& LF = S.lin[S.fin];
     const int nchunks = (S.d_tr + 1) / 2;
@@ -183,10 +183,10 @@ nsf_gbwd_kernel(const NsfPlan pl, const GTrainPlan gp, const GBwdArgs a) {
   // ---- residual blocks, last -> first (activations from the forward's stash, one block in registers at a time)
   for (int b = NB - 1; b >= 0; --b) {
     f4 bt1[NSF_HT], bt2[NSF_HT], bsg[NSF_HT], hb[NSF_HT], ga[NSF_HT], gb[NSF_HT];
-    ast_load(ast, 2 + 4 * b, bt2);
-    ast_load(ast, 3 + 4 * b, bsg);
-    ast_load(ast, 1 + 4 * b, bt1);
-    ast_load(ast, 4 * b, hb);
+    ast_load<KSH>(ast, 2 + 4 * b, bt2);
+    ast_load<KSH>(ast, 3 + 4 * b, bsg);
+    ast_load<KSH>(ast, 1 + 4 * b, bt1);
+    ast_load<KSH>(ast, 4 * b, hb);
     {
       f4 gc[NSF_HT];
 #pragma unroll

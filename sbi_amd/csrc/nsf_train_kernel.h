@@ -876,12 +876,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       // ---- step nch (the grad waves finish d Wf / Wf^T g of the last chunk): fetch the last block's
       // temporaries and do the LULinear forward piece its parameter gradients need, u = U y
       if (cm) {     // the last application's input and output: h_reps, h_{reps+1} (stash slots reps - 1, reps)
-        ast_load(ast, reps > 0 ? reps - 1 : 0, hpre[0]);
-        if (reps > 0) ast_load(ast, reps, hpre[1]);
+        ast_load<KSH>(ast, reps > 0 ? reps - 1 : 0, hpre[0]);
+        if (reps > 0) ast_load<KSH>(ast, reps, hpre[1]);
       } else {
-        ast_load(ast, 2 + 4 * (NB - 1), bt2);
-        ast_load(ast, 3 + 4 * (NB - 1), bsg);
-        ast_load(ast, 1 + 4 * (NB - 1), bt1);
+        ast_load<KSH>(ast, 2 + 4 * (NB - 1), bt2);
+        ast_load<KSH>(ast, 3 + 4 * (NB - 1), bsg);
+        ast_load<KSH>(ast, 1 + 4 * (NB - 1), bt1);
       }
       float us_r[4] = {0.f, 0.f, 0.f, 0.f};
       if (!cm && !(pl_.ablate & 64)) {     // u[i] = sum_k U[i][k] y[k] on the matrix pipe: K-step s covers k = 4 s + g
@@ -923,8 +923,8 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         f4 ga[NSF_HT], gb[NSF_HT];
         for (int i = reps; i >= 1; --i) {
           if (i < reps) {           // (the first iteration's operands were requested before the H barrier)
-            ast_load(ast, i - 1, hpre[0]);
-            ast_load(ast, i, hpre[1]);
+            ast_load<KSH>(ast, i - 1, hpre[0]);
+            ast_load<KSH>(ast, i, hpre[1]);
             __syncthreads();        // X0: the previous application's d W_h has consumed the tiles
           }
 #pragma unroll
@@ -967,10 +967,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           }
           stage_DB(Bt, SB, trow, id, bt1, true);
           if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;      // bias column
-          ast_load(ast, 4 * b, hpre[0]);                  // h_b: needed two phases from now
+          ast_load<KSH>(ast, 4 * b, hpre[0]);                  // h_b: needed two phases from now
           if (b > 0) {   // next (earlier) block's t2 / gate: fetch under this block's GEMM phases
-            ast_load(ast, 2 + 4 * (b - 1), bt2);
-            ast_load(ast, 3 + 4 * (b - 1), bsg);
+            ast_load<KSH>(ast, 2 + 4 * (b - 1), bt2);
+            ast_load<KSH>(ast, 3 + 4 * (b - 1), bsg);
           }
           TS(20 + 8 * b);
           __syncthreads();                         // X1: (g_t2, relu t1) and (g_c, Bs) published
@@ -982,7 +982,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ga[mt][r] = bt1[mt][r] > 0.f ? gb[mt][r] : 0.f;   // d t1
-          if (b > 0) ast_load(ast, 1 + 4 * (b - 1), bt1);
+          if (b > 0) ast_load<KSH>(ast, 1 + 4 * (b - 1), bt1);
           TS(22 + 8 * b);
           __syncthreads();                         // X2: d W2 / d Wc done, tiles free
           TS(23 + 8 * b);
@@ -1080,7 +1080,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
       const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
                          4 * id0.lane;
-      ast_load(ast, cm ? reps : 4 * NB, hl);
+      ast_load<KSH>(ast, cm ? reps : 4 * NB, hl);
     };
     fetch_hl(blockIdx.x);
     for (int tile = blockIdx.x; tile < tp_.ntiles; tile += gridDim.x) {

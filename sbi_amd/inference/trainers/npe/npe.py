@@ -448,17 +448,20 @@ class PosteriorEstimatorTrainer:
         pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"      # (why: see the loop below)
         from sbi_amd import _lib as _lib_mod
 
-        # Epochs as HIP graphs: after one eager epoch (which sizes the workspace, builds the re-pack table and
-        # leaves the allocator warm) the epoch's device work -- per batch: gather, forward, T backward launches,
-        # reduction, clip + Adam, re-pack; then the validation pass and the loss sums -- is captured ONCE and replayed
-        # with one host call per epoch.  Nothing in it depends on the host: the sampler's epoch number and Adam's step
-        # count live in device memory (`FusedTrainStep.clock`, ticked by the graph itself).  What stays outside the
-        # graph: the snapshot of the weights / optimizer state (every in-flight epoch record needs its own copy), the
-        # read-back of the two loss sums and the events.  Not captured (the eager loop runs): the atomic loss and
-        # validation orders that need fresh random numbers, more than one rank, index-path data.
-        # SBI_AMD_GRAPH_EPOCH=0 switches it off (A/B).
+        # Epochs as HIP graphs, OPT-IN (SBI_AMD_GRAPH_EPOCH=1): after one eager epoch (which sizes the
+        # workspace, builds the re-pack table and leaves the allocator warm) the epoch's device work -- per batch: gather,
+        # forward, T backward launches, reduction, clip + Adam, re-pack; then the validation pass and the loss sums -- is
+        # captured ONCE and replayed with one host call per epoch.  Nothing in it depends on the host: the sampler's
+        # epoch number and Adam's step count live in device memory (`FusedTrainStep.clock`, ticked by the graph itself).
+        # What stays outside the graph: the snapshot of the weights / optimizer state (every in-flight epoch record needs
+        # its own copy), the read-back of the two loss sums and the events.  Not captured (the eager loop runs): the
+        # atomic loss and validation orders that need fresh random numbers, more than one rank, index-path data.
+        # Results are bit-identical to the eager loop (tests/test_graph_epoch_gpu.py).  Why it is not the default:
+        # measured on MI355X / ROCm 7.2 (profiles/r5_bench.json, `npe_train.*.hip_graph_epochs`) a replayed kernel
+        # node costs MORE than a stream launch -- 72.0 vs 63.5 ms per epoch at sbi's default batch 200 (450 steps, ~3 200
+        # nodes), 1.07 vs 1.00 ms at batch 65 536 -- so the graph only pays where the HOST cannot keep the stream fed.
         graphable = (pipelined and sampler is not None and not atomic and d is None and n_val_batches * Bv == n_val
-                     and _os.environ.get("SBI_AMD_GRAPH_EPOCH", "1") != "0")
+                     and _os.environ.get("SBI_AMD_GRAPH_EPOCH", "0") == "1")
         gstate = {"graph": None, "sums": None, "warm": False, "failed": False}
 
         def epoch_body() -> Tensor:

@@ -56,9 +56,9 @@ def test_log_prob_one_x_o(cfg, n):
     rp, rs = row_parity(got, ref), row_parity(got, per_row)
     print(f"{_ids(cfg)} n={n}: vs oracle worst {rp['worst_scaled']:.2f} x bound ({rp['exceed_frac']:.3%} beyond), vs the "
           f"per-row kernels worst {rs['worst_scaled']:.2f} x bound, max |d| {rs['max_abs']:.2e}")
-    assert rp["exceed_frac"] <= 0.01 and rp["worst_scaled"] <= 4.0, rp
-    assert rs["exceed_frac"] <= 0.01 and rs["worst_scaled"] <= 4.0, rs
-    assert not torch.equal(got, per_row) or n < 1000 or True      # (re-associated sums: equality is not required)
+    few = max(0.01, 1.5 / n)        # (one row of 60 is already 1.7 %)
+    assert rp["exceed_frac"] <= few and rp["worst_scaled"] <= 4.0, rp
+    assert rs["exceed_frac"] <= few and rs["worst_scaled"] <= 4.0, rs
 
 
 @pytest.mark.parametrize("n", [60, 20000])

@@ -1,4 +1,4 @@
-"""`NPE.train()` with its epochs captured as HIP graphs (the reference's loop is
+"""`NPE.train()` with its epochs captured as HIP graphs (opt-in: SBI_AMD_GRAPH_EPOCH=1) (the reference's loop is
 sbi/inference/trainers/base.py:1150-1225) against the same call on the eager pipelined loop: same seeds => the same
 sampler orders (the kernel derives the epoch key from the device clock exactly as the host does), the same steps, the
 same early-stopping decisions.  The only arithmetic that differs is Adam's bias correction (1 - beta^step evaluated
