@@ -168,6 +168,16 @@ int sbi_amd_shuffled_gather(const float* a, int32_t da, const float* b, int32_t 
                             int64_t n_perm, uint64_t key, int64_t offset, int64_t count, float* a_out, float* b_out,
                             int64_t* idx_out, void* stream);
 
+/* Data parallelism and this ABI.  SURVEY 8(b) sketched an `allreduce_flat` export; it is deliberately NOT here.  The
+ * training pass leaves d( sum_n w_n loss_n ) / d params of the rank's rows in ONE flat buffer (grad_out), with the
+ * 1 / global_batch weighting already inside the kernels (uniform_weight / row_weight), so the whole collective of a step
+ * is a single SUM all-reduce of `param_count` floats between sbi_amd_nsf_loss_fwd_bwd and sbi_amd_adam_clip_step, in stream
+ * order.  The communicator (rank discovery, bootstrap, xGMI topology, the lifetime of an ncclComm_t) belongs to the
+ * host process's launcher -- `torch.distributed` with backend "nccl" (= RCCL) in sbi_amd/inference/trainers/fused.py,
+ * `ncclAllReduce(grad, grad, P, ncclFloat, ncclSum, comm, stream)` for a C caller -- and wrapping that one call would
+ * only add a second owner for the communicator.  Replicas that apply sbi_amd_adam_clip_step to identical reduced
+ * gradients stay bit-identical (csrc/adam_math.h pins the roundings). */
+
 /* Epochs as HIP graphs (trainers/base.py:1150-1225 is a Python loop over DataLoader batches).  A captured
  * launch must not depend on anything the host changes from epoch to epoch; two things in a training step do -- the
  * sampler's per-epoch key and Adam's step count.  Both move to device memory:

@@ -179,6 +179,32 @@ __device__ __forceinline__ void stage_layer(float* __restrict__ lds, const float
   for (; idx < n4; idx += nthreads) dst[idx] = src[idx];
 }
 
+// The same copy in two halves, for kernels that know the image size at compile time: the loads are issued EARLY (under
+// the LULinear phase of the transform before) into NPRE float4 registers per thread, the LDS stores happen between the
+// two barriers -- the L2 round trip no longer sits on the barrier-to-barrier critical path of every transform.
+template <int NPRE>
+__device__ __forceinline__ void stage_issue(const float* __restrict__ img, int img_floats, int tid, int nthreads,
+                                            float4 (&pre)[NPRE]) {
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(img);
+  const int n4 = img_floats >> 2;
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int idx = tid + i * nthreads;
+    pre[i] = idx < n4 ? src[idx] : float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NPRE>
+__device__ __forceinline__ void stage_commit(float* __restrict__ lds, int img_floats, int tid, int nthreads,
+                                             const float4 (&pre)[NPRE]) {
+  float4* dst = reinterpret_cast<float4*>(lds);
+  const int n4 = img_floats >> 2;
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int idx = tid + i * nthreads;
+    if (idx < n4) dst[idx] = pre[i];
+  }
+}
+
 // ---- MFMA GEMM pieces ------------------------------------------------------
 __device__ __forceinline__ void acc_init_bias(const float* __restrict__ lds, const LinDesc& L, const LaneId& id,
                                               f4 (&acc)[NSF_HT]) {

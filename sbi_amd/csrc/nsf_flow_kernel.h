@@ -18,6 +18,9 @@
 // SP instantiations take every offset / stride / count from these and only the floating-point constants and debug
 // switches from the kernel argument.  One static plan per workgroup shape: 8 waves (density direction at >= 32 768
 // rows), 12 waves (sampling direction at >= 49 152 rows).
+#ifndef NSF_FLOW_PREFETCH
+#define NSF_FLOW_PREFETCH 1      // A/B: -DNSF_FLOW_PREFETCH=0 in SBI_AMD_EXTRA_HIPCC_FLAGS
+#endif
 constexpr sbi_amd_nsf_config kFlowDefaultCfg = {10, 10, 50, 10, 5, 2, 3.0f, 1e-3f, 1e-3f, 1e-3f, 1e-3f};
 constexpr NsfPlan nsf_make_static_flow_plan(int nw) {
   NsfPlan p{};
@@ -77,6 +80,12 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
+  // static-plan density kernels: the next transform's image is requested into registers one phase early (stage_issue)
+  constexpr bool PREF = (SP == 8) && !INV && NSF_FLOW_PREFETCH;
+  constexpr int NPRE = PREF ? (kStaticFlow8.img_floats / 4 + 511) / 512 : 1;
+  float4 pre[NPRE];
+  const bool pref_on = PREF && !(pl_.ablate & 0x200000);     // (SBI_AMD_ABLATE bit 0x200000: A/B on one build)
+  if (pref_on) stage_issue<NPRE>(packed, pl.img_floats, tid, nthreads, pre);   // transform 0 (density direction: t = li)
   float* bxt = lds + pl.lds_w_floats + nw * pl.sc_total;   // BX: [64 (1 + NB)] table, then the standardized condition row
   float* cstd = bxt + 64 * (1 + pl.NB);
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
@@ -124,7 +133,9 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
     TSF(0);
     __syncthreads();   // every wave is done with the previous layer's weights
     TSF(1);
-    if (!(pl_.ablate & 16) || li == 0)
+    if (pref_on)
+      stage_commit<NPRE>(lds, pl.img_floats, tid, nthreads, pre);
+    else if (!(pl_.ablate & 16) || li == 0)
       stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
     if (BX) bx_fold_context(packed + (long long)t * pl.img_floats, pl, S, cstd, bxt, tid, nthreads);
     TSF(2);
@@ -227,6 +238,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       }
     }
     TSF(20);
+    if (pref_on && li + 1 < pl.T)      // the NEXT transform's image: in flight under LULinear and the wait at the barrier
+      stage_issue<NPRE>(packed + (long long)(t + 1) * pl.img_floats, pl.img_floats, tid, nthreads, pre);
     if (!INV && has_lu && !(pl_.ablate & 8)) {
       lu_forward(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
