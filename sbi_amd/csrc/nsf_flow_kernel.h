@@ -21,6 +21,9 @@
 #ifndef NSF_FLOW_PREFETCH
 #define NSF_FLOW_PREFETCH 1      // A/B: -DNSF_FLOW_PREFETCH=0 in SBI_AMD_EXTRA_HIPCC_FLAGS
 #endif
+#ifndef NSF_INV_PREFETCH
+#define NSF_INV_PREFETCH 6       // float4 per thread (of 8) the 12-wave sampling kernel requests early; per-row variant: half
+#endif
 constexpr sbi_amd_nsf_config kFlowDefaultCfg = {10, 10, 50, 10, 5, 2, 3.0f, 1e-3f, 1e-3f, 1e-3f, 1e-3f};
 constexpr NsfPlan nsf_make_static_flow_plan(int nw) {
   NsfPlan p{};
@@ -80,12 +83,19 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
-  // static-plan density kernels: the next transform's image is requested into registers one phase early (stage_issue)
-  constexpr bool PREF = (SP == 8) && !INV && NSF_FLOW_PREFETCH;
-  constexpr int NPRE = PREF ? (kStaticFlow8.img_floats / 4 + 511) / 512 : 1;
+  // static-plan kernels: the next transform's image is requested into registers one phase early (stage_issue): the
+  // density direction under its LULinear phase, the sampling direction (12 waves) under its last spline chunk
+  constexpr bool PREF = ((SP == 8 && !INV) || (SP == 12 && INV)) && NSF_FLOW_PREFETCH;
+  // density kernel (512 threads, 256 VGPRs each): the whole image, 11 float4 per thread; sampling kernel (768 threads,
+  // 170 VGPRs each): the first NSF_INV_PREFETCH float4 per thread early, the rest at the barrier as before
+  constexpr int NFULL = ((SP == 8 ? kStaticFlow8 : kStaticFlow12).img_floats / 4 + 64 * (SP ? SP : 1) - 1) / (64 * (SP ? SP : 1));
+  constexpr int NINV = BX ? NSF_INV_PREFETCH : NSF_INV_PREFETCH / 2;      // (register budget: 164 / 167 of 170 VGPRs, no spills)
+  constexpr int NPRE = !PREF ? 1 : (INV ? (NINV < NFULL ? NINV : NFULL) : NFULL);
   float4 pre[NPRE];
-  const bool pref_on = PREF && !(pl_.ablate & 0x200000);     // (SBI_AMD_ABLATE bit 0x200000: A/B on one build)
-  if (pref_on) stage_issue<NPRE>(packed, pl.img_floats, tid, nthreads, pre);   // transform 0 (density direction: t = li)
+  constexpr bool pref_on = PREF;      // (A/B: rebuild with -DNSF_FLOW_PREFETCH=0; a run-time switch keeps both copies alive
+                                      //  and costs the density kernel its last free registers: 9 spills)
+  if (pref_on)      // the first transform's image (density: t = 0; sampling: t = T - 1)
+    stage_issue<NPRE>(packed + (long long)(INV ? pl.T - 1 : 0) * pl.img_floats, pl.img_floats, tid, nthreads, pre);
   float* bxt = lds + pl.lds_w_floats + nw * pl.sc_total;   // BX: [64 (1 + NB)] table, then the standardized condition row
   float* cstd = bxt + 64 * (1 + pl.NB);
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
@@ -133,8 +143,12 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
     TSF(0);
     __syncthreads();   // every wave is done with the previous layer's weights
     TSF(1);
-    if (pref_on)
+    if (pref_on) {
       stage_commit<NPRE>(lds, pl.img_floats, tid, nthreads, pre);
+      if (NPRE < NFULL)      // the part of the image that was not prefetched
+        stage_layer(lds + 4 * NPRE * nthreads, packed + (long long)t * pl.img_floats + 4 * NPRE * nthreads,
+                    pl.img_floats - 4 * NPRE * nthreads, tid, nthreads);
+    }
     else if (!(pl_.ablate & 16) || li == 0)
       stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
     if (BX) bx_fold_context(packed + (long long)t * pl.img_floats, pl, S, cstd, bxt, tid, nthreads);
@@ -200,6 +214,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
         for (int c = 0; c < nchunks; ++c) {
           int nn = S.d_tr - c * pl.DCH;
           nn = nn < pl.DCH ? nn : pl.DCH;
+          if (INV && pref_on && c == nchunks - 1 && li + 1 < pl.T)      // sampling direction: next image = transform t - 1
+            stage_issue<NPRE>(packed + (long long)(t - 1) * pl.img_floats, pl.img_floats, tid, nthreads, pre);
           if (nn == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, c * pl.DCH);
           else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, c * pl.DCH);
           wave_lds_fence();
@@ -238,7 +254,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       }
     }
     TSF(20);
-    if (pref_on && li + 1 < pl.T)      // the NEXT transform's image: in flight under LULinear and the wait at the barrier
+    if (!INV && pref_on && li + 1 < pl.T)      // the NEXT transform's image: in flight under LULinear and the wait at the barrier
       stage_issue<NPRE>(packed + (long long)(t + 1) * pl.img_floats, pl.img_floats, tid, nthreads, pre);
     if (!INV && has_lu && !(pl_.ablate & 8)) {
       lu_forward(lds, pl, S, id, zs, us);
