@@ -105,3 +105,36 @@ def test_fmpe_two_rank_data_parallel_matches_single_process():
     assert (f0 - ref_flat).abs().max() <= 1e-5 * max(1.0, ref_flat.abs().max().item())
     assert len(v0) == len(ref_summary["validation_loss"])
     assert max(abs(a - b) for a, b in zip(v0, ref_summary["validation_loss"])) < 1e-5
+
+
+def test_collectives_choose_the_staged_path_by_capability_not_by_name():
+    """a group whose backend string is not literally "nccl" (the composite `cpu:gloo,cuda:nccl` of a bare
+    `init_process_group()`, or something unknown) must get device tensors as they are; only pure gloo is staged through
+    the host, and says so once."""
+    import warnings
+
+    from sbi_amd.utils import collectives
+
+    class FakeDist:
+        def __init__(self, backend):
+            self.backend = backend
+
+        def get_backend(self, group=None):
+            return self.backend
+
+    class FakeDeviceTensor:       # (no ROCm device in the CPU suite: only `.device.type` is looked at)
+        class device:
+            type = "cuda"
+
+    t = FakeDeviceTensor()
+    for backend in ("nccl", "cpu:gloo,cuda:nccl", "NCCL", "ucc", "custom"):
+        assert collectives._direct(FakeDist(backend), t), backend
+    collectives._warned_staged = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert not collectives._direct(FakeDist("gloo"), t)
+        assert not collectives._direct(FakeDist("gloo"), t)
+    assert sum("staged through the host" in str(x.message) for x in w) == 1
+    import torch
+
+    assert collectives._direct(FakeDist("gloo"), torch.zeros(1))      # host tensors never need staging

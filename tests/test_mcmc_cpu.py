@@ -71,3 +71,76 @@ def test_sampler_and_posterior_fail_loudly_without_a_gpu():
         post.sample((3,))
     assert post.thin == 1 and post.mcmc_method == "slice_np_vectorized"
     assert post.set_mcmc_method("slice_np").mcmc_method == "slice_np"
+
+
+def test_mcmc_transform_decision_table_edges():
+    """Priors that publish less than torch's distributions do (sbi/utils/sbiutils.py:867-980): no `.support` -> z-scoring
+    with a warning; no `.mean` / `.stddev` -> moments from prior draws with a warning; a transform that does not round
+    trip is refused by `check_transform`."""
+    import warnings
+
+    import pytest
+    from torch.distributions import MultivariateNormal
+    from torch.distributions.transforms import AffineTransform, IndependentTransform
+
+    from sbi_amd.utils.sbiutils import check_transform
+
+    base = MultivariateNormal(torch.tensor([1.0, -2.0]), torch.diag(torch.tensor([4.0, 0.25])))
+
+    class NoSupport:
+        mean, stddev = base.mean, base.stddev
+
+        def sample(self, shape=torch.Size()):
+            return base.sample(shape)
+
+        @property
+        def support(self):
+            raise NotImplementedError
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tf = mcmc_transform(NoSupport())
+    assert any("no support property" in str(x.message) for x in w)
+    th = torch.tensor([[1.0, -2.0], [3.0, -1.5]])
+    assert torch.allclose(tf(th), (th - base.mean) / base.stddev)
+
+    class NoMoments:
+        support = base.support
+
+        def sample(self, shape=torch.Size()):
+            return base.sample(shape)
+
+        @property
+        def mean(self):
+            raise NotImplementedError
+
+    torch.manual_seed(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tf2 = mcmc_transform(NoMoments(), num_prior_samples_for_zscoring=20000)
+    assert any("estimating them from samples" in str(x.message) for x in w)
+    assert (tf2(th) - (th - base.mean) / base.stddev).abs().max() < 0.1
+
+    broken = IndependentTransform(AffineTransform(torch.zeros(2), torch.tensor([1.0, 0.0])), 1)     # scale 0: not invertible
+    with pytest.raises(AssertionError, match="re-transformed"):
+        check_transform(base, broken)
+
+
+def test_gradient_ascent_bookkeeping():
+    """The incumbent is only replaced by a better point, the start is the best initial point, and `num_to_optimize`
+    larger than the number of inits is harmless."""
+    from torch.distributions import MultivariateNormal
+
+    from sbi_amd.utils.sbiutils import gradient_ascent, handle_invalid_x
+
+    target = MultivariateNormal(torch.tensor([0.5, -0.5]), 0.2 * torch.eye(2))
+    inits = torch.tensor([[0.5, -0.5], [3.0, 3.0], [-2.0, 1.0]])        # the first one IS the maximum
+    arg, val = gradient_ascent(target.log_prob, inits, num_iter=5, num_to_optimize=10, learning_rate=0.1)
+    assert torch.allclose(arg.reshape(-1), torch.tensor([0.5, -0.5])) and torch.allclose(val, target.log_prob(inits[:1])[0])
+    arg2, val2 = gradient_ascent(target.log_prob, inits[1:], num_iter=300, num_to_optimize=2, learning_rate=0.05)
+    assert (arg2.reshape(-1) - torch.tensor([0.5, -0.5])).abs().max() < 0.05 and val2 > target.log_prob(inits[1:]).max()
+    x = torch.tensor([[1.0, 2.0], [float("nan"), 0.0], [float("inf"), 1.0], [0.0, float("-inf")]])
+    keep, n_nan, n_inf = handle_invalid_x(x)
+    assert keep.tolist() == [True, False, False, False] and (n_nan, n_inf) == (1, 2)
+    keep_all, _, _ = handle_invalid_x(x, exclude_invalid_x=False)
+    assert keep_all.all()
