@@ -85,70 +85,59 @@ class DirectPosterior:
         return self
 
     # -- sampling -----------------------------------------------------------------------
+    def _batch_cap(self, requested: Optional[int]) -> int:
+        return self.max_sampling_batch_size if requested is None else requested
+
+    def _draw(self, how_many: int, x: Tensor, batch_cap: int, show_progress_bars: bool, reject_outside_prior: bool,
+              max_sampling_time: Optional[float], return_partial_on_timeout: bool) -> Tensor:
+        """(<= how_many, B, D) draws for the B condition rows of `x`: candidates from the estimator (one launch of the
+        sampling kernel per proposal batch, x never expanded), kept when inside the prior support
+        (direct_posterior.py:177-213 -> rejection.py:230-457); without rejection the raw draws."""
+        est = self.posterior_estimator
+        if not reject_outside_prior:
+            return est.sample(torch.Size([how_many]), condition=x)
+        kept, _acceptance = rejection.accept_reject_sample(
+            est.sample, lambda candidates: within_support(self.prior, candidates), how_many,
+            show_progress_bars=show_progress_bars, max_sampling_batch_size=batch_cap,
+            proposal_sampling_kwargs=dict(condition=x), alternative_method="build_posterior(..., sample_with='mcmc')",
+            max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout)
+        return kept
+
     def sample(self, sample_shape=torch.Size(), x: Optional[Tensor] = None, max_sampling_batch_size: int = 10_000,
                show_progress_bars: bool = True, reject_outside_prior: bool = True,
                max_sampling_time: Optional[float] = None, return_partial_on_timeout: bool = False) -> Tensor:
-        num_samples = torch.Size(sample_shape).numel()
-        x = self._x_else_default_x(x)
-        x = reshape_to_batch_event(x, event_shape=self.posterior_estimator.condition_shape)
-        if x.shape[0] > 1:
+        shape = torch.Size(sample_shape)
+        x_o = reshape_to_batch_event(self._x_else_default_x(x), event_shape=self.posterior_estimator.condition_shape)
+        if len(x_o) != 1:
             raise ValueError(
                 ".sample() supports only `batchsize == 1`. If you intend to sample multiple observations, use "
                 "`.sample_batched()`. If you intend to sample i.i.d. observations, set up the posterior density "
-                "estimator with an appropriate permutation invariant embedding net."
-            )
-        max_sampling_batch_size = (self.max_sampling_batch_size if max_sampling_batch_size is None
-                                   else max_sampling_batch_size)
-        if reject_outside_prior:
-            samples = rejection.accept_reject_sample(
-                proposal=self.posterior_estimator.sample,
-                accept_reject_fn=lambda theta: within_support(self.prior, theta),
-                num_samples=num_samples, show_progress_bars=show_progress_bars,
-                max_sampling_batch_size=max_sampling_batch_size,
-                proposal_sampling_kwargs={"condition": x},
-                alternative_method="build_posterior(..., sample_with='mcmc')",
-                max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout,
-            )[0]
-        else:
-            samples = self.posterior_estimator.sample(torch.Size([num_samples]), condition=x)
-            warn_if_outside_prior_support(self.prior, samples[:, 0])
-        samples = samples[:, 0]
-        if samples.shape[0] == num_samples:
-            samples = samples.reshape((*torch.Size(sample_shape), *samples.shape[1:]))
-        return samples
+                "estimator with an appropriate permutation invariant embedding net.")
+        drawn = self._draw(shape.numel(), x_o, self._batch_cap(max_sampling_batch_size), show_progress_bars,
+                           reject_outside_prior, max_sampling_time, return_partial_on_timeout)[:, 0]
+        if not reject_outside_prior:
+            warn_if_outside_prior_support(self.prior, drawn)
+        # (a timeout may hand back fewer rows than asked for: those stay a flat batch)
+        return drawn.reshape(*shape, *drawn.shape[1:]) if len(drawn) == shape.numel() else drawn
 
     def sample_batched(self, sample_shape, x: Tensor, max_sampling_batch_size: int = 10_000,
                        show_progress_bars: bool = True, reject_outside_prior: bool = True,
                        max_sampling_time: Optional[float] = None, return_partial_on_timeout: bool = False) -> Tensor:
-        num_samples = torch.Size(sample_shape).numel()
-        x = reshape_to_batch_event(self._x_else_default_x(x), self.posterior_estimator.condition_shape)
-        num_xos = x.shape[0]
-        if num_xos * num_samples > 2**21:
-            warnings.warn(
-                f"Note that for batched sampling, the direct posterior sampling generates {num_xos} * "
-                f"{num_samples} = {num_xos * num_samples} samples. This can be slow and memory-intensive.",
-                stacklevel=2,
-            )
-        max_sampling_batch_size = (self.max_sampling_batch_size if max_sampling_batch_size is None
-                                   else max_sampling_batch_size)
-        if max_sampling_batch_size * num_xos > 100_000:
-            capped = max(1, 100_000 // num_xos)
-            warnings.warn(f"Capping max_sampling_batch_size from {max_sampling_batch_size} to {capped} to avoid "
-                          "excessive memory usage.", stacklevel=2)
-            max_sampling_batch_size = capped
-        if reject_outside_prior:
-            samples = rejection.accept_reject_sample(
-                proposal=self.posterior_estimator.sample,
-                accept_reject_fn=lambda theta: within_support(self.prior, theta),
-                num_samples=num_samples, show_progress_bars=show_progress_bars,
-                max_sampling_batch_size=max_sampling_batch_size,
-                proposal_sampling_kwargs={"condition": x},
-                alternative_method="build_posterior(..., sample_with='mcmc')",
-                max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout,
-            )[0]
-        else:
-            samples = self.posterior_estimator.sample(torch.Size([num_samples]), condition=x)
-        return samples.reshape((*torch.Size(sample_shape), num_xos, *samples.shape[2:]))
+        shape = torch.Size(sample_shape)
+        xs = reshape_to_batch_event(self._x_else_default_x(x), self.posterior_estimator.condition_shape)
+        n_obs, per_obs = len(xs), shape.numel()
+        if n_obs * per_obs > 2**21:
+            warnings.warn(f"Note that for batched sampling, the direct posterior sampling generates {n_obs} * {per_obs} = "
+                          f"{n_obs * per_obs} samples. This can be slow and memory-intensive.", stacklevel=2)
+        cap = self._batch_cap(max_sampling_batch_size)
+        if cap * n_obs > 100_000:        # candidates are drawn for every observation at once
+            smaller = max(1, 100_000 // n_obs)
+            warnings.warn(f"Capping max_sampling_batch_size from {cap} to {smaller} to avoid excessive memory usage.",
+                          stacklevel=2)
+            cap = smaller
+        drawn = self._draw(per_obs, xs, cap, show_progress_bars, reject_outside_prior, max_sampling_time,
+                           return_partial_on_timeout)
+        return drawn.reshape(*shape, n_obs, *drawn.shape[2:])
 
     # -- density ------------------------------------------------------------------------
     def log_prob(self, theta: Tensor, x: Optional[Tensor] = None, norm_posterior: bool = True,

@@ -105,29 +105,25 @@ class RejectionPosterior:
                num_iter_to_find_max: Optional[int] = None, m: Optional[float] = None,
                show_progress_bars: bool = True, reject_outside_prior: bool = True,
                max_sampling_time: Optional[float] = None, return_partial_on_timeout: bool = False) -> Tensor:
-        sample_shape = torch.Size(sample_shape)
-        num_samples = sample_shape.numel()
+        shape = torch.Size(sample_shape)
         self.potential_fn.set_x(self._x_else_default_x(x))
-        potential = partial(self.potential_fn, track_gradients=True)
-        if reject_outside_prior:
-            samples, _ = rejection_sample(
-                potential, proposal=self.proposal, theta_transform=self.theta_transform, num_samples=num_samples,
-                show_progress_bars=show_progress_bars, warn_acceptance=0.01,
-                max_sampling_batch_size=(self.max_sampling_batch_size if max_sampling_batch_size is None
-                                         else max_sampling_batch_size),
-                num_samples_to_find_max=(self.num_samples_to_find_max if num_samples_to_find_max is None
-                                         else num_samples_to_find_max),
-                num_iter_to_find_max=(self.num_iter_to_find_max if num_iter_to_find_max is None
-                                      else num_iter_to_find_max),
-                m=self.m if m is None else m, max_sampling_time=max_sampling_time,
-                return_partial_on_timeout=return_partial_on_timeout, device=self._device,
-            )
-        else:
-            samples = self.proposal.sample((num_samples,))
+        if not reject_outside_prior:
             warn("Samples drawn with reject_outside_prior=False are taken directly from the proposal without "
                  "rejection sampling. These samples may lie outside the prior support, which could lead to "
                  "incorrect inference.", stacklevel=2)
-        return samples.reshape((*sample_shape, -1))
+            return self.proposal.sample((shape.numel(),)).reshape(*shape, -1)
+
+        def setting(given, name):            # per-call override, else what the posterior was built with
+            return getattr(self, name) if given is None else given
+
+        accepted, _rate = rejection_sample(
+            partial(self.potential_fn, track_gradients=True), self.proposal, self.theta_transform, shape.numel(),
+            show_progress_bars=show_progress_bars, warn_acceptance=0.01, device=self._device,
+            max_sampling_batch_size=setting(max_sampling_batch_size, "max_sampling_batch_size"),
+            num_samples_to_find_max=setting(num_samples_to_find_max, "num_samples_to_find_max"),
+            num_iter_to_find_max=setting(num_iter_to_find_max, "num_iter_to_find_max"), m=setting(m, "m"),
+            max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout)
+        return accepted.reshape(*shape, -1)
 
     def sample_batched(self, sample_shape, x: Tensor, max_sampling_batch_size: int = 10000,
                        show_progress_bars: bool = True) -> Tensor:
@@ -138,20 +134,18 @@ class RejectionPosterior:
             learning_rate: float = 0.01, init_method: Union[str, Tensor] = "proposal", num_init_samples: int = 1_000,
             save_best_every: int = 10, show_progress_bars: bool = False, force_update: bool = False) -> Tensor:
         """base_posterior.py:216-323: gradient ascent on the potential from proposal (or posterior) draws."""
-        if self._map is not None and not force_update and x is None:
+        if x is None and self._map is not None and not force_update:
             return self._map
         self.potential_fn.set_x(self._x_else_default_x(x))
         if isinstance(init_method, Tensor):
-            inits = init_method
-        elif init_method == "proposal":
-            inits = self.proposal.sample((num_init_samples,))
-        elif init_method == "posterior":
-            inits = self.sample((num_init_samples,), x=x, show_progress_bars=False)
+            starts = init_method
+        elif init_method in ("proposal", "posterior"):
+            starts = (self.proposal.sample((num_init_samples,)) if init_method == "proposal"
+                      else self.sample((num_init_samples,), x=x, show_progress_bars=False))
         else:
             raise ValueError("init_method must be 'posterior', 'proposal' or a tensor of initial parameters.")
-        best, _ = gradient_ascent(partial(self.potential_fn, track_gradients=True), inits.to(self._device),
-                                  theta_transform=self.theta_transform, num_iter=num_iter,
-                                  num_to_optimize=num_to_optimize, learning_rate=learning_rate,
-                                  save_best_every=save_best_every, show_progress_bars=show_progress_bars)
+        best, _ = gradient_ascent(partial(self.potential_fn, track_gradients=True), starts.to(self._device),
+                                  self.theta_transform, num_iter, num_to_optimize, learning_rate, save_best_every,
+                                  show_progress_bars)
         self._map = best
         return best
