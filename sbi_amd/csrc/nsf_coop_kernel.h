@@ -527,7 +527,7 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
         for (int u = 0; u < NT; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            gate[u][r] = sigmoid_f(gate[u][r]);
+            gate[u][r] = sigmoid_gate(gate[u][r]);
             tt[u][r] = fmaxf(u1[u][r], 0.f);
           }
 #pragma unroll

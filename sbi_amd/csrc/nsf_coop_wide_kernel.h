@@ -182,7 +182,7 @@ nsf_coopw_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
         cow_gemm<KQ>(a, bg, u1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          gate[q][r] = sigmoid_f(gate[q][r]);
+          gate[q][r] = sigmoid_gate(gate[q][r]);
           tt[q][r] = fmaxf(u1[r], 0.f);
         }
         if (ab) {
