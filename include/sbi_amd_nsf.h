@@ -258,6 +258,18 @@ int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples
 int sbi_amd_mcmc_to_constrained(int32_t kind, int32_t num_chains, int32_t dim, const float* p0, const float* p1,
                                 const float* u, float* theta_out, float* logabsdet_out, void* stream);
 
+/* The coupling transform's spline on its own (SURVEY 8b `spline_coupling_fwd / inv`): nflows 0.14
+ * unconstrained_rational_quadratic_spline (tails = "linear") exactly as the flow kernels evaluate it (the same device
+ * routine: bin search on the fp32 knots, the selected bin re-derived beyond fp32 in the forward direction, clamped
+ * discriminant / root in the inverse direction).  params (n, 3 K - 1) = [K width logits | K height logits | K - 1 interior
+ * derivative pre-activations] per task; width / height logits are multiplied by `logit_scale` first (sbi's couplings:
+ * 1 / sqrt(hidden_features); plain nflows splines: 1).  outputs (n); logabsdet (n, optional) = log|d output / d input|
+ * of the direction that ran.  num_bins in {4, 5, 8, 10, 16}.  A test hook and a convenience for binders; the flow
+ * kernels run the spline inside their own launches. */
+int sbi_amd_rq_spline(int32_t num_bins, int32_t inverse, float tail_bound, float min_bin_width, float min_bin_height,
+                      float min_derivative, float logit_scale, const float* params, const float* inputs, int64_t n,
+                      float* outputs, float* logabsdet, void* stream);
+
 /* Host-side consistency check of the cooperative kernels' address arithmetic against the plan tables, and of the
  * compile-time default layout against the run-time plan (no device work; used by the CPU tests).  0 = consistent,
  * -1 = the configuration has no cooperative image. */

@@ -126,6 +126,11 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float,
          c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    "sbi_amd_rq_spline": (
+        c_int,
+        [c_int32, c_int32, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+         c_void_p],
+    ),
     "sbi_amd_mcmc_slice_tick": (
         c_int,
         [c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
