@@ -64,6 +64,16 @@ class FusedTrainStep:
         return {"params": self.net.flat_params.data.clone(), "exp_avg": self.exp_avg.clone(),
                 "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count}
 
+    def snapshot_into(self, snap: Optional[dict]) -> dict:
+        """`snapshot()` into the buffers of an earlier snapshot (ONE multi-tensor copy launch, no allocation); `None`
+        allocates.  The epoch loop keeps a small ring of them."""
+        if snap is None:
+            return self.snapshot()
+        torch._foreach_copy_([snap["params"], snap["exp_avg"], snap["exp_avg_sq"]],
+                             [self.net.flat_params.data, self.exp_avg, self.exp_avg_sq])
+        snap["step"] = self.step_count
+        return snap
+
     def restore_optimizer(self, snap: dict) -> None:
         self.exp_avg.copy_(snap["exp_avg"])
         self.exp_avg_sq.copy_(snap["exp_avg_sq"])

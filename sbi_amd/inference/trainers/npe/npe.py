@@ -448,6 +448,27 @@ class PosteriorEstimatorTrainer:
         pipelined = fused and _os.environ.get("SBI_AMD_EAGER_EPOCH_SYNC") != "1"      # (why: see the loop below)
         from sbi_amd import _lib as _lib_mod
 
+        # Per-epoch bookkeeping on the device, kept to a handful of launches whatever the number of batches: the per-row
+        # losses of every batch are collected and summed ONCE per epoch (cat + sum per split, instead of a sum and an add
+        # per batch); when the validation batches tile the split its rows are gathered once per train() call; snapshots
+        # go into a ring of preallocated buffers with one multi-tensor copy.
+        def loss_sums(train_rows: list, val_rows: list) -> Tensor:
+            def total(parts):
+                return (parts[0] if len(parts) == 1 else torch.cat(parts)).sum()
+            return torch.stack([total(train_rows), total(val_rows)])
+
+        val_fixed = None
+        if fused and n_val_batches * Bv == n_val and world == 1 and not atomic:      # (fused: no calibration kernel)
+            val_fixed = (theta_d.index_select(0, val_idx), x_d.index_select(0, val_idx))
+
+        def val_batch_losses(b: int, val_epoch_idx) -> Tensor:
+            if val_fixed is not None:
+                with torch.no_grad():
+                    return net_losses(val_fixed[0][b * Bv : (b + 1) * Bv], val_fixed[1][b * Bv : (b + 1) * Bv], None)
+            return batch_losses(my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv]), False, Bv)
+
+        snap_ring = [None] * 4       # (at most three epoch records are alive at a time)
+
         # Epochs as HIP graphs, OPT-IN (SBI_AMD_GRAPH_EPOCH=1): after one eager epoch (which sizes the
         # workspace, builds the re-pack table and leaves the allocator warm) the epoch's device work -- per batch: gather,
         # forward, T backward launches, reduction, clip + Adam, re-pack; then the validation pass and the loss sums -- is
@@ -466,14 +487,15 @@ class PosteriorEstimatorTrainer:
 
         def epoch_body() -> Tensor:
             """One epoch's device work with no host-dependent launch argument (capturable)."""
-            sums_ = torch.zeros(2, device=self._device)
+            tr_rows, va_rows = [], []
             net.train()
             for b in range(n_train_batches):
                 th, xx = sampler.batch_clock(self._stepper.clock, *my_range(b * B, B))
-                sums_[0] += self._stepper.step(th, xx, global_batch=B).sum()
+                tr_rows.append(self._stepper.step(th, xx, global_batch=B))
             net.eval()
             for b in range(n_val_batches):
-                sums_[1] += batch_losses(val_idx[b * Bv : (b + 1) * Bv], False, Bv).sum()
+                va_rows.append(val_batch_losses(b, val_idx))
+            sums_ = loss_sums(tr_rows, va_rows)
             rc = _lib_mod.load().sbi_amd_train_clock_tick(_lib_mod.ptr(self._stepper.clock), None, 0, 0.0, 0.0,
                                                           _lib_mod.current_stream(torch.device(self._device)))
             _lib_mod.check(rc, "train_clock_tick")
@@ -507,7 +529,7 @@ class PosteriorEstimatorTrainer:
                 gstate["graph"].replay()
                 self._graph_epochs = getattr(self, "_graph_epochs", 0) + 1
                 self._stepper.step_count += n_train_batches       # (the device clock counted them itself)
-                rec["snap"] = self._stepper.snapshot()
+                rec["snap"] = snap_ring[e % len(snap_ring)] = self._stepper.snapshot_into(snap_ring[e % len(snap_ring)])
                 rec["host"] = host_ring[e % len(host_ring)]
                 rec["host"].copy_(gstate["sums"], non_blocking=True)
                 rec["event"] = torch.cuda.Event(enable_timing=True)
@@ -519,28 +541,28 @@ class PosteriorEstimatorTrainer:
                 rec["ev0"] = torch.cuda.Event(enable_timing=True)
                 rec["ev0"].record()
             net.train()
-            sums = torch.zeros(2, device=self._device)
+            tr_rows, va_rows = [], []
             if sampler is not None and not atomic:
                 for b in range(n_train_batches):
                     th, xx = sampler.batch(e, *my_range(b * B, B))
-                    sums[0] += self._stepper.step(th, xx, global_batch=B).sum()
+                    tr_rows.append(self._stepper.step(th, xx, global_batch=B))
             elif sampler is not None:
                 for b in range(n_train_batches):
-                    sums[0] += batch_losses(sampler.indices(e, *my_range(b * B, B)), True, B).sum()
+                    tr_rows.append(batch_losses(sampler.indices(e, *my_range(b * B, B)), True, B))
             else:
                 order = perm_of(n_train)   # SubsetRandomSampler
                 epoch_idx = train_idx[order]
                 for b in range(n_train_batches):
                     idx = my_slice(epoch_idx[b * B : (b + 1) * B])
-                    sums[0] += batch_losses(idx, True, B).sum()
-            if pipelined:
-                rec["snap"] = self._stepper.snapshot()      # weights + optimizer state after this epoch's steps
+                    tr_rows.append(batch_losses(idx, True, B))
+            if pipelined:      # weights + optimizer state after this epoch's steps
+                rec["snap"] = snap_ring[e % len(snap_ring)] = self._stepper.snapshot_into(snap_ring[e % len(snap_ring)])
             net.eval()
             # (every validation row is used when the batches tile the split exactly: the order of a sum is immaterial)
             val_epoch_idx = val_idx if n_val_batches * Bv == n_val else val_idx[perm_of(n_val)]
             for b in range(n_val_batches):
-                idx = my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv])
-                sums[1] += batch_losses(idx, False, Bv).sum()
+                va_rows.append(val_batch_losses(b, val_epoch_idx))
+            sums = loss_sums(tr_rows, va_rows)
             if d is not None:
                 all_reduce_sum(d, sums)
             if pipelined:
