@@ -380,11 +380,13 @@ def npe_train_leg(device, rank, world, epochs):
     try:
         keep = ("value", "ms_per_epoch", "epochs_replayed_as_hip_graph")
         head = run(N_SIMS, BATCH, epochs, False)
-        head["hip_graph_epochs"] = {k: v for k, v in run(N_SIMS, BATCH, epochs, True).items() if k in keep}
+        if world == 1:       # (epochs are only captured with one rank)
+            head["hip_graph_epochs"] = {k: v for k, v in run(N_SIMS, BATCH, epochs, True).items() if k in keep}
         dense = run(728_200, BATCH, max(2, epochs // 10), False)
         # sbi's default training_batch_size on the same simulations: 450 steps + 50 validation batches per epoch
         small = run(N_SIMS, 200, 6, False)
-        small["hip_graph_epochs"] = {k: v for k, v in run(N_SIMS, 200, 6, True).items() if k in keep}
+        if world == 1:
+            small["hip_graph_epochs"] = {k: v for k, v in run(N_SIMS, 200, 6, True).items() if k in keep}
     finally:
         if prev is None:
             os.environ.pop("SBI_AMD_GRAPH_EPOCH", None)

@@ -65,12 +65,14 @@ class FusedTrainStep:
                 "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count}
 
     def snapshot_into(self, snap: Optional[dict]) -> dict:
-        """`snapshot()` into the buffers of an earlier snapshot (ONE multi-tensor copy launch, no allocation); `None`
-        allocates.  The epoch loop keeps a small ring of them."""
+        """`snapshot()` into the buffers of an earlier snapshot (three plain copies, no allocation); `None` allocates.
+        The epoch loop keeps a small ring of them.  (A multi-tensor `_foreach_copy_` is one launch instead of three but
+        costs MORE host time, and the one-step-per-epoch loop is host-bound on slow boxes: measured, not kept.)"""
         if snap is None:
             return self.snapshot()
-        torch._foreach_copy_([snap["params"], snap["exp_avg"], snap["exp_avg_sq"]],
-                             [self.net.flat_params.data, self.exp_avg, self.exp_avg_sq])
+        snap["params"].copy_(self.net.flat_params.data)
+        snap["exp_avg"].copy_(self.exp_avg)
+        snap["exp_avg_sq"].copy_(self.exp_avg_sq)
         snap["step"] = self.step_count
         return snap
 

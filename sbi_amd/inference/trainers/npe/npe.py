@@ -451,11 +451,13 @@ class PosteriorEstimatorTrainer:
         # Per-epoch bookkeeping on the device, kept to a handful of launches whatever the number of batches: the per-row
         # losses of every batch are collected and summed ONCE per epoch (cat + sum per split, instead of a sum and an add
         # per batch); when the validation batches tile the split its rows are gathered once per train() call; snapshots
-        # go into a ring of preallocated buffers with one multi-tensor copy.
-        def loss_sums(train_rows: list, val_rows: list) -> Tensor:
-            def total(parts):
-                return (parts[0] if len(parts) == 1 else torch.cat(parts)).sum()
-            return torch.stack([total(train_rows), total(val_rows)])
+        # go into a ring of preallocated buffers (no allocation per epoch).
+        sums_ring = [torch.zeros(2, device=self._device) for _ in range(4)]      # (an epoch's pair is read back one epoch late)
+
+        def loss_sums(train_rows: list, val_rows: list, out: Tensor) -> Tensor:
+            for i, parts in enumerate((train_rows, val_rows)):
+                torch.sum(parts[0] if len(parts) == 1 else torch.cat(parts), dim=0, keepdim=True, out=out[i : i + 1])
+            return out
 
         val_fixed = None
         if fused and n_val_batches * Bv == n_val and world == 1 and not atomic:      # (fused: no calibration kernel)
@@ -495,7 +497,7 @@ class PosteriorEstimatorTrainer:
             net.eval()
             for b in range(n_val_batches):
                 va_rows.append(val_batch_losses(b, val_idx))
-            sums_ = loss_sums(tr_rows, va_rows)
+            sums_ = loss_sums(tr_rows, va_rows, torch.zeros(2, device=self._device))
             rc = _lib_mod.load().sbi_amd_train_clock_tick(_lib_mod.ptr(self._stepper.clock), None, 0, 0.0, 0.0,
                                                           _lib_mod.current_stream(torch.device(self._device)))
             _lib_mod.check(rc, "train_clock_tick")
@@ -562,7 +564,7 @@ class PosteriorEstimatorTrainer:
             val_epoch_idx = val_idx if n_val_batches * Bv == n_val else val_idx[perm_of(n_val)]
             for b in range(n_val_batches):
                 va_rows.append(val_batch_losses(b, val_epoch_idx))
-            sums = loss_sums(tr_rows, va_rows)
+            sums = loss_sums(tr_rows, va_rows, sums_ring[e % len(sums_ring)])
             if d is not None:
                 all_reduce_sum(d, sums)
             if pipelined:
