@@ -89,14 +89,15 @@ def test_reference_trainer_sequence_matches_the_oracle(D, C, batch):
         tot += float(d.sum())
         cnt += d.numel()
     # Adam moves every weight by ~lr per step whatever the gradient's size, so a weight whose gradient is ~0 can take
-    # opposite signs in two fp32 evaluations: the bound is a few lr for the worst weight, the MEAN is held tightly
+    # opposite signs in two fp32 evaluations: the bound for the worst weight is a fraction of one lr step (measured:
+    # 1.2e-5 / 1.9e-6), the MEAN is held tightly (measured: 4 - 7e-9)
     from tests.parity_log import record
 
     record("reference_trainer_replay", f"D{D}-C{C}-batch{batch}", steps=steps, worst_weight_diff=worst,
            mean_weight_diff=tot / cnt, probe_abs_diff=(probe - oprobe.detach()).abs().max().item())
     print(f"replay D={D} batch={batch}: after {steps} Adam steps worst weight diff {worst:.2e}, mean {tot / cnt:.2e}")
-    assert worst <= 3 * 5e-4, f"worst weight differs by {worst:.2e} after {steps} steps"
-    assert tot / cnt <= 2e-6, f"mean weight difference {tot / cnt:.2e}"
+    assert worst <= 2e-4, f"worst weight differs by {worst:.2e} after {steps} steps"
+    assert tot / cnt <= 2e-7, f"mean weight difference {tot / cnt:.2e}"
 
     # best-so-far snapshot: a deep copy of the state_dict taken mid-training restores exactly
     held = {k: v.clone() for k, v in net.state_dict().items()}
