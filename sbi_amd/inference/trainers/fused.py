@@ -83,6 +83,10 @@ class FusedTrainStep:
         self.sync_clock()
 
     # -- device-resident clock (epochs as HIP graphs: include/sbi_amd_nsf.h "Epochs as HIP graphs") --------------
+    # images (bit 0 throughput, bit 1 cooperative) the step's table-driven re-pack refreshes IN ADDITION to the one the
+    # training batches read: a loop whose validation batches take the other kernel family and that has only a step or
+    # two per epoch saves the separate pack launch per epoch (NPE.train sets it; 0: only the training image)
+    tail_extra_images = 0
     clock: Optional[Tensor] = None          # int64[2] on the device: [epoch number, optimizer steps taken]
     bias_corr: Optional[Tensor] = None      # float[2]: 1 - beta1^step, sqrt(1 - beta2^step)
     _clock_mode = False                     # True while an epoch is being CAPTURED: apply() reads the device clock
@@ -211,8 +215,8 @@ class FusedTrainStep:
         kind = lib.sbi_amd_nsf_image_kind(cfg, int(rows), 1)
         if kind < 0:
             return None
-        mask = 2 if kind == 1 else 1
-        packed = packed_weights(self.net, rows=int(rows), training=True)
+        mask = (2 if kind == 1 else 1) | int(getattr(self, "tail_extra_images", 0))
+        packed = packed_weights(self.net, rows=int(rows), training=True)      # (build_step_map packs every image of `mask`)
         maps = self.__dict__.setdefault("_step_maps", {})
         key = (mask, packed.data_ptr(), self.net.flat_params.data_ptr())
         for stale in [k for k in maps if k[1:] != key[1:]]:      # a moved / re-allocated buffer drops its tables

@@ -470,6 +470,20 @@ class PosteriorEstimatorTrainer:
             return batch_losses(my_slice(val_epoch_idx[b * Bv : (b + 1) * Bv]), False, Bv)
 
         snap_ring = [None] * 4       # (at most three epoch records are alive at a time)
+        if (fused and not atomic and n_train_batches <= 2 and isinstance(net, NSFFlow) and hasattr(net.net, "hyper")
+                and _os.environ.get("SBI_AMD_TAIL_EXTRA", "1") != "0"):
+            # one or two steps per epoch, validation batches on the OTHER kernel family (e.g. batch 65 536 / 10 000
+            # validation rows): let the step's table pack refresh the validation image too instead of a separate pack
+            # launch every epoch
+            try:
+                lib_ = _lib_mod.load()
+                cfg_ = net.net.hyper.c_config()
+                k_tr, k_va = lib_.sbi_amd_nsf_image_kind(cfg_, int(B), 1), lib_.sbi_amd_nsf_image_kind(cfg_, int(Bv), 0)
+                self._stepper.tail_extra_images = (2 if k_va == 1 else 1) if (k_tr >= 0 and k_va >= 0 and k_tr != k_va) else 0
+            except (AttributeError, RuntimeError):
+                self._stepper.tail_extra_images = 0
+        elif fused:
+            self._stepper.tail_extra_images = 0
 
         # Epochs as HIP graphs, OPT-IN (SBI_AMD_GRAPH_EPOCH=1): after one eager epoch (which sizes the
         # workspace, builds the re-pack table and leaves the allocator warm) the epoch's device work -- per batch: gather,
