@@ -19,18 +19,14 @@ class ConditionalEstimatorBuildFn(Protocol):
 
 
 class ConditionalEstimator(nn.Module, ABC):
+    """An `nn.Module` that knows the event shapes of its input and of what it is conditioned on."""
+
     def __init__(self, input_shape: Tuple, condition_shape: Tuple) -> None:
         super().__init__()
-        self._input_shape = torch.Size(input_shape)
-        self._condition_shape = torch.Size(condition_shape)
+        self._event_shapes = (torch.Size(input_shape), torch.Size(condition_shape))
 
-    @property
-    def input_shape(self) -> torch.Size:
-        return self._input_shape
-
-    @property
-    def condition_shape(self) -> torch.Size:
-        return self._condition_shape
+    input_shape = property(lambda self: self._event_shapes[0], doc="event shape of `input` (theta)")
+    condition_shape = property(lambda self: self._event_shapes[1], doc="event shape of `condition` (x)")
 
     @abstractmethod
     def loss(self, input: Tensor, condition: Tensor, **kwargs) -> Tensor: ...
@@ -76,17 +72,14 @@ class ConditionalEstimator(nn.Module, ABC):
         return input, sample_dim, batch_dim, cond_has_sample
 
     def _broadcast_and_align(self, input: Tensor, condition: Tensor) -> Tuple[Tensor, Tensor, int]:
-        input, sample_dim, batch_dim, cond_has_sample = self._broadcast_dims(input, condition)
-        input = input.expand(sample_dim, batch_dim, *self.input_shape)
-        if cond_has_sample:
-            condition = condition.expand(sample_dim, batch_dim, *self.condition_shape)
-        else:
-            condition = (
-                condition.expand(batch_dim, *self.condition_shape)
-                .unsqueeze(0)
-                .expand(sample_dim, batch_dim, *self.condition_shape)
-            )
-        return input, condition, batch_dim
+        """Both arguments as (sample, batch, *event) views of one common (sample, batch) grid, plus the batch size
+        (base.py:142-198; expanded VIEWS -- whoever reshapes them pays for the copy, the kernels never do)."""
+        input, n_sample, n_batch, cond_has_sample = self._broadcast_dims(input, condition)
+        grid = (n_sample, n_batch)
+        if not cond_has_sample:
+            condition = condition.unsqueeze(0)                   # (1, 1 | batch, *event)
+        return (torch.broadcast_to(input, grid + tuple(self.input_shape)),
+                torch.broadcast_to(condition, grid + tuple(self.condition_shape)), n_batch)
 
 
 class ConditionalDensityEstimator(ConditionalEstimator):
@@ -110,6 +103,6 @@ class ConditionalDensityEstimator(ConditionalEstimator):
     def sample(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tensor: ...
 
     def sample_and_log_prob(self, sample_shape: torch.Size, condition: Tensor, **kwargs) -> Tuple[Tensor, Tensor]:
-        samples = self.sample(sample_shape, condition, **kwargs)
-        log_probs = self.log_prob(samples, condition, **kwargs)
-        return samples, log_probs
+        """Default: draw, then evaluate the draws (flows override it with the one-pass form)."""
+        drawn = self.sample(sample_shape, condition, **kwargs)
+        return drawn, self.log_prob(drawn, condition, **kwargs)

@@ -1,8 +1,8 @@
-"""Linear-Gaussian toy simulators and analytic posteriors (test / benchmark inputs).
+"""Linear-Gaussian toy simulators and their analytic posterior: inputs of the C2ST / parity tests and of bench.py.
 
-Same functions, arguments and maths as sbi/simulators/linear_gaussian.py:15-105:
-``x = shift + theta + chol(cov) eps``; the product of the Gaussian likelihood and
-a Gaussian prior gives the reference posterior the C2ST checks compare against.
+Behaviour of sbi/simulators/linear_gaussian.py:15-105 (pinned by tests/golden/reference_intree.pt):
+``x = shift + theta + L eps`` with ``L L^T = cov``; under a Gaussian prior the posterior given n i.i.d. observations is
+the normalised product of ``N(mean(x_o) - shift, cov / n)`` and the prior.
 """
 
 from __future__ import annotations
@@ -17,33 +17,35 @@ from sbi_amd.utils.torchutils import atleast_2d
 
 
 def diagonal_linear_gaussian(theta: Tensor, std: float = 1.0) -> Tensor:
-    """Gaussian likelihood with diagonal covariance: ``theta + std * eps``."""
-    return theta + std * torch.randn_like(theta)
+    """One observation per parameter row with independent noise of scale `std` on every coordinate."""
+    noise = torch.randn_like(theta)
+    return theta + std * noise
 
 
 def linear_gaussian(theta: Tensor, likelihood_shift: Tensor, likelihood_cov: Tensor,
                     num_discarded_dims: int = 0) -> Tensor:
-    """``x ~ N(likelihood_shift + theta, likelihood_cov)``, optionally on the leading dims only."""
+    """One observation per parameter row, ``N(theta + likelihood_shift, likelihood_cov)``; the last
+    `num_discarded_dims` parameter coordinates do not enter the observation."""
     theta = torch.as_tensor(theta)
-    if num_discarded_dims:
-        theta = theta[:, :-num_discarded_dims]
-    chol = torch.linalg.cholesky(likelihood_cov)
-    return likelihood_shift + theta + torch.mm(chol, torch.randn_like(theta).T).T
+    kept = theta if num_discarded_dims == 0 else theta[:, : theta.shape[1] - num_discarded_dims]
+    factor = torch.linalg.cholesky(likelihood_cov)
+    correlated = (factor @ torch.randn_like(kept).T).T          # (noise drawn row-major, as the golden run drew it)
+    return likelihood_shift + kept + correlated
 
 
 def multiply_gaussian_pdfs(mu1: Tensor, s1: Tensor, mu2: Tensor, s2: Tensor) -> Tuple[Tensor, Tensor]:
-    """Mean and covariance of the (unnormalised) product N(mu1,s1) * N(mu2,s2)."""
-    inv_s1s2 = torch.inverse(s1 + s2)
-    product_mean = torch.mv(torch.mm(s2, inv_s1s2), mu1) + torch.mv(torch.mm(s1, inv_s1s2), mu2)
-    product_cov = torch.mm(torch.mm(s1, inv_s1s2), s2)
-    return product_mean, product_cov
+    """(mean, covariance) of the normalised product of two Gaussian densities in the same variable:
+    with ``G = (s1 + s2)^-1``: mean ``s2 G mu1 + s1 G mu2``, covariance ``s1 G s2``."""
+    gain = torch.inverse(s1 + s2)
+    to_first, to_second = s2 @ gain, s1 @ gain
+    return to_first @ mu1 + to_second @ mu2, to_second @ s2
 
 
 def true_posterior_linear_gaussian_mvn_prior(x_o: Tensor, likelihood_shift: Tensor, likelihood_cov: Tensor,
                                              prior_mean: Tensor, prior_cov: Tensor) -> MultivariateNormal:
-    """Analytic posterior for Gaussian likelihood (iid trials in x_o rows) and Gaussian prior."""
-    x_o = atleast_2d(x_o)
-    num_trials = x_o.shape[0]
-    likelihood_mean = x_o.mean(0) - likelihood_shift
-    mean, cov = multiply_gaussian_pdfs(likelihood_mean, 1 / num_trials * likelihood_cov, prior_mean, prior_cov)
+    """The exact posterior for the rows of `x_o` read as i.i.d. observations under a Gaussian prior."""
+    observations = atleast_2d(x_o)
+    n = observations.shape[0]
+    evidence_mean = observations.mean(dim=0) - likelihood_shift
+    mean, cov = multiply_gaussian_pdfs(evidence_mean, likelihood_cov / n, prior_mean, prior_cov)
     return MultivariateNormal(mean, cov)
