@@ -121,3 +121,31 @@ def test_accept_reject_sample_reproduces_reference_run():
                                     proposal_sampling_kwargs={"condition": torch.zeros(2, 5)})
     assert torch.equal(smp, G["accept_reject"]["samples"])
     assert torch.allclose(acc, G["accept_reject"]["acceptance"])
+
+
+def test_accept_reject_all_accepted_first_pass_returns_the_candidates_in_order():
+    """The fast path of `accept_reject_sample` (a request-sized first pass in which every candidate is accepted) must
+    return exactly what the compaction would have produced: the candidates, in the order they were drawn, acceptance 1;
+    one rejected candidate sends the call down the general path with the same result as before."""
+    from sbi_amd.samplers.rejection.rejection import accept_reject_sample
+
+    def proposal(shape, condition=None):
+        return torch.randn(shape[0], 1, 3)
+
+    torch.manual_seed(4)
+    ref = proposal(torch.Size((500,)))
+    torch.manual_seed(4)
+    s, acc = accept_reject_sample(proposal, lambda th: torch.ones(th.shape[:2], dtype=torch.bool), 500,
+                                  max_sampling_batch_size=500)
+    assert torch.equal(s, ref) and torch.equal(acc, torch.ones(1))
+    # not request-sized (two passes of 250): general path, same samples
+    torch.manual_seed(4)
+    s2, acc2 = accept_reject_sample(proposal, lambda th: torch.ones(th.shape[:2], dtype=torch.bool), 500,
+                                    max_sampling_batch_size=250)
+    torch.manual_seed(4)
+    ref2 = torch.cat([proposal(torch.Size((250,))), proposal(torch.Size((250,)))])
+    assert torch.equal(s2, ref2) and torch.allclose(acc2, torch.ones(1))
+    # one rejection in a request-sized pass: the general path compacts and tops up
+    torch.manual_seed(4)
+    s3, acc3 = accept_reject_sample(proposal, lambda th: th[..., 0] > -1.0, 500, max_sampling_batch_size=500)
+    assert s3.shape == (500, 1, 3) and bool((s3[..., 0] > -1.0).all()) and float(acc3) < 1.0
