@@ -58,6 +58,7 @@ class FusedTrainStep:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        self.sync_clock()
 
     # -- device snapshots for the software-pipelined epoch loop of NPE.train() -------------------
     def snapshot(self) -> dict:
