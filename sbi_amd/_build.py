@@ -71,14 +71,25 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose: bool) -> Path:
+DEBUG_LIB_PATH = LIB_PATH.with_name("libsbi_amd_nsf_debug.so")
+
+
+def build_debug(verbose: bool = False) -> Path:
+    """Developer aid: the same library with -DNSF_DEBUG (cycle-counter timeline stores, run-time ablation switches) as
+    ``libsbi_amd_nsf_debug.so``.  Never loaded by default: ``SBI_AMD_LIB=<path>`` selects it (tools/timeline.py)."""
+    return _build_locked(verbose, debug=True)
+
+
+def _build_locked(verbose: bool, debug: bool = False) -> Path:
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = hipcc_path()
-    objdir = CSRC / "build"
+    objdir = CSRC / ("build_debug" if debug else "build")
     objdir.mkdir(exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
     flags += os.environ.get("SBI_AMD_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DNSF_PRIO_MODE=1)
+    if debug:
+        flags.append("-DNSF_DEBUG")
 
     def compile_one(src: str):
         obj = objdir / (Path(src).stem + ".o")
@@ -93,17 +104,21 @@ def _build_locked(verbose: bool) -> Path:
     srcs = [s for s in SOURCES if (CSRC / s).exists()]
     with ThreadPoolExecutor(max_workers=min(12, len(srcs))) as pool:
         objs = list(pool.map(compile_one, srcs))
-    tmp = LIB_PATH.with_suffix(".so.tmp")
+    out = DEBUG_LIB_PATH if debug else LIB_PATH
+    tmp = out.with_suffix(".so.tmp")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
-    os.replace(tmp, LIB_PATH)          # atomic: a concurrent dlopen never sees a half-written file
-    HASH_PATH.write_text(source_hash() + "\n")
-    return LIB_PATH
+    os.replace(tmp, out)          # atomic: a concurrent dlopen never sees a half-written file
+    if not debug:
+        HASH_PATH.write_text(source_hash() + "\n")
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build_debug(verbose=True) if "--debug" in sys.argv else build(force=True, verbose=True))

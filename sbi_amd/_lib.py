@@ -202,7 +202,21 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if _LIB is not None:
         return _LIB
     path = _build.LIB_PATH
-    if not path.exists() and not build_if_missing:
+    import os
+
+    override = os.environ.get("SBI_AMD_LIB")
+    if override:      # developer aid (the -DNSF_DEBUG build of tools/timeline.py): never silent
+        import sys
+
+        print(f"sbi_amd: WARNING: SBI_AMD_LIB={override}: loading a non-default kernel library "
+              "(debug / timing build: results may be INVALID)", file=sys.stderr)
+        path = _build.Path(override)
+        build_if_missing = False
+        if not path.exists():
+            raise RuntimeError(f"SBI_AMD_LIB={override} does not exist")
+    if override:
+        pass
+    elif not path.exists() and not build_if_missing:
         raise RuntimeError(f"{path} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
     if build_if_missing:
         try:
@@ -222,7 +236,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
             else:
                 warnings.warn(f"sbi_amd: {path.name} has no source hash next to it and cannot be checked against the "
                               f"sources ({e}); loading it as is (only the ABI version is verified)", stacklevel=2)
-    elif _build.needs_build():
+    elif not override and _build.needs_build():
         raise RuntimeError(f"{path} is stale (built from different sources); rebuild it with "
                            "`python -c 'import __graft_entry__ as g; g.build()'`")
     lib = ctypes.CDLL(str(path))

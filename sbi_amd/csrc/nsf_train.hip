@@ -146,21 +146,11 @@ extern "C" int64_t sbi_amd_nsf_train_workspace_floats(const sbi_amd_nsf_config* 
   return ws_layout(pl, tp, n > 0 ? n : 1, &a, &b, &c, &d, &e, &f, &g);
 }
 
-template int launch_bwd_k<10>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
-                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
-                              long long*, hipStream_t);
-extern template int launch_bwd_k<5>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
-                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
-                              long long*, hipStream_t);
-extern template int launch_bwd_k<4>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
-                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
-                              long long*, hipStream_t);
-extern template int launch_bwd_k<16>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
-                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
-                              long long*, hipStream_t);
-extern template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
-                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
-                              long long*, hipStream_t);
+template int launch_bwd_k<10>(const NsfPlan&, const TrainPlan&, const BwdIo&, hipStream_t);
+extern template int launch_bwd_k<5>(const NsfPlan&, const TrainPlan&, const BwdIo&, hipStream_t);
+extern template int launch_bwd_k<4>(const NsfPlan&, const TrainPlan&, const BwdIo&, hipStream_t);
+extern template int launch_bwd_k<16>(const NsfPlan&, const TrainPlan&, const BwdIo&, hipStream_t);
+extern template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, const BwdIo&, hipStream_t);
 
 // Which kernel family laid out a workspace: the two halves of a training pass take the decision independently from
 // (cfg, n) and a process-wide threshold (sbi_amd_nsf_set_coop_max_rows); a backward pass that would read a stash the
@@ -272,20 +262,33 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
   float* gz[2] = {workspace + o_gza, workspace + o_gzb};
   float* partial = workspace + o_part;
   long long* dbg = (long long*)(workspace + ws_total - 2048);
-  for (int t = pl.T - 1; t >= 0; --t) {
-    const float* up = (t == pl.T - 1) ? noise : gz[(t + 1) & 1];
-    float* dn = gz[t & 1];
-    const float* z_in = stash + (int64_t)t * n * pl.D;
-    switch (cfg->K) {
-#define CASE_K(KK) \
-  case KK: rc = launch_bwd_k<KK>(pl, tp, t, packed, zstats, z_in, x, up, row_weight, uniform_weight, n, x_rows, dn, \
-                                 partial, grad_theta_out, astash, (t == 0 && sbi_amd_dbg_timeline()) ? dbg : nullptr, st); break;
-      CASE_K(4) CASE_K(5) CASE_K(8) CASE_K(10) CASE_K(16)
-#undef CASE_K
-      default: rc = SBI_AMD_E_UNSUPPORTED;
-    }
-    if (rc) return rc;
+  BwdIo io{};
+  io.t_hi = pl.T - 1;
+  io.t_lo = 0;
+  io.packed = packed;
+  io.zstats = zstats;
+  io.stash = stash;
+  io.x = x;
+  io.noise = noise;
+  io.gz[0] = gz[0];
+  io.gz[1] = gz[1];
+  io.row_w = row_weight;
+  io.uni_w = uniform_weight;
+  io.n = n;
+  io.x_rows = x_rows;
+  io.partial = partial;
+  io.grad_theta = grad_theta_out;
+  io.astash = astash;
+  io.dbg = sbi_amd_dbg_timeline() ? dbg : nullptr;
+  switch (cfg->K) {
+    case 4: rc = launch_bwd_k<4>(pl, tp, io, st); break;
+    case 5: rc = launch_bwd_k<5>(pl, tp, io, st); break;
+    case 8: rc = launch_bwd_k<8>(pl, tp, io, st); break;
+    case 10: rc = launch_bwd_k<10>(pl, tp, io, st); break;
+    case 16: rc = launch_bwd_k<16>(pl, tp, io, st); break;
+    default: rc = SBI_AMD_E_UNSUPPORTED;
   }
+  if (rc) return rc;
   float* sq_out = workspace + ws_total - 2048 - (thr_sq_parts(pl, tp) + 3) / 4 * 4;
   hipLaunchKernelGGL(nsf_grad_reduce_kernel, dim3((tp.PLP / 4 + 63) / 64, pl.T), dim3(64 * RED_GROUPS), 0, st, pl, tp,
                      params, partial, grad_out, (const float*)(workspace + o_logp), loss_out, (long long)n, sq_out);

@@ -3,6 +3,4 @@
 #include <stdlib.h>
 #include "nsf_train_kernel.h"
 
-template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, int, const float*, const float*, const float*, const float*,
-                              const float*, const float*, float, int64_t, int64_t, float*, float*, float*, const float*,
-                              long long*, hipStream_t);
+template int launch_bwd_k<8>(const NsfPlan&, const TrainPlan&, const BwdIo&, hipStream_t);

@@ -200,7 +200,8 @@ __device__ __forceinline__ void dw_gemm(const float* __restrict__ Ast, const flo
                                         int abl = 0, f4* accb = nullptr) {
   if (abl & 1) return;
   const float ones_b = id.j == 0 ? 1.f : 0.f;   // B operand of the bias-gradient MFMA: column 0 = sum over the rows
-  constexpr int KS = TR_ROWS / 4, LA = TR_LA;
+  // few MFMAs per K-step (NT < 4) cover less LDS latency per step: look further ahead
+  constexpr int KS = TR_ROWS / 4, LA = NT >= 4 ? TR_LA : 2 * TR_LA;
   // K-step s covers tile rows krow(s) + 4 g (not 4 s + g): with the gradient tiles' row stride 68 (= 4 mod 64,
   // what keeps the ROW waves' accesses conflict-free) the four k-slots of an A read then sit 16 banks apart
   // (4 * 68 = 16 mod 64) instead of 4, so the read is conflict-free as well (it was a 4-way conflict).
@@ -245,7 +246,7 @@ __device__ __forceinline__ void dw_gemm_rs(const float* __restrict__ Ast, const 
                                            int acol0, int bcol0, const LaneId& id, f4 (&acc)[NT], int nt_on = NT,
                                            int abl = 0) {
   if (abl & 1) return;
-  constexpr int KS = TR_ROWS / 4, LA = TR_LA;
+  constexpr int KS = TR_ROWS / 4, LA = NT >= 4 ? TR_LA : 2 * TR_LA;
   const float* ap = Ast + 4 * id.g * SA + acol0 + id.j;     // rows krow(s) + 4 g, see dw_gemm
   const float* bp = Bst + 4 * id.g * SBr + bcol0 + id.j;
   float a[LA + 1], b[LA + 1][NT];
@@ -662,21 +663,55 @@ __device__ __forceinline__ constexpr int cm_reps(const NsfPlan& pl) { return pl.
 // NTW = n-tiles of the narrow input-side weight gradients (d W0, d Wc): 1 when their inputs (+ bias column) fit
 // 16 columns, which frees 12 accumulator registers in the grad waves.
 // SP = 0: layout from the kernel arguments; SP = 1 + parity: the static default layout (kStaticPl / kStaticTp)
+// Everything a backward launch reads and writes.  One launch walks the transforms t_hi ... t_lo (last -> first): the
+// dependency between consecutive transforms is tile-local (the gradient wrt a transform's input rows is produced and
+// consumed by the same lanes of the same persistent workgroup), so no grid-wide rendezvous is needed between them.
+struct BwdIo {
+  int t_hi, t_lo;
+  const float* packed;       // T weight images
+  const float* zstats;
+  const float* stash;        // (T, n, D) per-transform input states of the forward pass
+  const float* x;
+  const float* noise;        // (n, D) base-space point: upstream "gradient" of the last transform
+  float* gz[2];              // ping-pong (n, D): gradient wrt transform t's input lives in gz[t & 1]
+  const float* row_w;
+  float uni_w;
+  long long n, x_rows;
+  float* partial;            // (T, grid, PLP) per-workgroup partial gradients
+  float* grad_theta;
+  const float* astash;
+  long long* dbg;
+};
 template <int K, int KSH, int NBT, int NCH, int NTW, bool HB, int SP = 0>
 __global__ void __launch_bounds__(128 * TR_NW, HB ? 1 : 2)
-nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const float* __restrict__ packed,
-                     const float* __restrict__ zstats, const float* __restrict__ z_in,
-                     const float* __restrict__ x, const float* __restrict__ gz_up,
-                     const float* __restrict__ row_w, const float uni_w, long long n, long long x_rows,
-                     float* __restrict__ gz_dn, float* __restrict__ partial, float* __restrict__ grad_theta,
-                     const float* __restrict__ astash, long long* __restrict__ dbg) {
+nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
+  const float* __restrict__ packed = io.packed;
+  const float* __restrict__ zstats = io.zstats;
+  const float* __restrict__ x = io.x;
+  const float* __restrict__ row_w = io.row_w;
+  const float uni_w = io.uni_w;
+  const long long n = io.n, x_rows = io.x_rows;
+  float* __restrict__ partial = io.partial;
+  float* __restrict__ grad_theta = io.grad_theta;
+  const float* __restrict__ astash = io.astash;
+  long long* __restrict__ dbg = io.dbg;
   // LAYOUT fields (offsets, strides, counts) come from `pl` / `tp`: compile-time constants in the SP instantiations;
   // the floating-point spline constants, the debug switches and the batch-dependent fields from the arguments
   const NsfPlan& pl = SP != 0 ? kStaticPl : pl_;
   const TrainPlan& tp = SP != 0 ? kStaticTp : tp_;
+  // Debug aids exist in -DNSF_DEBUG builds only (tools/timeline.py, tools/ablate.sh): the shipped kernels carry neither
+  // the cycle-counter stores nor the run-time ablation switches.
+#ifdef NSF_DEBUG
   const int dbg_tile_sel = pl_.ablate & 128;   // timeline of the 2nd tile (warm caches) instead of the 1st
-#define TS(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tile == (int)(blockIdx.x + (dbg_tile_sel ? gridDim.x : 0))) \
+#define NSF_ABL(bit) (pl_.ablate & (bit))
+#define NSF_ABLV (pl_.ablate)
+#define TS(i) do { if (dbg && t == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tile == (int)(blockIdx.x + (dbg_tile_sel ? gridDim.x : 0))) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define NSF_ABL(bit) 0
+#define NSF_ABLV 0
+#define TS(i) do { } while (0)
+#endif
   constexpr int PT = (3 * K - 1 + 15) / 16;
   constexpr int DCHB = (4 / PT) > 2 ? 2 : (4 / PT);   // dim slots per chunk (lane pairs: <= 2)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -687,18 +722,15 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
   constexpr int NB = cm ? 1 : NBT;            // ctx_mlp: one hidden H x H gradient tile set
   const int SLOTS = nsf_ast_slots(pl);           // (a compile-time constant in the static-plan instantiations)
   const int reps = cm_reps(pl);                  // ctx_mlp: applications of the shared hidden layer (>= 1)
-  const int par = cm ? 0 : (SP != 0 ? SP - 1 : (t & 1));
-  const ShapeDesc& S = pl.shape[par];
   const int D = pl.D, C = pl.C;
   constexpr int SA = TR_SA, SB = TR_SB;
   const int SS = tp.SS;
-  const bool is_last = (t == pl.T - 1);
   float* Bt = lds + tp.o_B;
   float* Bs = lds + tp.o_Bs;
   const float* x_mean = zstats + 2 * D;
   const float* x_std = x_mean + C;
 
-  if (pl_.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): NaN-filled LDS exposes reads of unwritten locations
+  if (NSF_ABL(256)) {   // test aid (SBI_AMD_ABLATE=256): NaN-filled LDS exposes reads of unwritten locations
     for (int i = tid; i < tp.lds_floats; i += blockDim.x) lds[i] = __builtin_nanf("");
     __syncthreads();
   }
@@ -706,26 +738,36 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
   // [final layer, U, L] during the chunk steps and the hidden layers during the block phase, re-staged every
   // tile; `ldsF` makes the final-layer / LU offsets of the plan valid in either mode.
   const bool ov = tp.overlay != 0;
-  const float* img = packed + (long long)t * pl.img_floats;
-  const int F0 = ov ? S.final_off : 0;
-  const float* ldsF = lds - F0;
-  if (!ov) stage_layer(lds, img, pl.lds_w_train_floats, tid, blockDim.x);
+  if (!ov) stage_layer(lds, packed + (long long)io.t_hi * pl.img_floats, pl.lds_w_train_floats, tid, blockDim.x);
   if (tid == 0) *(int*)(lds + tp.o_cnt) = 0;
   if (tid < 32) {
     lds[tp.o_xs + tid] = tid < C ? x_mean[tid] : 0.f;
     lds[tp.o_xs + 32 + tid] = tid < C ? 1.f / x_std[tid] : 1.f;
   }
   const float* xs = lds + tp.o_xs;
-
-  const LinDesc& L0 = S.lin[0];
-  const LinDesc& LF = S.lin[S.fin];
-  const int nch = tp.nch[par];
-  const int nt0 = (S.in0 + 1 + 15) / 16;        // n-tiles of d W0 (incl. the bias column)
   const int ntc = (C + 1 + 15) / 16;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  // after the chunk steps: AX receives g_h from the grad waves, AY is the other gradient tile
-  const int o_AX = (nch & 1) ? tp.o_A1 : tp.o_A0;
-  const int o_AY = (nch & 1) ? tp.o_A0 : tp.o_A1;
+  // does this workgroup walk more than one tile per transform?  (then the first tile of the NEXT transform can be
+  // prefetched during the last tile of this one: its upstream gradient was written several tiles ago)
+  const bool multi = (int)(blockIdx.x + gridDim.x) < tp_.ntiles;
+  // Per-transform view of the layout.  SP != 0: the two mask parities of the static default layout differ only in WHICH
+  // dims are transformed (2 d + par) -- every offset, stride and count is the same (static_assert below), so ONE body
+  // serves both and takes `par` as a run-time scalar.
+#define BWD_T_VARS                                                                                                  \
+  const int par = cm ? 0 : (t & 1);                                                                                 \
+  const ShapeDesc& S = pl.shape[(SP != 0 || cm) ? 0 : par];                                                         \
+  const bool is_last = (t == pl.T - 1);                                                                             \
+  const float* img = packed + (long long)t * pl.img_floats;                                                         \
+  const int F0 = ov ? S.final_off : 0;                                                                              \
+  const float* ldsF = lds - F0;                                                                                     \
+  const LinDesc& L0 = S.lin[0];                                                                                     \
+  const LinDesc& LF = S.lin[S.fin];                                                                                 \
+  const int nch = tp.nch[(SP != 0 || cm) ? 0 : par];                                                                \
+  const int nt0 = (S.in0 + 1 + 15) / 16;        /* n-tiles of d W0 (incl. the bias column) */                       \
+  /* after the chunk steps: AX receives g_h from the grad waves, AY is the other gradient tile */                   \
+  const int o_AX = (nch & 1) ? tp.o_A1 : tp.o_A0;                                                                   \
+  const int o_AY = (nch & 1) ? tp.o_A0 : tp.o_A1;                                                                   \
+  (void)img; (void)L0; (void)LF; (void)nt0; (void)o_AX; (void)o_AY; (void)ldsF; (void)is_last;
 
   if (wave < TR_NW) {
     // =========================== row waves ===========================
@@ -741,25 +783,36 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
     // state, context, upstream gradient and row weight of the NEXT tile are requested a whole block phase
     // ahead (clamped addresses instead of predicated loads), so the tile prologue never waits on HBM
     float zv[4], gv[4], xv[8], wv;
-    auto fetch_inputs = [&](int tile_, const LaneId& id) {
+    auto fetch_inputs = [&](int t_, int tile_, const LaneId& id) {
       const long long row_ = (long long)tile_ * TR_ROWS + arow0 + id.j;
       const long long rs = row_ < n ? row_ : 0;
       const long long xr = (x_rows == n) ? rs : (x_rows == 1 ? 0 : rs % x_rows);
+      const float* z_in = io.stash + (long long)t_ * n * D;
+      const float* gz_up = (t_ == pl.T - 1) ? io.noise : io.gz[(t_ + 1) & 1];
+      const int d_id_ = pl.shape[(SP != 0 || cm) ? 0 : (t_ & 1)].d_id;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int d = id.g + 4 * u;
         const int dc = d < D ? d : 0;
         zv[u] = z_in[rs * D + dc];
-        gv[u] = gz_up[rs * D + dc];
+        // (written by these very lanes while they walked the transform above: agent-scope load, not an L1 hit)
+        gv[u] = __hip_atomic_load(gz_up + rs * D + dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int c = id.g + 4 * u - S.d_id;
+        const int c = id.g + 4 * u - d_id_;
         xv[u] = x[xr * C + ((c >= 0 && c < C) ? c : 0)];
       }
       wv = row_w ? row_w[rs] : uni_w;
     };
-    fetch_inputs(blockIdx.x, id0);
+    for (int t = io.t_hi; t >= io.t_lo; --t) {
+    BWD_T_VARS
+    // (lane coordinates re-materialised per transform as well: LICM would otherwise carry every lane-dependent address
+    //  of the loop body across the whole launch)
+    LaneId id = id0;
+    asm volatile("" : "+v"(id.lane), "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
+    float* __restrict__ gz_dn = io.gz[t & 1];
+    if (t == io.t_hi || !multi) fetch_inputs(t, blockIdx.x, id);
     for (int tile = blockIdx.x; tile < tp_.ntiles; tile += gridDim.x) {
       // Re-materialise the lane coordinates per tile: otherwise LICM hoists every
       // lane-dependent LDS address of the body out of the persistent loop and the
@@ -811,7 +864,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       float gus_r[4] = {0.f, 0.f, 0.f, 0.f};     // g_u of dims 4 g + ii, kept for the LU parameter gradients
       if (cm) {   // no LULinear for theta-dim 1: the transform output IS the layer output
         for (int k = id.g; k < D; k += 4) gys[id.j * pl.ZW + k] = gzs[id.j * pl.ZW + k];
-      } else if (!(pl_.ablate & 64)) {
+      } else if (!(NSF_ABL(64))) {
         // two chained 16 x 16 mat-vecs on the matrix pipe (was: two VALU mat-vecs with an LDS round trip between them,
         // ~3 k cycles of the prologue while the partner grad wave waits at K0): D fragment reg r of lane (j, g) is dim
         // 4 g + r of row j, and a K-step that covers k = 4 g + s takes that register as its B operand unchanged.
@@ -858,7 +911,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         const int dd = d0 + slot;
         float* pp = lds + ((c & 1) ? tp.o_A1 : tp.o_A0) + trow * SA + slot * TR_SLOT(PT);
         if (slot < DCHB) {
-          if (dd < S.d_tr && !(pl_.ablate & 4)) {
+          if (dd < S.d_tr && !(NSF_ABL(4))) {
             const int zi = id.j * pl.ZW + 2 * dd + par;
             float yv, gxv;
             rq_spline_pair_bwd<K>(pp, tp.PTW, zs[zi], gys[zi], gld, pl_, part, yv, gxv);
@@ -884,7 +937,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         ast_load<KSH>(ast, 1 + 4 * (NB - 1), bt1);
       }
       float us_r[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!cm && !(pl_.ablate & 64)) {     // u[i] = sum_k U[i][k] y[k] on the matrix pipe: K-step s covers k = 4 s + g
+      if (!cm && !(NSF_ABL(64))) {     // u[i] = sum_k U[i][k] y[k] on the matrix pipe: K-step s covers k = 4 s + g
         const float* Um = ldsF + S.l_U;
         float au[4], by[4];
 #pragma unroll
@@ -912,9 +965,12 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       // last -> first transform on one stream: the first contribution of the first launch overwrites)
       const bool want_gx = tp_.grad_x != nullptr;
       float* gx_row = want_gx ? tp_.grad_x + (valid ? row : 0) * C : nullptr;
-      {   // next tile's inputs (the last tile re-reads itself: harmless)
+      {   // next tile's inputs; after the last tile of a transform: the first tile of the next one (its upstream
+          // gradient left this workgroup several tiles ago -- unless this IS the only tile: then the fetch waits for
+          // the top of the next transform; re-reading the own tile is harmless)
         const int nxt = tile + (int)gridDim.x;
-        fetch_inputs(nxt < tp_.ntiles ? nxt : tile, id);
+        const bool more = nxt < tp_.ntiles, hop = !more && multi && t > io.t_lo;
+        fetch_inputs(hop ? t - 1 : t, more ? nxt : (hop ? (int)blockIdx.x : tile), id);
       }
 
       if (cm) {
@@ -937,7 +993,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           __syncthreads();                           // X1
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[1], id, ga, gb, pl_.ablate);
+          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[1], id, ga, gb, NSF_ABLV);
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = gb[mt];     // gradient wrt h_i (post-relu)
         }
@@ -977,7 +1033,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           TS(21 + 8 * b);
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb, pl_.ablate);       // d relu(t1)
+          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[3 + 3 * b], id, ga, gb, NSF_ABLV);       // d relu(t1)
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -993,7 +1049,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
           TS(24 + 8 * b);
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt) gb[mt] = zero4;
-          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb, pl_.ablate);       // d relu(h_b)
+          gemm_T_breg<KSH, NSF_HT>(lds, S.lin[2 + 3 * b], id, ga, gb, NSF_ABLV);       // d relu(h_b)
 #pragma unroll
           for (int mt = 0; mt < NSF_HT; ++mt)
 #pragma unroll
@@ -1011,7 +1067,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       {
         f4 gin[1];
         gin[0] = zero4;
-        gemm_T_breg<KSH, 1>(lds, L0, id, gh, gin, pl_.ablate);
+        gemm_T_breg<KSH, 1>(lds, L0, id, gh, gin, NSF_ABLV);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 4 * r + id.g;     // identity feature slot
@@ -1045,13 +1101,31 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       }
       TS(43);
     }
+    // the next transform's weight image (nobody reads the old one after the last tile's Y2; the grad waves are busy
+    // writing their partial gradients meanwhile; the S0 barrier of the next tile publishes it)
+    if (t > io.t_lo && !ov) stage_layer(lds, packed + (long long)(t - 1) * pl.img_floats, pl.lds_w_train_floats, tid, 64 * TR_NW);
+    }   // transforms
 
   } else {
     // =========================== grad waves ==========================
     const int gw = wave - TR_NW;
     int* cnt = (int*)(lds + tp.o_cnt);
     int sync_target = 0;
-    // weight-gradient accumulators owned by this wave (m-tile = wave) for the whole launch
+    const LaneId id0 = id;
+    f4 hl[NSF_HT];
+    auto fetch_hl = [&](int t_, int tile_) {
+      const long long nt16 = (n + 15) / 16;   // clamp as the row waves do: unstashed wave-tiles hold stale memory
+      const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
+      const float* ast = astash + (((long long)t_ * nt16 + wt16) * SLOTS) * 1024 +
+                         4 * id0.lane;
+      ast_load<KSH>(ast, cm ? reps : 4 * NB, hl);
+    };
+    fetch_hl(io.t_hi, blockIdx.x);
+    for (int t = io.t_hi; t >= io.t_lo; --t) {
+    BWD_T_VARS
+    LaneId id = id0;      // (re-materialised per transform: keeps the write-out's ~130 lane-dependent offsets out of registers)
+    asm volatile("" : "+v"(id.lane), "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
+    // weight-gradient accumulators owned by this wave (m-tile = wave) for the whole transform
     f4 acc0[NTW], accC[NB][NTW], acc1[NB][4], acc2[NB][4], accF[NCH][4], accLU[1];
     f4 acc1b[HB ? NB : 1], acc2b[HB ? NB : 1], accFb[HB ? NCH : 1];   // bias gradients when hidden_features == 64
   #pragma unroll
@@ -1073,21 +1147,15 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       for (int i = 0; i < 4; ++i) accF[c][i] = zero4;
     accLU[0] = zero4;
 
-    const LaneId id0 = id;
-    f4 hl[NSF_HT];
-    auto fetch_hl = [&](int tile_) {
-      const long long nt16 = (n + 15) / 16;   // clamp as the row waves do: unstashed wave-tiles hold stale memory
-      const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
-      const float* ast = astash + (((long long)t * nt16 + wt16) * SLOTS) * 1024 +
-                         4 * id0.lane;
-      ast_load<KSH>(ast, cm ? reps : 4 * NB, hl);
-    };
-    fetch_hl(blockIdx.x);
     for (int tile = blockIdx.x; tile < tp_.ntiles; tile += gridDim.x) {
       LaneId id = id0;
       asm volatile("" : "+v"(id.j), "+v"(id.g), "+v"(id.iperm));
       const int trow = 16 * gw + id.j;             // rows of the partner row wave
-      const int tile_nxt = tile + (int)gridDim.x < tp_.ntiles ? tile + (int)gridDim.x : tile;
+      // next h_last: the next tile's, or after the last tile the first tile of the next transform (the stash is
+      // read-only here)
+      const bool more_tiles = tile + (int)gridDim.x < tp_.ntiles;
+      const int t_nxt = more_tiles ? t : (t > io.t_lo ? t - 1 : t);
+      const int tile_nxt = more_tiles ? tile + (int)gridDim.x : (t > io.t_lo ? (int)blockIdx.x : tile);
       __syncthreads();                             // S0
       if (ov) {
         stage_layer(lds, img + F0, pl.lds_w_train_floats - F0, tid, blockDim.x);
@@ -1098,7 +1166,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
       // during the previous tile), its activation-tile rows, and the spline parameters of chunk 0
       stage_DB(Bt, SB, trow, id, hl, false);
       if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
-      if (!(pl_.ablate & 32)) final_layer_chunk_T<PT, KSH>(ldsF, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
+      if (!(NSF_ABL(32))) final_layer_chunk_T<PT, KSH>(ldsF, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
       f4 gh[NSF_HT];
   #pragma unroll
       for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
@@ -1121,21 +1189,21 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
 #pragma unroll
               for (int i = 0; i < (PT < 3 ? PT : 1); ++i) part[i] = af[i];
               dw_gemm<(PT < 3 ? PT : 1), TR_SA, TR_SB, true>(lds + oa, Bt, 16 * (gw % PT), 16 * PT * (gw / PT), id, part,
-                                                             PT < 3 ? PT : 1, pl_.ablate, nullptr);
+                                                             PT < 3 ? PT : 1, NSF_ABLV, nullptr);
 #pragma unroll
               for (int i = 0; i < (PT < 3 ? PT : 1); ++i) af[i] = part[i];
             } else
             dw_gemm<4, TR_SA, TR_SB, true>(lds + oa, Bt, 16 * gw + (gw / PT < DCHB ? gw / PT : 0), 0, id,
-                                           accF[k - 1 < NCH ? k - 1 : 0], 4, pl_.ablate,
+                                           accF[k - 1 < NCH ? k - 1 : 0], 4, NSF_ABLV,
                                            HB ? &accFb[k - 1 < NCH ? k - 1 : 0] : nullptr);
             TS(13 + k);
-            if (!(pl_.ablate & 2)) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
+            if (!(NSF_ABL(2))) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
           }
           TS(3 + 2 * k);
           if (k + 1 < nch) {
             if (k >= 1) { sync_target += 4; grad_wave_sync(cnt, sync_target, id.lane); }   // all d Wf reads of that tile done
             TS(17 + k);
-            if (!(pl_.ablate & 32))
+            if (!(NSF_ABL(32)))
               final_layer_chunk_T<PT, KSH>(ldsF, lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, pl, tp, S, id,
                                            hl, (k + 1) * DCHB);
           }
@@ -1152,30 +1220,30 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         for (int i = reps; i >= 1; --i) {
           if (i < reps) __syncthreads();           // X0
           __syncthreads();                         // X1
-          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, pl_.ablate, HB ? &acc1b[0] : nullptr);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[0], 4, NSF_ABLV, HB ? &acc1b[0] : nullptr);
         }
       } else {
   #pragma unroll
         for (int b = NB - 1; b >= 0; --b) {
           __syncthreads();                         // X1
           TS(21 + 8 * b);
-          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, pl_.ablate, HB ? &acc2b[b] : nullptr);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc2[b], 4, NSF_ABLV, HB ? &acc2b[b] : nullptr);
           TS(22 + 8 * b);
           __syncthreads();                         // X2
           // d Wc under the row waves' re-staging of AY / B (the matrix pipe used to idle between X2 and X3): its
           // operands -- g_c in AX, the static input tile Bs -- are not rewritten before X4 / the initial layer's Y1
-          dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, S.d_id, id, accC[b], ntc, pl_.ablate);
+          dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, S.d_id, id, accC[b], ntc, NSF_ABLV);
           __syncthreads();                         // X3
           TS(24 + 8 * b);
-          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[b], 4, pl_.ablate, HB ? &acc1b[b] : nullptr);
+          dw_gemm<4, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 0, id, acc1[b], 4, NSF_ABLV, HB ? &acc1b[b] : nullptr);
           TS(25 + 8 * b);
           if (b > 0) __syncthreads();              // X4
         }
       }
       __syncthreads();                             // Y1
       TS(41);
-      fetch_hl(tile_nxt);   // next tile's h_last: lands under this tile's last two phases
-      dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, 0, id, acc0, nt0, pl_.ablate);
+      fetch_hl(t_nxt, tile_nxt);   // next tile's h_last: lands under this tile's last two phases
+      dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, 0, id, acc0, nt0, NSF_ABLV);
       TS(42);
       __syncthreads();                             // Y2
       if (gw < 2 && !cm) dw_gemm<1, TR_SA, TR_SB, true>(lds + o_AY, Bt, 16 * gw, 16 * gw, id, accLU);
@@ -1268,41 +1336,30 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const int t, const 
         }
       }
     }
+    }   // transforms
 
   }
+#undef BWD_T_VARS
+#undef NSF_ABL
+#undef NSF_ABLV
+#undef TS
 }
 
 
 // ---- launch helpers
 template <int K, int KSH, int NB, int NCH, int NTW, bool HB = false, int SP = 0>
-static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
-                      const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
-                      int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
-                      const float* astash, long long* dbg, hipStream_t st) {
+static int launch_bwd(const NsfPlan& pl, const TrainPlan& tp, const BwdIo& io, hipStream_t st) {
   auto kern = nsf_bwd_layer_kernel<K, KSH, NB, NCH, NTW, HB, SP>;
   const int lds_bytes = 4 * tp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(tp.grid), dim3(128 * TR_NW), (size_t)lds_bytes, st, pl, tp, t, packed, zstats, z_in, x,
-                     gz_up, row_w, uni_w, (long long)n, (long long)x_rows, gz_dn, partial, grad_theta, astash, dbg);
+  hipLaunchKernelGGL(kern, dim3(tp.grid), dim3(128 * TR_NW), (size_t)lds_bytes, st, pl, tp, io);
   return (int)hipGetLastError();
 }
 
 template <int K>
-int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* packed, const float* zstats,
-                        const float* z_in, const float* x, const float* gz_up, const float* row_w, float uni_w,
-                        int64_t n, int64_t x_rows, float* gz_dn, float* partial, float* grad_theta,
-                        const float* astash, long long* dbg, hipStream_t st) {
-#define BWD_ARGS pl, tp, t, packed, zstats, z_in, x, gz_up, row_w, uni_w, n, x_rows, gz_dn, partial, grad_theta, \
-                 astash, dbg, st
-  if constexpr (K == 10) {     // the benchmark configuration: layout folded into the kernel (see kStaticPl)
-    if (plan_is_static_default(pl, tp))
-      return (t & 1) ? launch_bwd<10, 13, 2, 3, 1, false, 2>(BWD_ARGS) : launch_bwd<10, 13, 2, 3, 1, false, 1>(BWD_ARGS);
-  }
-  const int nchmax = tp.nch[0] > tp.nch[1] ? tp.nch[0] : tp.nch[1];
-  // narrow input side (d W0 / d Wc fit one 16-column n-tile incl. the bias column): the common case
-  int in0max = pl.shape[0].in0 > pl.shape[1].in0 ? pl.shape[0].in0 : pl.shape[1].in0;
-  const bool wide = (in0max + 1 > 16) || (pl.C + 1 > 16);
+static int launch_bwd_one(const NsfPlan& pl, const TrainPlan& tp, const BwdIo& io, int nchmax, bool wide, hipStream_t st) {
+#define BWD_ARGS pl, tp, io, st
 #define BWD_NCH(KS, NBV) \
   switch (nchmax) { \
     case 1: return wide ? launch_bwd<K, KS, NBV, 1, 2>(BWD_ARGS) : launch_bwd<K, KS, NBV, 1, 1>(BWD_ARGS); \
@@ -1330,3 +1387,40 @@ int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, int t, const float* pac
 #undef BWD_ARGS
 }
 
+// the two mask parities of the static default layout are the same layout (ONE kernel body, run-time parity)
+constexpr bool static_parities_match() {
+  const ShapeDesc& a = kStaticPl.shape[0];
+  const ShapeDesc& b = kStaticPl.shape[1];
+  if (a.d_id != b.d_id || a.d_tr != b.d_tr || a.in0 != b.in0 || a.fin != b.fin || a.final_off != b.final_off ||
+      a.l_U != b.l_U || a.l_L != b.l_L || a.l_lub != b.l_lub || a.g_lu != b.g_lu || a.n_params != b.n_params)
+    return false;
+  for (int i = 0; i <= a.fin; ++i) {
+    const LinDesc& x = a.lin[i];
+    const LinDesc& y = b.lin[i];
+    if (x.in != y.in || x.out != y.out || x.ldk != y.ldk || x.rows != y.rows || x.l_w != y.l_w || x.l_b != y.l_b ||
+        x.g_w != y.g_w || x.g_b != y.g_b || x.ksteps != y.ksteps)
+      return false;
+  }
+  return kStaticTp.nch[0] == kStaticTp.nch[1];
+}
+static_assert(static_parities_match(), "static default layout: both mask parities must share one layout");
+
+// Runs the transforms io.t_hi ... io.t_lo.  The static default layout takes them all in ONE launch (no kernel boundaries,
+// the next image staged under the partial-gradient write-out); every other shape one launch per transform.
+template <int K>
+int launch_bwd_k(const NsfPlan& pl, const TrainPlan& tp, const BwdIo& io_all, hipStream_t st) {
+  if constexpr (K == 10) {     // the benchmark configuration: layout folded into the kernel (see kStaticPl)
+    if (plan_is_static_default(pl, tp)) return launch_bwd<10, 13, 2, 3, 1, false, 1>(pl, tp, io_all, st);
+  }
+  const int nchmax = tp.nch[0] > tp.nch[1] ? tp.nch[0] : tp.nch[1];
+  // narrow input side (d W0 / d Wc fit one 16-column n-tile incl. the bias column): the common case
+  int in0max = pl.shape[0].in0 > pl.shape[1].in0 ? pl.shape[0].in0 : pl.shape[1].in0;
+  const bool wide = (in0max + 1 > 16) || (pl.C + 1 > 16);
+  for (int t = io_all.t_hi; t >= io_all.t_lo; --t) {
+    BwdIo io = io_all;
+    io.t_hi = io.t_lo = t;
+    const int rc = launch_bwd_one<K>(pl, tp, io, nchmax, wide, st);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -3,6 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SBI_AMD_TIMELINE"] = "1"
+os.environ.setdefault("SBI_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sbi_amd", "libsbi_amd_nsf_debug.so"))   # python -m sbi_amd._build --debug
 from bench import make_data, build_estimator
 from sbi_amd.inference.trainers.fused import FusedTrainStep
 dev = torch.device("cuda:0")
