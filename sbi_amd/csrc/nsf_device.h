@@ -452,10 +452,19 @@ __device__ __forceinline__ void conditioner_hidden(const float* __restrict__ lds
 // final_layer for the spline dims [d0, d0+NACT) -> per-wave LDS staging pst[slot][row][param].
 // NACT (active dim slots of this chunk) is a template parameter so the K loop is one
 // branch-free stream of MFMAs the scheduler can software-pipeline.
+// spline-parameter stash (training forward): `pstw` = this wave-tile's block + 4 * lane (nsf_plan.h, nsf_pst_tile_floats)
+template <int PT>
+__device__ __forceinline__ void pst_store(float* __restrict__ pstw, int dd, int pt, const f4& v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f4*>(pstw + (dd * PT + pt) * 256));
+}
+template <int PT>
+__device__ __forceinline__ f4 pst_load(const float* __restrict__ pstw, int dd, int pt) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f4*>(pstw + (dd * PT + pt) * 256));
+}
 template <int PT, int KSH, int NACT>
 __device__ __forceinline__ void final_layer_chunk_n(const float* __restrict__ lds, float* __restrict__ pst,
                                                     const NsfPlan& pl, const ShapeDesc& S, const LaneId& id,
-                                                    const f4 (&h)[NSF_HT], int d0) {
+                                                    const f4 (&h)[NSF_HT], int d0, float* __restrict__ pstw = nullptr) {
   const LinDesc& L = S.lin[S.fin];
   f4 acc[NACT][PT];
   int ro[NACT][PT];
@@ -485,6 +494,12 @@ __device__ __forceinline__ void final_layer_chunk_n(const float* __restrict__ ld
 #pragma unroll
       for (int r = 0; r < 4; ++r)   // rows are 16*PT+1 wide: padding outputs (zeros) are stored too, no branch
         pst[sl * pl.DS + id.j * pl.PSW + 16 * pt + 4 * r + id.g] = acc[sl][pt][r];
+  if (pstw) {
+#pragma unroll
+    for (int sl = 0; sl < NACT; ++sl)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) pst_store<PT>(pstw, d0 + sl, pt, acc[sl][pt]);
+  }
 }
 
 // The same final-layer GEMM as a resumable stream: operator() issues ONE MFMA (K-step major, then
@@ -535,9 +550,16 @@ struct FinalLayerStream {
   }
   // nyield = number of yield points the host routine went through (steps 0 .. nyield-1 are done)
   template <int NYIELD>
-  __device__ __forceinline__ void finish(float* __restrict__ pst, const NsfPlan& pl, const LaneId& id) {
+  __device__ __forceinline__ void finish(float* __restrict__ pst, const NsfPlan& pl, const LaneId& id,
+                                         float* __restrict__ pstw = nullptr, int d0 = 0) {
 #pragma unroll
     for (int n = NYIELD; n < NACT * PT * KSH; ++n) step(n);
+    if (pstw) {
+#pragma unroll
+      for (int sl = 0; sl < NACT; ++sl)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) pst_store<PT>(pstw, d0 + sl, pt, acc[sl][pt]);
+    }
 #pragma unroll
     for (int sl = 0; sl < NACT; ++sl)
 #pragma unroll

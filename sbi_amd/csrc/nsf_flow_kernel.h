@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(INV ? 768 : 512)
 nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
-                float* __restrict__ astash, long long* __restrict__ dbg) {
+                float* __restrict__ astash, float* __restrict__ pstash, long long* __restrict__ dbg) {
 #define TSF(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && li == 1) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
   constexpr int PT = (3 * K - 1 + 15) / 16;
@@ -179,6 +179,12 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       const long long tile16 = (long long)blockIdx.x * nw + wave;
       if (tile16 < nt16) ast = astash + (((long long)t * nt16 + tile16) * nsf_ast_slots(pl)) * 1024 + 4 * id.lane;
     }
+    float* pstw = nullptr;      // spline-parameter stash of this wave-tile (training forward only)
+    if (!INV && !BX && pstash) {
+      const long long nt16 = (n + 15) / 16;
+      const long long tile16 = (long long)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(wave);
+      if (tile16 < nt16) pstw = pstash + ((long long)t * nt16 + tile16) * nsf_pst_tile_floats(pl) + 4 * id.lane;
+    }
     if (!(pl_.ablate & 4)) conditioner_hidden<KSH, BX>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast, bxt);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
@@ -216,8 +222,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
           nn = nn < pl.DCH ? nn : pl.DCH;
           if (INV && pref_on && c == nchunks - 1 && li + 1 < pl.T)      // sampling direction: next image = transform t - 1
             stage_issue<NPRE>(packed + (long long)(t - 1) * pl.img_floats, pl.img_floats, tid, nthreads, pre);
-          if (nn == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, c * pl.DCH);
-          else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, c * pl.DCH);
+          if (nn == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, c * pl.DCH, pstw);
+          else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, c * pl.DCH, pstw);
           wave_lds_fence();
           spline_chunk(c, NoYield());
           wave_lds_fence();
@@ -225,8 +231,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       } else {
       {
         const int n0 = S.d_tr < pl.DCH ? S.d_tr : pl.DCH;
-        if (n0 == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 0);
-        else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, 0);
+        if (n0 == 2) final_layer_chunk_n<PT, KSH, 2>(lds, pst, pl, S, id, h, 0, pstw);
+        else final_layer_chunk_n<PT, KSH, 1>(lds, pst, pl, S, id, h, 0, pstw);
       }
       wave_lds_fence();
       for (int c = 0; c < nchunks; ++c) {
@@ -240,12 +246,12 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
           FinalLayerStream<PT, KSH, 2> fs;
           fs.init(lds, pl, S, id, h, dnext);
           spline_chunk(c, fs);
-          fs.template finish<5 * K + 1>(pnext, pl, id);
+          fs.template finish<5 * K + 1>(pnext, pl, id, pstw, dnext);
         } else if (nnext == 1) {
           FinalLayerStream<PT, KSH, 1> fs;
           fs.init(lds, pl, S, id, h, dnext);
           spline_chunk(c, fs);
-          fs.template finish<5 * K + 1>(pnext, pl, id);
+          fs.template finish<5 * K + 1>(pnext, pl, id, pstw, dnext);
         } else {
           spline_chunk(c, NoYield());
         }
@@ -314,11 +320,11 @@ static inline bool nsf_bx_applies(const NsfPlan& pl, int nw, int64_t x_rows, con
 template <int K, int KSH, bool INV, int SP = 0, bool BX = false>
 static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                        const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                       float* z_stash, float* astash, hipStream_t stream) {
+                       float* z_stash, float* astash, float* pstash, hipStream_t stream) {
   if constexpr (!BX) {
     if (nsf_bx_applies(pl, nw, x_rows, z_stash, astash))
       return launch_flow<K, KSH, INV, SP, true>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash,
-                                                astash, stream);
+                                                astash, pstash, stream);
   }
   const int64_t lds_bytes = nsf_lds_bytes(pl, nw) + (BX ? nsf_bx_extra_bytes(pl) : 0);
   auto kern = nsf_flow_kernel<K, KSH, INV, SP, BX>;
@@ -327,7 +333,7 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
   const int64_t rows_per_wg = 16 * nw;
   const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nw), (size_t)lds_bytes, stream, pl, packed, zstats, in,
-                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash, astash,
+                     x, (long long)n, (long long)x_rows, out_main, out_aux, z_stash, astash, pstash,
                      sbi_amd_dbg_timeline() ? (long long*)out_aux : nullptr);
   return (int)hipGetLastError();
 }
@@ -335,18 +341,18 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
 template <int K, bool INV>
 static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                            const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                           float* z_stash, float* astash, hipStream_t st) {
+                           float* z_stash, float* astash, float* pstash, hipStream_t st) {
   if constexpr (K == 10) {     // the benchmark configuration: layout folded into the kernel
     if constexpr (!INV) {
       if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8))
-        return launch_flow<10, 13, INV, 8>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+        return launch_flow<10, 13, INV, 8>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
     } else {
       if (nw == 12 && flow_plan_is_static(pl, kStaticFlow12))
-        return launch_flow<10, 13, INV, 12>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+        return launch_flow<10, 13, INV, 12>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
     }
   }
   if (pl.KSH == 13)
-    return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
-  return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, st);
+    return launch_flow<K, 13, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
+  return launch_flow<K, 16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
 }
 

@@ -77,6 +77,13 @@ int nsf_plan_for_rows(const sbi_amd_nsf_config* cfg, int64_t n, NsfPlan* pl, int
 // nsf_pack_kernel from the flat parameters; kernels stage a layer with a float4 copy.
 // activation-stash slots per (transform, 16-row tile): h_0 | per block t1 t2 sigmoid(gate) h; ctx_mlp: h_1 ... h_{reps+1}
 constexpr int nsf_ast_slots(const NsfPlan& pl) { return pl.ctx_mlp ? 1 + pl.ctx_reps : 1 + 4 * pl.NB; }
+// spline-parameter stash of the training pass (round 6): the forward kernel keeps the final layer's outputs -- the raw
+// spline parameters -- per (transform, 16-row wave-tile, transformed dim, parameter m-tile) as one 16-byte word per lane
+// in MFMA D-fragment order (lane (j, g), register r = parameter 16 pt + 4 r + g of row j), and the wave-specialised
+// backward reloads them instead of recomputing the final layer (130 of ~1000 MFMAs per 16 rows at the defaults).
+constexpr int nsf_pst_tile_floats(const NsfPlan& pl) {
+  return (pl.shape[0].d_tr > pl.shape[1].d_tr ? pl.shape[0].d_tr : pl.shape[1].d_tr) * pl.PT * 256;
+}
 static inline int64_t nsf_packed_floats(const NsfPlan& pl) { return (int64_t)pl.T * pl.img_floats; }
 static inline int64_t nsf_lds_bytes(const NsfPlan& pl, int nw) {
   return 4ll * ((int64_t)pl.lds_w_floats + (int64_t)nw * pl.sc_total);

@@ -102,12 +102,13 @@ static bool fast_path_refuses(int rc) {
 
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
-                       float* z_stash, float* astash, void* stream);
+                       float* z_stash, float* astash, float* pstash, void* stream);
 
 // workgroups of nsf_grad_reduce_kernel = partial sums of squares it leaves behind the activation stash
 static inline int64_t thr_sq_parts(const NsfPlan& pl, const TrainPlan& tp) { return (int64_t)((tp.PLP / 4 + 63) / 64) * pl.T; }
 static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int64_t* o_stash, int64_t* o_noise,
-                         int64_t* o_logp, int64_t* o_gza, int64_t* o_gzb, int64_t* o_part, int64_t* o_ast) {
+                         int64_t* o_logp, int64_t* o_gza, int64_t* o_gzb, int64_t* o_part, int64_t* o_ast,
+                         int64_t* o_pst = nullptr) {
   int64_t o = 0;
   *o_stash = o; o += (int64_t)pl.T * n * pl.D;
   *o_noise = o; o += n * pl.D;
@@ -119,6 +120,8 @@ static int64_t ws_layout(const NsfPlan& pl, const TrainPlan& tp, int64_t n, int6
   o = (o + 3) / 4 * 4;
   *o_ast = o;   // activation stash: T x ceil(n/16) wave-tiles x slots x 1024 floats
   o += (int64_t)pl.T * ((n + 15) / 16) * nsf_ast_slots(pl) * 1024;
+  if (o_pst) *o_pst = o;   // spline-parameter stash: T x ceil(n/16) wave-tiles x d_tr x PT x 256 floats
+  if (TR_PSTASH) o += (int64_t)pl.T * ((n + 15) / 16) * nsf_pst_tile_floats(pl);
   o += (thr_sq_parts(pl, tp) + 3) / 4 * 4;   // partial sums of squares of the reduced gradient (the clip's norm)
   o += 2048;   // debug timeline (SBI_AMD_TIMELINE): last 1024 int64 of the workspace
   return o;
@@ -199,10 +202,10 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
   }
   if (rc) return rc;
   ws_family_record(workspace, WS_FAM_THROUGHPUT, n);
-  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
-  ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
+  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast, o_pst;
+  ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast, &o_pst);
   rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, workspace + o_logp, workspace + o_noise,
-                          workspace + o_stash, workspace + o_ast, stream);
+                          workspace + o_stash, workspace + o_ast, TR_PSTASH ? workspace + o_pst : nullptr, stream);
   if (rc) return rc;
   if (logp_out) {
     hipError_t e = hipMemcpyAsync(logp_out, workspace + o_logp, sizeof(float) * n, hipMemcpyDeviceToDevice,
@@ -254,8 +257,8 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
   if (rc) return rc;
   tp.grad_x = grad_x_out;
   hipStream_t st = (hipStream_t)stream;
-  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast;
-  const int64_t ws_total = ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast);
+  int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast, o_pst;
+  const int64_t ws_total = ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast, &o_pst);
   float* astash = workspace + o_ast;
   float* stash = workspace + o_stash;
   float* noise = workspace + o_noise;
@@ -279,6 +282,7 @@ static int train_backward_impl(const sbi_amd_nsf_config* cfg, const float* param
   io.partial = partial;
   io.grad_theta = grad_theta_out;
   io.astash = astash;
+  io.pstash = TR_PSTASH ? workspace + o_pst : nullptr;
   io.dbg = sbi_amd_dbg_timeline() ? dbg : nullptr;
   switch (cfg->K) {
     case 4: rc = launch_bwd_k<4>(pl, tp, io, st); break;

@@ -32,6 +32,19 @@
 #ifndef TR_LA
 #define TR_LA 2            // K-steps of operand lookahead in the LDS-fed MFMA loops
 #endif
+// A/B switches of round 6 (defaults = what measured best; -D... in SBI_AMD_EXTRA_HIPCC_FLAGS rebuilds a variant)
+#ifndef TR_SPLINE_PRIO
+#define TR_SPLINE_PRIO 0   // s_setprio of the row waves while they run the (VALU-only, latency-bound) spline chunks
+#endif
+#ifndef TR_H_SPLIT
+#define TR_H_SPLIT 0       // hand g_h to the row waves BEFORE the last chunk's d Wf (one more barrier, ~2.5 k cycles less wait)
+#endif
+#ifndef TR_PSTASH
+#define TR_PSTASH 1        // the forward pass stashes the spline parameters, the backward pass does not recompute the final layer
+#endif
+#ifndef TR_NO_S0
+#define TR_NO_S0 1         // no workgroup barrier between tiles: the grad waves rendezvous among themselves instead
+#endif
 
 struct TrainPlan {
   int SA, SB, SS;          // row strides: gradient tiles A0/A1, activation tile B, static input tile Bs
@@ -543,12 +556,19 @@ __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int pl
     dact = (part ? d_n : d_i) * r * r;       // slope = exp(clip(u)): slope * clip'(u)
   }
   const float gud = (inside && kd >= 1 && kd <= K - 1) ? (part ? gdn : gdi) * dact : 0.f;
+  // Branch-free write-out (it was a ladder of K exec-masked single stores): both lanes hold both knots' gradients after
+  // one swap -- slot idx - 1 (knot idx) <- g_lo, slot idx (knot idx + 1) <- g_hi, every other slot 0 -- and split the
+  // K - 1 slots plus the padding [3K - 1, plen) between them as unconditional selects.
+  const float gud_o = xchg32(gud);
+  const float gk_lo = part ? gud_o : gud, gk_hi = part ? gud : gud_o;
+  constexpr int KH = K / 2;                   // part 0: slots [0, KH), part 1: slots [KH, K - 1) and the padding
+  float* ds_out = p + 2 * K;
   if (part == 0) {
 #pragma unroll
-    for (int k = 0; k < K - 1; ++k)
-      if (k != idx) p[2 * K + k] = (k + 1 == idx) ? gud : 0.f;
+    for (int k = 0; k < KH; ++k) ds_out[k] = (k + 1 == idx) ? gk_lo : ((k == idx) ? gk_hi : 0.f);
   } else {
-    if (idx <= K - 2) p[2 * K + idx] = gud;
+#pragma unroll
+    for (int k = KH; k < K - 1; ++k) ds_out[k] = (k + 1 == idx) ? gk_lo : ((k == idx) ? gk_hi : 0.f);
     for (int k = 3 * K - 1; k < plen; ++k) p[k] = 0.f;
   }
 }
@@ -680,6 +700,7 @@ struct BwdIo {
   float* partial;            // (T, grid, PLP) per-workgroup partial gradients
   float* grad_theta;
   const float* astash;
+  const float* pstash;       // spline-parameter stash of the forward pass (nullptr: the final layer is recomputed)
   long long* dbg;
 };
 template <int K, int KSH, int NBT, int NCH, int NTW, bool HB, int SP = 0>
@@ -824,21 +845,27 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
       const float wn = valid ? wv : 0.f;
       const float gld = -wn;                       // d(sum w loss)/d(any logabsdet term)
       const int trow = arow0 + id.j;
-      __syncthreads();                             // S0: weights staged / previous tile fully consumed
+      // S0 (weights staged / previous tile fully consumed).  Between two tiles of one transform a row wave needs no
+      // barrier at all: after Y2 it touches only its own scratch rows and Bs (whose readers finished before Y2), and the
+      // shared tiles are next written by the grad waves, who rendezvous among themselves (TR_NO_S0).
+      const bool need_s0 = !TR_NO_S0 || ov || tile == (int)blockIdx.x;
+      if (need_s0) __syncthreads();
       if (ov) {
         stage_layer(lds, img + F0, pl.lds_w_train_floats - F0, tid, blockDim.x);
         __syncthreads();
       }
       TS(0);
       // ---- P0: state, context, upstream gradient (prefetched) -> LDS
+      float gzr[4];       // upstream gradient of dims g + 4 u (zero past D / past the last row)
       {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int d = id.g + 4 * u;
+          const float gz = (valid && d < D) ? gv[u] : 0.f;
+          gzr[u] = is_last ? wn * gz : gz;                    // last transform: d/dz_T of w*(0.5|z|^2) = w z
           if (d < D) {
             zs[id.j * pl.ZW + d] = valid ? zv[u] : 0.f;
-            const float gz = valid ? gv[u] : 0.f;
-            gzs[id.j * pl.ZW + d] = is_last ? wn * gz : gz;   // last transform: d/dz_T of w*(0.5|z|^2) = w z
+            gzs[id.j * pl.ZW + d] = gzr[u];
           }
         }
         wave_lds_fence();
@@ -878,7 +905,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           al[s4] = Lm[(4 * s4 + id.g) * 16 + id.j];
-          bz[s4] = gzs[id.j * pl.ZW + 4 * s4 + id.g];
+          bz[s4] = gzr[s4];       // = gzs[row j][4 s4 + g]: the prefetched registers already have this layout
           au[s4] = Um[(4 * id.g + s4) * 16 + id.j];
         }
 #pragma unroll
@@ -905,6 +932,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
       // ---- chunk steps: spline forward + reverse mode in place on the grad waves' parameter rows
       f4 bt1[NSF_HT], bt2[NSF_HT], bsg[NSF_HT];   // block temporaries, loaded one phase ahead of their use
       f4 hpre[cm ? 2 : 1][NSF_HT];                // block input h_b (ctx_mlp: h1, h2)
+      if (TR_SPLINE_PRIO) __builtin_amdgcn_s_setprio(TR_SPLINE_PRIO);
       for (int c = 0; c < nch; ++c) {
         const int d0 = c * DCHB;
         const int slot = id.g & 1, part = id.g >> 1;
@@ -926,6 +954,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
         TS(3 + c);
         __syncthreads();                           // K_{c+1}
       }
+      if (TR_SPLINE_PRIO) __builtin_amdgcn_s_setprio(0);
       // ---- step nch (the grad waves finish d Wf / Wf^T g of the last chunk): fetch the last block's
       // temporaries and do the LULinear forward piece its parameter gradients need, u = U y
       if (cm) {     // the last application's input and output: h_reps, h_{reps+1} (stash slots reps - 1, reps)
@@ -951,6 +980,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) us_r[ii] = uv[ii];
       }
+      {   // next tile's inputs (requested while this wave waits for g_h); after the last tile of a transform: the first
+          // tile of the next one (its upstream gradient left this workgroup several tiles ago -- unless this IS the only
+          // tile: then the fetch waits for the top of the next transform; re-reading the own tile is harmless)
+        const int nxt = tile + (int)gridDim.x;
+        const bool more = nxt < tp_.ntiles, hop = !more && multi && t > io.t_lo;
+        fetch_inputs(hop ? t - 1 : t, more ? nxt : (hop ? (int)blockIdx.x : tile), id);
+      }
       TS(8);
       __syncthreads();                             // H: g_h = Wf^T g_p of this wave's rows is in AX
       if (ov) {   // nobody needs the final layer / LU any more this tile: the hidden layers take the region
@@ -958,6 +994,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
         __syncthreads();
       }
       TS(9);
+      // TR_H_SPLIT: the grad waves published g_h BEFORE the last chunk's d Wf, which still reads AY and B: everything up
+      // to this wave's writes into those two tiles runs under that GEMM, then barrier H2
+      const bool hsplit = TR_H_SPLIT && !cm && !ov;
       f4 gh[NSF_HT];
       load_D(lds + o_AX, SA, trow, id, gh);
       wave_lds_fence();
@@ -965,13 +1004,6 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
       // last -> first transform on one stream: the first contribution of the first launch overwrites)
       const bool want_gx = tp_.grad_x != nullptr;
       float* gx_row = want_gx ? tp_.grad_x + (valid ? row : 0) * C : nullptr;
-      {   // next tile's inputs; after the last tile of a transform: the first tile of the next one (its upstream
-          // gradient left this workgroup several tiles ago -- unless this IS the only tile: then the fetch waits for
-          // the top of the next transform; re-reading the own tile is harmless)
-        const int nxt = tile + (int)gridDim.x;
-        const bool more = nxt < tp_.ntiles, hop = !more && multi && t > io.t_lo;
-        fetch_inputs(hop ? t - 1 : t, more ? nxt : (hop ? (int)blockIdx.x : tile), id);
-      }
 
       if (cm) {
         // ---- ctx_mlp: h_{i+1} = relu(W_h h_i + b_h), i = reps ... 1: the SAME hidden layer walked back `reps` times
@@ -1016,10 +1048,15 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
                 ga[mt][r] = gh[mt][r] * sgm;                                 // d t2
                 gc[mt][r] = gh[mt][r] * bt2[mt][r] * sgm * (1.f - sgm);      // d (Wc c + bc)
               }
-            stage_D(lds + o_AY, SA, trow, id, ga, false);
-            stage_D(lds + o_AX, SA, trow, id, gc, false);
+            stage_D(lds + o_AX, SA, trow, id, gc, false);     // (own rows of AX: nobody else reads them before X1)
             if (want_gx)
               ctx_grad_update<KSH>(lds, S.lin[1 + 3 * b], id, gc, 0, C, xs, gx_row, valid, is_last && b == NB - 1);
+            if (hsplit && b == NB - 1) {
+              TS(50);
+              __syncthreads();                     // H2: the last chunk's d Wf has consumed AY and B
+              TS(51);
+            }
+            stage_D(lds + o_AY, SA, trow, id, ga, false);
           }
           stage_DB(Bt, SB, trow, id, bt1, true);
           if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;      // bias column
@@ -1120,7 +1157,35 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
                          4 * id0.lane;
       ast_load<KSH>(ast, cm ? reps : 4 * NB, hl);
     };
+    // spline parameters of the NEXT chunk, requested from the forward pass's stash one phase ahead (they replace the
+    // final-layer recompute: 52 MFMAs + 60 LDS reads per chunk and wave)
+    constexpr bool use_pst = TR_PSTASH != 0;      // (the host passes the stash whenever the kernels were built for it)
+    f4 pq[DCHB][PT];
+    auto pq_load = [&](int t_, int tile_, int c_) {
+      const long long nt16 = (n + 15) / 16;
+      const long long wt16 = (long long)tile_ * TR_NW + gw < nt16 ? (long long)tile_ * TR_NW + gw : nt16 - 1;
+      const float* pstw = io.pstash + ((long long)t_ * nt16 + wt16) * nsf_pst_tile_floats(pl) + 4 * id0.lane;
+      const int d_tr_ = pl.shape[(SP != 0 || cm) ? 0 : (t_ & 1)].d_tr;
+#pragma unroll
+      for (int sl = 0; sl < DCHB; ++sl) {
+        const int dd = c_ * DCHB + sl;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) pq[sl][pt] = pst_load<PT>(pstw, dd < d_tr_ ? dd : d_tr_ - 1, pt);   // (dead slot: any valid word)
+      }
+    };
+    // parameters -> this wave's rows of a gradient tile, exactly where final_layer_chunk_T puts them
+    auto pq_store = [&](float* __restrict__ arow, const LaneId& id, int c_, int d_tr_) {
+#pragma unroll
+      for (int sl = 0; sl < DCHB; ++sl)
+        if (c_ * DCHB + sl < d_tr_) {        // (wave-uniform; a dead slot's rows are zero-filled by the row wave)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) arow[id.j * SA + sl * TR_SLOT(PT) + 16 * pt + 4 * r + id.g] = pq[sl][pt][r];
+        }
+    };
     fetch_hl(io.t_hi, blockIdx.x);
+    if (use_pst) pq_load(io.t_hi, blockIdx.x, 0);
     for (int t = io.t_hi; t >= io.t_lo; --t) {
     BWD_T_VARS
     LaneId id = id0;      // (re-materialised per transform: keeps the write-out's ~130 lane-dependent offsets out of registers)
@@ -1156,7 +1221,9 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
       const bool more_tiles = tile + (int)gridDim.x < tp_.ntiles;
       const int t_nxt = more_tiles ? t : (t > io.t_lo ? t - 1 : t);
       const int tile_nxt = more_tiles ? tile + (int)gridDim.x : (t > io.t_lo ? (int)blockIdx.x : tile);
-      __syncthreads();                             // S0
+      const bool need_s0 = !TR_NO_S0 || ov || tile == (int)blockIdx.x;
+      if (need_s0) __syncthreads();                // S0
+      else { sync_target += 4; grad_wave_sync(cnt, sync_target, id.lane); }   // every d LU read of the previous tile is done
       if (ov) {
         stage_layer(lds, img + F0, pl.lds_w_train_floats - F0, tid, blockDim.x);
         __syncthreads();
@@ -1166,7 +1233,10 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
       // during the previous tile), its activation-tile rows, and the spline parameters of chunk 0
       stage_DB(Bt, SB, trow, id, hl, false);
       if (!HB && id.g == 0) Bt[trow * SB + il_col(pl.H)] = 1.f;   // bias column
-      if (!(NSF_ABL(32))) final_layer_chunk_T<PT, KSH>(ldsF, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
+      if (use_pst) {
+        pq_store(lds + tp.o_A0 + 16 * gw * SA, id, 0, S.d_tr);
+        if (1 < nch) pq_load(t, tile, 1);
+      } else if (!(NSF_ABL(32))) final_layer_chunk_T<PT, KSH>(ldsF, lds + tp.o_A0 + 16 * gw * SA, pl, tp, S, id, hl, 0);
       f4 gh[NSF_HT];
   #pragma unroll
       for (int mt = 0; mt < NSF_HT; ++mt) gh[mt] = zero4;
@@ -1180,6 +1250,13 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
           if (k >= 1) {
             const int oa = ((k - 1) & 1) ? tp.o_A1 : tp.o_A0;
             // m-tile gw = 16 spline-parameter columns of dim slot gw / PT (the second slot starts one float late)
+            const bool hsplit = TR_H_SPLIT && !cm && !ov;
+            if (hsplit && k == nch) {     // critical path first: g_h to the partner row wave, THEN this chunk's d Wf
+              if (!(NSF_ABL(2))) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
+              stage_D(lds + o_AX, SA, trow, id, gh, false);
+              TS(9);
+              __syncthreads();            // H
+            }
             if (!HB && DCHB == 2 && k == nch && (S.d_tr & 1)) {
               // last chunk of an odd number of dims: only dim slot 0 is live (PT parameter tiles).  Instead of two
               // waves multiplying the dead slot's zeros, the four waves split the live tiles' n-tiles: wave gw takes
@@ -1197,19 +1274,23 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
                                            accF[k - 1 < NCH ? k - 1 : 0], 4, NSF_ABLV,
                                            HB ? &accFb[k - 1 < NCH ? k - 1 : 0] : nullptr);
             TS(13 + k);
-            if (!(NSF_ABL(2))) wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
+            if (!(hsplit && k == nch) && !(NSF_ABL(2)))
+              wft_chunk<PT>(ldsF, LF, pl, S, id, lds + oa + 16 * gw * SA, SA, (k - 1) * DCHB, gh);
           }
           TS(3 + 2 * k);
           if (k + 1 < nch) {
             if (k >= 1) { sync_target += 4; grad_wave_sync(cnt, sync_target, id.lane); }   // all d Wf reads of that tile done
             TS(17 + k);
-            if (!(NSF_ABL(32)))
+            if (use_pst) {
+              pq_store(lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, id, k + 1, S.d_tr);
+              if (k + 2 < nch) pq_load(t, tile, k + 2);
+            } else if (!(NSF_ABL(32)))
               final_layer_chunk_T<PT, KSH>(ldsF, lds + (((k + 1) & 1) ? tp.o_A1 : tp.o_A0) + 16 * gw * SA, pl, tp, S, id,
                                            hl, (k + 1) * DCHB);
           }
-          if (k == nch) stage_D(lds + o_AX, SA, trow, id, gh, false);   // hand g_h to the partner row wave
+          if (k == nch && !(TR_H_SPLIT && !cm && !ov)) stage_D(lds + o_AX, SA, trow, id, gh, false);   // hand g_h to the partner row wave
           TS(4 + 2 * k);
-          __syncthreads();                         // K_{k+1} / H
+          __syncthreads();                         // K_{k+1} / H (TR_H_SPLIT: H2)
           if (ov && k == nch) {                    // mirrors the row waves: hidden layers take the weight region
             stage_layer(lds, img, S.final_off, tid, blockDim.x);
             __syncthreads();
@@ -1243,6 +1324,7 @@ nsf_bwd_layer_kernel(const NsfPlan pl_, const TrainPlan tp_, const BwdIo io) {
       __syncthreads();                             // Y1
       TS(41);
       fetch_hl(t_nxt, tile_nxt);   // next tile's h_last: lands under this tile's last two phases
+      if (use_pst) pq_load(t_nxt, tile_nxt, 0);
       dw_gemm_rs<NTW, TR_SA>(lds + o_AX, Bs, SS, 16 * gw, 0, id, acc0, nt0, NSF_ABLV);
       TS(42);
       __syncthreads();                             // Y2
