@@ -679,7 +679,7 @@ class PosteriorEstimatorTrainer:
             # the final epoch was never scored by `_converged` (base.py:1122-1129)
             if self._val_loss < self._best_val_loss:
                 self._best_val_loss = self._val_loss
-                self._best_model_state_dict = deepcopy(net.state_dict())
+                self._best_model_state_dict = deepcopy(PosteriorEstimatorTrainer._native_state(net))
             elif self._best_model_state_dict is not None:
                 self._load_state(net, self._best_model_state_dict)
             warnings.warn("Maximum number of epochs `max_num_epochs={}` reached, but network has not yet fully "
@@ -700,6 +700,19 @@ class PosteriorEstimatorTrainer:
         return deepcopy(net)
 
     @staticmethod
+    def _native_state(net: nn.Module):
+        """The estimator's state in the kernels' own two-tensor form (the public `state_dict()` speaks nflows' key
+        names: ~100 per-layer copies, not something to build once per improved epoch)."""
+        inner = getattr(net, "net", None)
+        if inner is None or not hasattr(inner, "native_state_dict"):
+            return net.state_dict()
+        inner._native_state_dict = True
+        try:
+            return net.state_dict()
+        finally:
+            inner._native_state_dict = False
+
+    @staticmethod
     def _load_state(net: nn.Module, sd) -> None:
         net.load_state_dict(sd)
         inner = getattr(net, "net", None)
@@ -716,11 +729,12 @@ class PosteriorEstimatorTrainer:
             self._best_val_loss = self._val_loss
             self._epochs_since_last_improvement = 0
             if snapshot is None:
-                self._best_model_state_dict = deepcopy(net.state_dict())
+                self._best_model_state_dict = deepcopy(PosteriorEstimatorTrainer._native_state(net))
             else:
-                self._best_model_state_dict = type(net.state_dict())(
+                native = PosteriorEstimatorTrainer._native_state(net)
+                self._best_model_state_dict = type(native)(
                     (k, snapshot["params"].clone() if k == "net.flat_params" else v.clone())
-                    for k, v in net.state_dict().items())
+                    for k, v in native.items())
         else:
             self._epochs_since_last_improvement += 1
         if self._epochs_since_last_improvement > stop_after_epochs - 1:

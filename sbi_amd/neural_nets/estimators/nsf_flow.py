@@ -126,6 +126,53 @@ class NSFNet(nn.Module):
             persistent=False,
         )
         self.reset_parameters()
+        # Checkpoints are interchangeable with the reference's: `state_dict()` speaks nflows' key names (what
+        # `deepcopy(neural_net.state_dict())` / `load_state_dict` of sbi's trainer and users' save / load code see,
+        # trainers/base.py:1275-1281, tests/save_and_load_test.py:23-43) and `load_state_dict()` accepts them -- as
+        # well as the native two-tensor form (`flat_params`, `zstats`) of earlier versions of this package.
+        self._register_state_dict_hook(NSFNet._emit_nflows_keys)
+        self._register_load_state_dict_pre_hook(self._accept_nflows_keys, with_module=False)
+
+    _NATIVE_KEYS = ("flat_params", "zstats")
+
+    @staticmethod
+    def _emit_nflows_keys(module, state_dict, prefix, local_metadata):
+        """state_dict hook: replace the native entries by the reference's keys."""
+        if getattr(module, "_native_state_dict", False):
+            return state_dict
+        for k in NSFNet._NATIVE_KEYS:
+            state_dict.pop(prefix + k, None)
+        for k, v in module.nflows_state_dict(prefix=prefix, with_masks=True).items():
+            state_dict[k] = v
+        return state_dict
+
+    def _accept_nflows_keys(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """load_state_dict pre-hook: nflows-keyed entries under `prefix` become the native pair."""
+        if prefix + "flat_params" in state_dict:
+            return      # native form
+        mine = {k: v for k, v in state_dict.items() if k.startswith(prefix + "_transform.") or k.startswith(prefix + "_embedding_net.0._")
+                or k.startswith(prefix + "_distribution.")}
+        if not mine:
+            return      # nothing of ours: let the regular missing-key report speak
+        flat = self.flat_params.detach().clone()
+        zst = self.zstats.detach().clone()
+        try:
+            self._fill_from_nflows(mine, prefix, flat, zst)
+        except (KeyError, ValueError) as e:
+            error_msgs.append(f"NSFNet: cannot read the nflows-keyed checkpoint: {e!r}")
+            return
+        for k in mine:
+            del state_dict[k]
+        state_dict[prefix + "flat_params"] = flat
+        state_dict[prefix + "zstats"] = zst
+
+    def native_state_dict(self) -> "OrderedDict[str, Tensor]":
+        """The two-tensor form (`flat_params`, `zstats`): what the kernels read, no per-layer views."""
+        self._native_state_dict = True
+        try:
+            return self.state_dict()
+        finally:
+            self._native_state_dict = False
 
     # nflows-equivalent initialisation, drawing from torch's global generator in
     # the same order nflows constructs its modules (SURVEY.md 8a row a16).
@@ -200,14 +247,30 @@ class NSFNet(nn.Module):
                 yield pre + key, off, n, shape
                 off += n
 
-    def nflows_state_dict(self, prefix: str = "net.") -> "OrderedDict[str, Tensor]":
+    def nflows_state_dict(self, prefix: str = "net.", with_masks: bool = False) -> "OrderedDict[str, Tensor]":
         h = self.hyper
         sd: "OrderedDict[str, Tensor]" = OrderedDict()
         flat = self.flat_params.detach()
         if self.z_score_theta:
             sd[prefix + "_transform._transforms.0._shift"] = self.zstats[: h.D].clone()
             sd[prefix + "_transform._transforms.0._scale"] = self.zstats[h.D : 2 * h.D].clone()
+        seen_masks = set()
         for key, off, n, shape in self._slices():
+            if with_masks and ".transform_net." in key:
+                # the coupling transforms' index buffers (nflows CouplingTransform registers them): transform t masks
+                # with create_alternating_binary_mask(D, even = t % 2 == 0) (flow.py:1395-1416); theta-dim 1: mask [1]
+                tpre = key.split(".transform_net.")[0]
+                if tpre not in seen_masks:
+                    seen_masks.add(tpre)
+                    t = len(seen_masks) - 1
+                    dev = flat.device
+                    if h.ctx_mlp:
+                        ident, trans = torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.long, device=dev)
+                    else:
+                        trans = torch.arange(t % 2, h.D, 2, dtype=torch.long, device=dev)
+                        ident = torch.arange(1 - t % 2, h.D, 2, dtype=torch.long, device=dev)
+                    sd[prefix + tpre + ".identity_features"] = ident
+                    sd[prefix + tpre + ".transform_features"] = trans
             sd[prefix + key] = flat[off : off + n].reshape(shape).clone()
             if h.ctx_mlp and ".spline_predictor.2." in key:
                 # the reference's state_dict lists the shared hidden Linear under every index it occupies
@@ -220,6 +283,10 @@ class NSFNet(nn.Module):
 
     @torch.no_grad()
     def load_nflows_state_dict(self, sd: Dict[str, Tensor], prefix: str = "net.") -> None:
+        self._fill_from_nflows(sd, prefix, self.flat_params, self.zstats)
+
+    @torch.no_grad()
+    def _fill_from_nflows(self, sd: Dict[str, Tensor], prefix: str, flat_params: Tensor, zstats: Tensor) -> None:
         h = self.hyper
         for key, off, n, shape in self._slices():
             src = sd[prefix + key]
@@ -231,15 +298,15 @@ class NSFNet(nn.Module):
                     if dup is not None and not torch.equal(dup, src):
                         raise ValueError(f"{key}: the checkpoint holds different weights for the repeated hidden layer "
                                          "(ContextSplineMap shares ONE Linear across hidden_layers_spline_context)")
-            self.flat_params[off : off + n].copy_(src.reshape(-1).to(self.flat_params))
+            flat_params[off : off + n].copy_(src.reshape(-1).to(flat_params))
         if self.z_score_theta:
-            self.zstats[: h.D].copy_(sd[prefix + "_transform._transforms.0._shift"].reshape(-1))
-            self.zstats[h.D : 2 * h.D].copy_(sd[prefix + "_transform._transforms.0._scale"].reshape(-1))
+            zstats[: h.D].copy_(sd[prefix + "_transform._transforms.0._shift"].reshape(-1))
+            zstats[h.D : 2 * h.D].copy_(sd[prefix + "_transform._transforms.0._scale"].reshape(-1))
         if self.z_score_x:
             mean = sd[prefix + "_embedding_net.0._mean"].reshape(-1)
             std = sd[prefix + "_embedding_net.0._std"].reshape(-1)
-            self.zstats[2 * h.D : 2 * h.D + h.C].copy_(mean.expand(h.C))
-            self.zstats[2 * h.D + h.C :].copy_(std.expand(h.C))
+            zstats[2 * h.D : 2 * h.D + h.C].copy_(mean.expand(h.C))
+            zstats[2 * h.D + h.C :].copy_(std.expand(h.C))
 
 
 # --------------------------------------------------------------------- kernel calls
