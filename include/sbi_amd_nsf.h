@@ -237,6 +237,10 @@ int sbi_amd_nsf_build_step_map(const sbi_amd_nsf_config* cfg, int32_t images, co
                                int32_t* map, float* workspace, void* stream);
 int sbi_amd_nsf_table_pack(const sbi_amd_nsf_config* cfg, const float* params, float* packed, const int32_t* map,
                            void* stream);
+/* sbi_amd_nsf_table_pack only accepts a `map` that sbi_amd_nsf_build_step_map completed for the same configuration in
+ * this process (SBI_AMD_E_BADARG otherwise: the kernel trusts the table's header and gather indices).  Before freeing
+ * or reusing the map buffer, tell the library: a later allocation at the same address must not pass for a table. */
+int sbi_amd_nsf_release_step_map(const int32_t* map);
 
 /* One tick of the vectorised slice sampler for all chains (the loop body of SliceSamplerVectorized.run,
  * sbi/samplers/mcmc/slice_numpy.py:353-587): consumes the log-probabilities of `next_param` (what the batched
@@ -276,7 +280,7 @@ int sbi_amd_rq_spline(int32_t num_bins, int32_t inverse, float tail_bound, float
 int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg);
 
 /* Library/ABI version (major*100 + minor) and the gfx arch string it was built for. */
-#define SBI_AMD_NSF_ABI_VERSION 113
+#define SBI_AMD_NSF_ABI_VERSION 114
 int sbi_amd_nsf_abi_version(void);
 const char* sbi_amd_nsf_arch(void);
 

@@ -15,12 +15,12 @@ import torch
 from sbi_amd import _build
 
 _LIB: Optional[ctypes.CDLL] = None
-ABI_VERSION = 113    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
+ABI_VERSION = 114    # must equal sbi_amd_nsf_abi_version() (csrc/nsf_plan.cpp) and SBI_AMD_NSF_ABI_VERSION (include/)
 
 E_UNSUPPORTED, E_BADARG, E_LDS = -1, -2, -3
 _ERRORS = {
     E_UNSUPPORTED: "configuration not supported by the HIP kernels "
-    "(need 1<=D<=64, H<=64, num_bins in {4,5,8,10,16}, num_transforms<=16, num_blocks<=4)",
+    "(need 1<=D<=64, hidden_features<=64 (<=128 for theta-dim 2..16 with x-dim<=32), num_bins in {4,5,8,10,16}, num_transforms<=16, num_blocks<=4)",
     E_BADARG: "bad argument",
     E_LDS: "configuration needs more than 160 KiB of LDS per workgroup (one transform's weight image plus the "
     "kernel's tiles must fit: e.g. with hidden_features=50, 10 bins, 2 blocks training reaches x-dim 94 at theta-dim "
@@ -110,6 +110,7 @@ _SIGNATURES = {
     "sbi_amd_nsf_build_step_map": (
         c_int, [POINTER(NSFConfigC), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sbi_amd_nsf_table_pack": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sbi_amd_nsf_release_step_map": (c_int, [c_void_p]),
     "sbi_amd_shuffled_gather": (
         c_int,
         [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_int64, c_int64, c_void_p, c_void_p,

@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
   }
   const float invH = 1.0f / (float)H;
   FmPipe pipe;
-  pipe.init(lds, a.packed, pl.fgrp_off, pl.fgrp_floats, pl.nfg, pl.lds_fwd_floats, wave, lane, pl.ablate & 2);
+  pipe.init(lds, a.packed, pl.fgrp_off, pl.fgrp_floats, pl.nfg, pl.lds_fwd_floats, wave, lane, NSF_DBG_ABL(pl.ablate, 2));
   const float* wb = lds;
   int titer = -1;
   // theta / noise / t of the first four blocks travel one tile ahead (loaded during the previous tile's output
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         if (kb < pl.DB) {
-          if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_in + kb, c, g, blk4[kb]);
+          if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_in + kb, c, g, blk4[kb]);
           gemm_blk<HB>(wl, q.ldk, kb, blk4[kb], ie);
         }
       }
@@ -517,12 +517,12 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
           nv[i] = (MODE != 0 && f < D) ? nz[f] : 0.f;
         }
         const f4 v = in_block(kb, tv, nv);
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_in + kb, c, g, v);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_in + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, ie);
       }
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_ie + ob, c, g, ie[ob]);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_ie + ob, c, g, ie[ob]);
         h[ob] = gelu4(ie[ob]);
       }
     }
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         if (kb < pl.CB) {
-          if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_c + kb, c, g, blk4[kb]);
+          if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_c + kb, c, g, blk4[kb]);
           gemm_blk<HB>(wl, q.ldk, kb, blk4[kb], ce);
         }
       }
@@ -570,12 +570,12 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
           const int f = 16 * kb + 4 * g + i;
           v[i] = f < C ? (xr[f] - z_xm[f]) * z_xi[f] : 0.f;
         }
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_c + kb, c, g, v);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_c + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, ce);
       }
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_ce + ob, c, g, ce[ob]);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_ce + ob, c, g, ce[ob]);
         h[ob] = gelu4(ce[ob]);
       }
     }
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
     }
 #pragma unroll
     for (int ob = 0; ob < HB; ++ob) {
-      if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_h0 + ob, c, g, acc[ob]);
+      if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_h0 + ob, c, g, acc[ob]);
       h[ob] = gelu4(acc[ob]);
     }
     // ---- time embedding: sin/cos features -> Linear(E, H)
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
           }
           v[i] = val;
         }
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_te + kb, c, g, v);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_te + kb, c, g, v);
         gemm_blk<HB>(wl, q.ldk, kb, v, temb);
       }
     }
@@ -625,12 +625,12 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
       const FmLin& q = pl.lin[J_L0 + l];
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) acc[ob] = *reinterpret_cast<const f4*>(wb + q.lb + 16 * ob + 4 * g);
-      if (!(pl.ablate & 8)) gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
+      if (!NSF_DBG_ABL(pl.ablate, 8)) gemm_rr<HB, HB>(wb + q.lw + c * q.ldk + 4 * g, q.ldk, h, acc);
       float s1 = 0.f;
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_u + l * HB + ob, c, g, acc[ob]);
-        acc[ob] = ((pl.ablate & 4) ? acc[ob] : gelu4(acc[ob])) + temb[ob] + h[ob];
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_u + l * HB + ob, c, g, acc[ob]);
+        acc[ob] = (NSF_DBG_ABL(pl.ablate, 4) ? acc[ob] : gelu4(acc[ob])) + temb[ob] + h[ob];
         s1 += (acc[ob][0] + acc[ob][1]) + (acc[ob][2] + acc[ob][3]);
       }
       const float mu = sum_over_g(s1) * invH;
@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int ob = 0; ob < HB; ++ob) {
         const f4 sh = acc[ob] * rstd;
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_sh + l * HB + ob, c, g, sh);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_sh + l * HB + ob, c, g, sh);
         const f4 gam = *reinterpret_cast<const f4*>(wb + q.lb + 16 * HB + 16 * ob + 4 * g);
         const f4 bet = *reinterpret_cast<const f4*>(wb + q.lb + 32 * HB + 16 * ob + 4 * g);
         h[ob] = sh * gam + bet;
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_fwd_kernel(const FmPlan pl, 
             lsum += d * d;
           }
         }
-        if (MODE == 2 && !(pl.ablate & 1)) st_nat(wtb, pl.s_diff + ob, c, g, diff);
+        if (MODE == 2 && !NSF_DBG_ABL(pl.ablate, 1)) st_nat(wtb, pl.s_diff + ob, c, g, diff);
       }
       if (MODE != 0) {
         lsum = sum_over_g(lsum);
@@ -987,7 +987,7 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
   const float invH = 1.0f / (float)H;
   float* lnp = a.ln_part + ((long long)blockIdx.x * FM_WAVES + wave) * (long long)(L * 2 * 16 * HB);
   FmPipe pipe;
-  pipe.init(lds, a.packed, pl.bgrp_off, pl.bgrp_floats, pl.nbg, pl.lds_bwd_floats, wave, lane, pl.ablate & 2);
+  pipe.init(lds, a.packed, pl.bgrp_off, pl.bgrp_floats, pl.nbg, pl.lds_bwd_floats, wave, lane, NSF_DBG_ABL(pl.ablate, 2));
   const float* wb = lds;
   // Stash reads are issued one stage ahead, in place, as soon as the registers they refill are dead (see
   // FmPipe::enter_wait for where their first use must sit); the head of the next tile is fetched during the
@@ -1032,13 +1032,13 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
 #pragma unroll
       for (int ob = 0; ob < 4; ++ob) {
         if (ob < pl.DB) {
-          if (!(pl.ablate & 1)) st_tr(wtb, pl.g_v + ob, c, g, dv[ob]);
+          if (!NSF_DBG_ABL(pl.ablate, 1)) st_tr(wtb, pl.g_v + ob, c, g, dv[ob]);
           gemm_blk<HB>(wl, q.ldt, ob, dv[ob], gh);
         }
       }
       for (int ob = 4; ob < pl.DB; ++ob) {
         const f4 gv = ld_nat(wtb, pl.s_diff + ob, c, g) * wrow;
-        if (!(pl.ablate & 1)) st_tr(wtb, pl.g_v + ob, c, g, gv);
+        if (!NSF_DBG_ABL(pl.ablate, 1)) st_tr(wtb, pl.g_v + ob, c, g, gv);
         gemm_blk<HB>(wl, q.ldt, ob, gv, gh);
       }
     }
@@ -1077,8 +1077,8 @@ __global__ void __launch_bounds__(FM_THREADS, 1) fm_bwd_kernel(const FmPlan pl, 
           gs[i] = (16 * ob + 4 * g + i) < H ? rstd * (gh[ob][i] - m1 - sh[ob][i] * m2) : 0.f;
         gte[ob] += gs;
         acc[ob] = gs;                                   // skip connection
-        u[ob] = (pl.ablate & 4) ? gs * u[ob] : gs * gelu_grad4(u[ob]);     // g_u, in place
-        if (!(pl.ablate & 1)) st_tr(wtb, pl.g_u + l * HB + ob, c, g, u[ob]);
+        u[ob] = NSF_DBG_ABL(pl.ablate, 4) ? gs * u[ob] : gs * gelu_grad4(u[ob]);     // g_u, in place
+        if (!NSF_DBG_ABL(pl.ablate, 1)) st_tr(wtb, pl.g_u + l * HB + ob, c, g, u[ob]);
       }
       // refill for the next stage: layer l-1's (s_hat, u, rstd), or (ie, h0) after the first block; the u
       // blocks are refilled inside the GEMM as soon as it has consumed them
@@ -1181,7 +1181,7 @@ __device__ __forceinline__ void fm_dw_body(const FmPlan& pl, const float* __rest
   if (PF && wt0 < wt1) load_ops(wt0, av, bv);
   for (long long wt = wt0; wt < wt1; wt += 4) {
     if constexpr (PF) {
-      if (wt + 4 < wt1 && !(pl.ablate & 32)) load_ops(wt + 4, avn, bvn);
+      if (wt + 4 < wt1 && !NSF_DBG_ABL(pl.ablate, 32)) load_ops(wt + 4, avn, bvn);
     } else {
       load_ops(wt, av, bv);
     }
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ void fm_dw_body(const FmPlan& pl, const float* __rest
 #pragma unroll
       for (int kb = 0; kb < KBT; ++kb) bv[kb] = gelu4(bv[kb]);
     }
-    if (!(pl.ablate & 16)) {
+    if (!NSF_DBG_ABL(pl.ablate, 16)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll

@@ -240,7 +240,7 @@ extern "C" int sbi_amd_nsf_coop_selfcheck(const sbi_amd_nsf_config* cfg) {
     NsfPlan p4;
     TrainPlan tp;
     if (nsf_build_plan(cfg, TR_NW, &p4) != 0 || build_train_plan(p4, 65536, &tp) != 0) return 20;
-    if (!plan_is_static_default(p4, tp) && !(p4.ablate & 0x40000)) return 21;
+    if (!plan_is_static_default(p4, tp) && !NSF_DBG_ABL(p4.ablate, 0x40000)) return 21;
   }
   return 0;
 }

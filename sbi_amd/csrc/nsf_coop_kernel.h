@@ -380,8 +380,12 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
                     float* __restrict__ logp, float* __restrict__ noise_out, float* __restrict__ zst,
                     float* __restrict__ ast, long long* __restrict__ dbg) {
   // debug timeline (SBI_AMD_TIMELINE): cycle stamps of workgroup 0's waves while they walk transform 1
+#ifdef NSF_DEBUG
 #define TSC(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 1) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSC(i) do { } while (0)
+#endif
   constexpr int PT = (3 * K - 1 + 15) / 16;
   constexpr int R = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -755,8 +759,12 @@ nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
                     const float* __restrict__ ast, float* __restrict__ partial, float* __restrict__ grad_theta,
                     float* __restrict__ grad_x, long long* __restrict__ dbg) {
   // debug timeline (SBI_AMD_TIMELINE): cycle stamps of workgroup 0's waves while they walk transform T - 2
+#ifdef NSF_DEBUG
 #define TSB(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == k.T - 2) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSB(i) do { } while (0)
+#endif
   constexpr int PT = (3 * K - 1 + 15) / 16;
   constexpr int R = 16 * NT;
   constexpr int NZ = (R * 16 + 64 * CO_WAVES - 1) / (64 * CO_WAVES);   // state values per thread (theta-dim <= 16)
@@ -858,7 +866,7 @@ nsf_coop_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
     const int par = t & 1;
     const CoKP& kp = k.p[par];
     const float* img = cimg + (long long)t * k.img_floats;
-    float* part = (k.ablate & 32768) ? nullptr : partial + ((long long)t * gridDim.x + blockIdx.x) * k.PLP;
+    float* part = NSF_DBG_ABL(k.ablate, 32768) ? nullptr : partial + ((long long)t * gridDim.x + blockIdx.x) * k.PLP;
     const int tb_blk0 = 4 * kp.nnt0;                 // slab tile bases: d W0 | blocks | d Wf | LULinear tail
     const int tb_wf = tb_blk0 + NB * blk_tiles;
     TSB(0);

@@ -13,40 +13,27 @@ static int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 // backward kernel's persistent workgroups are faster)
 // (atomics: the setter is a process-wide tuning / test hook and may race with calls on other threads; every call reads
 //  the threshold ONCE, and a training pass whose two halves would disagree is refused: nsf_train.hip, ws_family_*)
-static std::atomic<int64_t> g_coop_max_rows{-1}, g_coop_train_rows{-1};
-int64_t coop_max_rows() {
-  int64_t v = g_coop_max_rows.load();
-  if (v < 0) {
-    const char* a = getenv("SBI_AMD_COOP_MAX_ROWS");
-    v = a ? atoll(a) : 12288;
-    int64_t expect = -1;
-    if (g_coop_max_rows.compare_exchange_strong(expect, v))
-      g_coop_train_rows.store(a ? v : 8192);      // (the environment variable and the setter move both)
-    else
-      v = expect;
-  }
-  return v;
-}
-int64_t coop_train_rows() {
-  coop_max_rows();
-  int64_t t;
-  while ((t = g_coop_train_rows.load()) < 0) {}     // (the initialising thread is between its two stores)
-  return t;
-}
-// tuning / test hook: route calls of <= `rows` rows to the cooperative kernels (0: never); returns the previous value
+static std::atomic<int64_t> g_coop_max_rows{12288}, g_coop_train_rows{8192};
+int64_t coop_max_rows() { return g_coop_max_rows.load(); }
+int64_t coop_train_rows() { return g_coop_train_rows.load(); }
+// tuning / test hook: route calls of <= `rows` rows to the cooperative kernels (0 or negative: never); returns the
+// previous log_prob / sampling threshold.  (No environment variable, no lazily initialised sentinel: both thresholds
+// are plain atomics with their measured defaults.)
 extern "C" int64_t sbi_amd_nsf_set_coop_max_rows(int64_t rows) {
-  const int64_t prev = coop_max_rows();
   const int64_t v = rows < 0 ? 0 : rows;
   g_coop_train_rows.store(v);
-  g_coop_max_rows.store(v);
-  return prev;
+  return g_coop_max_rows.exchange(v);
 }
 
-// debug aid: SBI_AMD_COOP_LEAN=0 keeps the forward pass of > 4096-row calls on the two-tile workgroups
+// SBI_AMD_COOP_LEAN=0 (-DNSF_DEBUG builds only) keeps the forward pass of > 4096-row calls on the two-tile workgroups
 bool coop_lean_forward() {
+#ifdef NSF_DEBUG
   static int lean_env = -1;
   if (lean_env < 0) { const char* a = getenv("SBI_AMD_COOP_LEAN"); lean_env = a ? atoi(a) : 1; }
   return lean_env != 0;
+#else
+  return true;
+#endif
 }
 
 static void add_mat(CoMat* m, int* off, int mtiles, int quads, int kind, int lin) {
@@ -135,9 +122,11 @@ int coop_build_plan(const NsfPlan& pl, int64_t n, int nt_force, bool training, C
 
   // rows per workgroup: one 16-row tile while that still gives every CU at most two workgroups' worth of partial
   // slabs; two tiles per workgroup beyond (the A operands are then shared by both, the slabs halve)
+#ifdef NSF_DEBUG
   static int nt_env = -1;   // debug aid: SBI_AMD_COOP_NT=1|2 forces the workgroup shape
   if (nt_env < 0) { const char* a = getenv("SBI_AMD_COOP_NT"); nt_env = a ? atoi(a) : 0; }
   if (nt_force <= 0) nt_force = nt_env;
+#endif
   int NT = nt_force > 0 ? nt_force : (n > 4096 ? 2 : 1);
   if (NT > CO_MAX_NT) NT = CO_MAX_NT;
   cp->MT = wide ? 2 : 1;

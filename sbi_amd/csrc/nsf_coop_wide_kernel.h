@@ -424,7 +424,7 @@ nsf_coopw_bwd_kernel(const CoK k, const float* __restrict__ cimg, const float* _
     const int par = t & 1;
     const CoKP& kp = k.p[par];
     const float* img = cimg + (long long)t * k.img_floats;
-    float* part = (k.ablate & 32768) ? nullptr : partial + ((long long)t * gridDim.x + blockIdx.x) * k.PLP;
+    float* part = NSF_DBG_ABL(k.ablate, 32768) ? nullptr : partial + ((long long)t * gridDim.x + blockIdx.x) * k.PLP;
     const float* at[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) at[u] = abase[u] + t * astride;

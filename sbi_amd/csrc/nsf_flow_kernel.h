@@ -43,7 +43,7 @@ static bool flow_plan_is_static(const NsfPlan& pl, const NsfPlan& st) {
   a.one_minus_kw = a.one_minus_kh = a.d_const = a.log_z = 0.f;
   a.ablate = 0;
   const NsfPlan b = st;
-  return memcmp(&a, &b, sizeof(NsfPlan)) == 0 && (pl.ablate & 0x40000) == 0;   // bit 0x40000: force the dynamic plan
+  return memcmp(&a, &b, sizeof(NsfPlan)) == 0 && NSF_DBG_ABL(pl.ablate, 0x40000) == 0;   // bit 0x40000: force the dynamic plan
 }
 
 // Only the sampling direction ever launches 12-wave workgroups (nsf_plan_for_rows(..., wide)); the density direction
@@ -57,8 +57,12 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
                 float* __restrict__ out_main, float* __restrict__ out_aux, float* __restrict__ z_stash,
                 float* __restrict__ astash, float* __restrict__ pstash, long long* __restrict__ dbg) {
+#ifdef NSF_DEBUG
 #define TSF(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && li == 1) \
     dbg[(threadIdx.x >> 6) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSF(i) do { } while (0)
+#endif
   constexpr int PT = (3 * K - 1 + 15) / 16;
   const NsfPlan& pl = SP == 8 ? kStaticFlow8 : (SP == 12 ? kStaticFlow12 : pl_);   // LAYOUT only; floats / debug: pl_
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -100,7 +104,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
   float* cstd = bxt + 64 * (1 + pl.NB);
   float ld_acc = 0.f;   // per-lane partial of the row's log|det|; reduced over g at the end
   float cr[4] = {0.f, 0.f, 0.f, 0.f};   // standardized context of this lane (C <= 16)
-  if (pl_.ablate & 256) {   // test aid (SBI_AMD_ABLATE=256): start from NaN-filled LDS, so that any read of a
+  if NSF_DBG_ABL(pl_.ablate, 256) {   // test aid (SBI_AMD_ABLATE=256): start from NaN-filled LDS, so that any read of a
     // location the kernel did not write itself shows up in the results
     const int total = pl.lds_w_floats + nw * pl.sc_total;
     for (int i = tid; i < total; i += nthreads) lds[i] = __builtin_nanf("");
@@ -149,7 +153,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
         stage_layer(lds + 4 * NPRE * nthreads, packed + (long long)t * pl.img_floats + 4 * NPRE * nthreads,
                     pl.img_floats - 4 * NPRE * nthreads, tid, nthreads);
     }
-    else if (!(pl_.ablate & 16) || li == 0)
+    else if (!NSF_DBG_ABL(pl_.ablate, 16) || li == 0)
       stage_layer(lds, packed + (long long)t * pl.img_floats, pl.img_floats, tid, nthreads);
     if (BX) bx_fold_context(packed + (long long)t * pl.img_floats, pl, S, cstd, bxt, tid, nthreads);
     TSF(2);
@@ -160,7 +164,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       for (int d = id.g; d < D; d += 4)
         if (valid) z_stash[((long long)t * n + row) * D + d] = zs[id.j * pl.ZW + d];
     }
-    if (INV && has_lu && !(pl_.ablate & 8)) {
+    if (INV && has_lu && !NSF_DBG_ABL(pl_.ablate, 8)) {
       lu_inverse(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc -= lu_logabsdet(lds, pl, S);
     }
@@ -185,7 +189,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
       const long long tile16 = (long long)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(wave);
       if (tile16 < nt16) pstw = pstash + ((long long)t * nt16 + tile16) * nsf_pst_tile_floats(pl) + 4 * id.lane;
     }
-    if (!(pl_.ablate & 4)) conditioner_hidden<KSH, BX>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast, bxt);
+    if (!NSF_DBG_ABL(pl_.ablate, 4)) conditioner_hidden<KSH, BX>(lds, pl, S, id, cin + id.j * pl.CINW + id.g, h, ast, bxt);
     else { for (int mt = 0; mt < NSF_HT; ++mt) for (int r = 0; r < 4; ++r) h[mt][r] = zs[id.j * pl.ZW + (mt + r) % D]; }
 
     TSF(5);
@@ -196,7 +200,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
     {
       const int nchunks = (S.d_tr + pl.DCH - 1) / pl.DCH;
       const int dch_ = pl.DCH, dtr_ = S.d_tr;
-      const bool spl_on = !(pl_.ablate & 1);
+      const bool spl_on = !NSF_DBG_ABL(pl_.ablate, 1);
       // integer offsets (not a pointer array): keeps the accesses in the LDS address space
       auto spline_chunk = [&](int c, auto&& yield) {
         // lane pair (lane, lane^32) = one (row, dim) task; dim slot = bit 4 of the lane id.
@@ -262,7 +266,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
     TSF(20);
     if (!INV && pref_on && li + 1 < pl.T)      // the NEXT transform's image: in flight under LULinear and the wait at the barrier
       stage_issue<NPRE>(packed + (long long)(t + 1) * pl.img_floats, pl.img_floats, tid, nthreads, pre);
-    if (!INV && has_lu && !(pl_.ablate & 8)) {
+    if (!INV && has_lu && !NSF_DBG_ABL(pl_.ablate, 8)) {
       lu_forward(lds, pl, S, id, zs, us);
       if (id.g == 0) ld_acc += lu_logabsdet(lds, pl, S);
     }
@@ -313,7 +317,7 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
 // the whole launch, nothing is stashed for a backward pass, the conditioner is the residual net, and it fits
 static inline int64_t nsf_bx_extra_bytes(const NsfPlan& pl) { return 4ll * (64 * (1 + pl.NB) + ((pl.C + 3) & ~3)); }
 static inline bool nsf_bx_applies(const NsfPlan& pl, int nw, int64_t x_rows, const float* z_stash, const float* astash) {
-  return x_rows == 1 && !z_stash && !astash && !pl.ctx_mlp && !(pl.ablate & 0x80000) &&
+  return x_rows == 1 && !z_stash && !astash && !pl.ctx_mlp && !NSF_DBG_ABL(pl.ablate, 0x80000) &&
          nsf_lds_bytes(pl, nw) + nsf_bx_extra_bytes(pl) <= NSF_LDS_LIMIT_BYTES;
 }
 

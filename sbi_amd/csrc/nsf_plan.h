@@ -20,6 +20,7 @@
 #define NSF_MAX_DCH 2     // spline dims per chunk: one (row, dim) task per lane pair (lane, lane^32)
 #define NSF_LDS_LIMIT_BYTES (160 * 1024)
 
+#include "debug_env.h"   // NSF_DBG_ABL and the (debug-build-only) environment switches
 struct LinDesc {
   int g_w, g_b;   // float offsets relative to the layer's block in the flat buffer
   int l_w, l_b;   // float offsets inside the LDS weight image
@@ -64,7 +65,7 @@ struct NsfPlan {
   // per-wave scratch (float offsets relative to the wave's scratch base)
   int ZW, CW, CINW, PSW, DS, DCH;
   int sc_zs, sc_us, sc_cs, sc_cin, sc_pst, sc_pst2, sc_total;
-  int ablate;                   // debug/timing only (env SBI_AMD_ABLATE): skip phases, results invalid
+  int ablate;                   // -DNSF_DEBUG builds only (env SBI_AMD_ABLATE): skip phases, results invalid; else 0
 };
 
 // Builds the plan for nw waves per workgroup; returns 0 or SBI_AMD_E_*.

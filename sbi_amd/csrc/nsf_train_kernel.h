@@ -135,7 +135,7 @@ static int build_train_plan(const NsfPlan& pl, int64_t n, TrainPlan* tp) {
   if (rc) return rc;
   tp->ntiles = (int)((n + TR_ROWS - 1) / TR_ROWS);
   tp->grid = tp->ntiles < TR_GRID_MAX ? tp->ntiles : TR_GRID_MAX;
-  if ((pl.ablate & 512) && tp->grid > 4) tp->grid = 4;   // debug aid: many tiles per persistent workgroup at small n
+  if (NSF_DBG_ABL(pl.ablate, 512) && tp->grid > 4) tp->grid = 4;   // debug aid: many tiles per persistent workgroup at small n
   return 0;
 }
 
@@ -172,7 +172,7 @@ static bool plan_is_static_default(const NsfPlan& pl, const TrainPlan& tp) {
   c.grid = c.ntiles = 0;
   c.grad_x = nullptr;
   const TrainPlan d = kStaticTp;
-  return memcmp(&c, &d, sizeof(TrainPlan)) == 0 && (pl.ablate & 0x40000) == 0;   // bit 0x40000: force the dynamic plan
+  return memcmp(&c, &d, sizeof(TrainPlan)) == 0 && NSF_DBG_ABL(pl.ablate, 0x40000) == 0;   // bit 0x40000: force the dynamic plan
 }
 
 // ------------------------------------------------------------------ device helpers

@@ -173,19 +173,33 @@ extern "C" int64_t sbi_amd_nsf_step_map_workspace_floats(const sbi_amd_nsf_confi
 #include <unordered_map>
 static std::mutex g_map_mu;
 static std::unordered_map<const void*, sbi_amd_nsf_config> g_maps;
+// (entries are never evicted behind a live table's back: the owner releases its table with
+//  sbi_amd_nsf_release_step_map when it drops the buffer -- 48 bytes per entry otherwise stay until process exit)
 static void st_register(const void* map, const sbi_amd_nsf_config* cfg) {
   std::lock_guard<std::mutex> lk(g_map_mu);
-  if (g_maps.size() > 1024) g_maps.clear();
   g_maps[map] = *cfg;
 }
 static void st_unregister(const void* map) {
   std::lock_guard<std::mutex> lk(g_map_mu);
   g_maps.erase(map);
 }
+// field by field (a C caller's struct padding is not part of the configuration)
+static bool st_same_cfg(const sbi_amd_nsf_config& a, const sbi_amd_nsf_config& b) {
+  return a.D == b.D && a.C == b.C && a.H == b.H && a.K == b.K && a.T == b.T && a.NB == b.NB &&
+         a.tail_bound == b.tail_bound && a.min_bin_width == b.min_bin_width && a.min_bin_height == b.min_bin_height &&
+         a.min_derivative == b.min_derivative && a.lu_eps == b.lu_eps && a.ctx_layers == b.ctx_layers;
+}
 static bool st_registered_for(const void* map, const sbi_amd_nsf_config* cfg) {
   std::lock_guard<std::mutex> lk(g_map_mu);
   auto it = g_maps.find(map);
-  return it != g_maps.end() && memcmp(&it->second, cfg, sizeof(*cfg)) == 0;
+  return it != g_maps.end() && st_same_cfg(it->second, *cfg);
+}
+// The owner of a table is about to free (or rebuild) its buffer: sbi_amd_nsf_table_pack refuses the address from now
+// on, so a later allocation that happens to reuse it cannot pass for a built table.
+extern "C" int sbi_amd_nsf_release_step_map(const int32_t* map) {
+  if (!map) return SBI_AMD_E_BADARG;
+  st_unregister(map);
+  return 0;
 }
 
 extern "C" int sbi_amd_nsf_build_step_map(const sbi_amd_nsf_config* cfg, int32_t images, const float* params,

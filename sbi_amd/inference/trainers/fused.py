@@ -221,7 +221,7 @@ class FusedTrainStep:
         maps = self.__dict__.setdefault("_step_maps", {})
         key = (mask, packed.data_ptr(), self.net.flat_params.data_ptr())
         for stale in [k for k in maps if k[1:] != key[1:]]:      # a moved / re-allocated buffer drops its tables
-            del maps[stale]
+            self._drop_step_map(maps.pop(stale))
         ent = maps.get(key)                                       # (at most one table per image: batch sizes on both
         if ent is None:                                           #  sides of the kernel families' threshold keep two)
             dev = packed.device
@@ -245,11 +245,20 @@ class FusedTrainStep:
                 else:
                     _lib.check(rc, "nsf_build_step_map")
                     ent = mp
+                    # the library keeps a registry of built tables by address: release the entry when the tensor goes
+                    import weakref
+
+                    weakref.finalize(mp, lib.sbi_amd_nsf_release_step_map, mp.data_ptr())
                 del ws
             maps[key] = ent
         if ent is False:
             return None
         return mask, packed, ent
+
+    @staticmethod
+    def _drop_step_map(ent) -> None:
+        if isinstance(ent, torch.Tensor):
+            _lib.load().sbi_amd_nsf_release_step_map(ent.data_ptr())
 
     def grad_modified(self) -> None:
         """Tell the stepper that `self.grad` is no longer what the last training pass wrote (the caller scaled it,
@@ -322,6 +331,16 @@ class FusedTrainStep:
             with torch.cuda.device(dev):
                 rc = lib.sbi_amd_nsf_table_pack(self.net.hyper.c_config(), _lib.ptr(p.data), _lib.ptr(packed),
                                                 _lib.ptr(mp), _lib.current_stream(dev))
+            if rc == _lib.E_BADARG:
+                # the library no longer knows this table (released, or built for another configuration): the optimizer
+                # step has already happened, so do not raise here -- forget the table (it is rebuilt on the next step)
+                # and let packed_weights re-pack from the new parameters with the full pack kernels
+                for k in [k for k, v in self.__dict__.get("_step_maps", {}).items() if v is mp]:
+                    self._drop_step_map(self._step_maps.pop(k))
+                cache = self.net.__dict__.get("_packed_cache")
+                if cache is not None:
+                    self.net.__dict__["_packed_cache"] = (None, cache[1])
+                return
             _lib.check(rc, "nsf_table_pack")
             # the image named by `mask` holds the new parameters; every other image (and the explicit LU inverses) is
             # stale: packed_weights re-packs those on demand

@@ -30,7 +30,39 @@ def test_table_pack_refuses_tables_it_did_not_build():
     # built for another configuration: refused
     assert lib.sbi_amd_nsf_table_pack(cfg_other, _lib.ptr(other.net.flat_params.data), _lib.ptr(packed), _lib.ptr(table),
                                       stream) == _lib.E_BADARG
+    # released (the owner is about to free the buffer): refused again, and building 2 000 other tables in between
+    # never evicts a live one (the registry used to clear itself at 1 024 entries)
+    assert lib.sbi_amd_nsf_release_step_map(_lib.ptr(table)) == 0
+    assert lib.sbi_amd_nsf_table_pack(cfg, _lib.ptr(flat), _lib.ptr(packed), _lib.ptr(table), stream) == _lib.E_BADARG
+    assert lib.sbi_amd_nsf_build_step_map(cfg, 1, _lib.ptr(flat), _lib.ptr(packed), _lib.ptr(table), _lib.ptr(scratch),
+                                          stream) == 0
     torch.cuda.synchronize()
+
+
+def test_fused_step_survives_a_released_table():
+    """A table the library no longer knows must not raise AFTER the optimizer step: the stepper falls back to the full
+    pack and rebuilds the table."""
+    from sbi_amd.inference.trainers.fused import FusedTrainStep
+
+    lib = _lib.load()
+    _, est, theta, x = matched_pair(D=10, C=10)
+    th, xx = theta[:512].cuda().contiguous(), x[:512].cuda().contiguous()
+    st, ref = FusedTrainStep(est, distributed=False), None
+    st.step(th, xx)
+    st.step(th, xx)
+    maps = [v for v in st.__dict__.get("_step_maps", {}).values() if isinstance(v, torch.Tensor)]
+    assert maps, "the stepper did not build a re-pack table"
+    for mp in maps:
+        lib.sbi_amd_nsf_release_step_map(mp.data_ptr())
+    st.step(th, xx)                     # table refused -> full re-pack on demand, no exception
+    losses = st.step(th, xx)            # table rebuilt
+    # the same four steps on a twin that never lost its table: identical parameters
+    _, twin, _, _ = matched_pair(D=10, C=10)
+    st2 = FusedTrainStep(twin, distributed=False)
+    for _ in range(4):
+        losses2 = st2.step(th, xx)
+    torch.cuda.synchronize()
+    assert torch.equal(est.net.flat_params.data, twin.net.flat_params.data) and torch.equal(losses, losses2)
 
 
 def test_backward_refuses_a_stash_of_the_other_kernel_family():
