@@ -19,12 +19,24 @@ from torch import Tensor
 
 from sbi_amd.neural_nets.estimators.shape_handling import reshape_to_batch_event
 from sbi_amd.samplers.mcmc import SliceSamplerVectorized, proposal_init, resample_given_potential_fn, sir_init
-from sbi_amd.utils.potentialutils import transformed_potential
 from sbi_amd.utils.sbiutils import mcmc_transform
 from sbi_amd.utils.torchutils import ensure_theta_batched, process_device
 
 _SLICE_METHODS = ("slice_np", "slice_np_vectorized")
 _OTHER_METHODS = ("hmc_pyro", "nuts_pyro", "slice_pymc", "hmc_pymc", "nuts_pymc")
+
+
+def unconstrained_potential(potential_fn, transform, device):
+    """The slice sampler walks UNCONSTRAINED space: returns u -> potential of the constrained point T^-1(u), corrected
+    by the volume change of the map (what mcmc_posterior.py:953-986 gets from utils/potentialutils.py:15-51)."""
+
+    def density_of(u) -> Tensor:
+        u = ensure_theta_batched(torch.as_tensor(u, dtype=torch.float32)).to(device)
+        constrained = transform.inv(u)
+        volume = transform.log_abs_det_jacobian(constrained, u).to(device)
+        return potential_fn(constrained, track_gradients=False).to(device) - volume
+
+    return density_of
 
 
 def _process_thin_default(thin: int) -> int:
@@ -139,9 +151,7 @@ class MCMCPosterior:
         if method not in _SLICE_METHODS:
             raise NameError(f"The sampling method {method} is not implemented!")
 
-        def potential_(theta_unconstrained: Tensor) -> Tensor:       # mcmc_posterior.py:953-986
-            return transformed_potential(theta_unconstrained, self.potential_fn, self.theta_transform, self._device,
-                                         track_gradients=False)
+        potential_ = unconstrained_potential(self.potential_fn, self.theta_transform, self._device)
 
         fused = self._fused_potential()
         if fused is not None:

@@ -253,10 +253,10 @@ class PosteriorEstimatorTrainer:
     def _bcast(self, t: Tensor) -> Tensor:
         d = self._dist()
         if d is not None:
-            from sbi_amd.utils.collectives import _direct
+            from sbi_amd.utils.collectives import device_capable
 
             buf = t.to(self._device)
-            backend_dev = self._device if (buf.device.type == "cuda" and _direct(d, buf)) else "cpu"
+            backend_dev = self._device if (buf.device.type == "cuda" and device_capable(d)) else "cpu"
             buf = t.to(backend_dev)
             d.broadcast(buf, src=0)
             t = buf.to(t.device)
@@ -459,6 +459,8 @@ class PosteriorEstimatorTrainer:
                 torch.sum(parts[0] if len(parts) == 1 else torch.cat(parts), dim=0, keepdim=True, out=out[i : i + 1])
             return out
 
+        # (`val_fixed` is a second device copy of the validation split -- n_val (D + C) floats, 800 KB at 10 000 rows --
+        #  alive for the duration of this train() call: it saves one gather launch per validation batch and epoch)
         val_fixed = None
         if fused and n_val_batches * Bv == n_val and world == 1 and not atomic:      # (fused: no calibration kernel)
             val_fixed = (theta_d.index_select(0, val_idx), x_d.index_select(0, val_idx))
@@ -478,7 +480,9 @@ class PosteriorEstimatorTrainer:
             try:
                 lib_ = _lib_mod.load()
                 cfg_ = net.net.hyper.c_config()
-                k_tr, k_va = lib_.sbi_amd_nsf_image_kind(cfg_, int(B), 1), lib_.sbi_amd_nsf_image_kind(cfg_, int(Bv), 0)
+                # (the kernel family is chosen by the rows ONE rank passes to a call: its share of the global batch)
+                rows_tr, rows_va = max(my_range(0, B)[1], 1), max(my_range(0, Bv)[1], 1)
+                k_tr, k_va = lib_.sbi_amd_nsf_image_kind(cfg_, int(rows_tr), 1), lib_.sbi_amd_nsf_image_kind(cfg_, int(rows_va), 0)
                 self._stepper.tail_extra_images = (2 if k_va == 1 else 1) if (k_tr >= 0 and k_va >= 0 and k_tr != k_va) else 0
             except (AttributeError, RuntimeError):
                 self._stepper.tail_extra_images = 0

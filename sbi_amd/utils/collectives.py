@@ -18,6 +18,17 @@ from torch import Tensor
 _warned_staged = False
 
 
+def device_capable(dist, group=None) -> bool:
+    """Does the group's backend take ROCm device tensors?  Parsed from the backend string: a per-device map
+    ("cpu:gloo,cuda:nccl") is judged by its `cuda` entry -- a missing or gloo `cuda` entry means staging -- a single name
+    applies to every device ("nccl": yes, "gloo": no); anything unknown is trusted with the tensor as it is."""
+    backend = str(dist.get_backend(group)).lower()
+    if ":" in backend:
+        entries = dict(e.split(":", 1) for e in backend.split(",") if ":" in e)
+        return "cuda" in entries and entries["cuda"] != "gloo"
+    return backend != "gloo"
+
+
 def _direct(dist, t: Tensor, group=None) -> bool:
     """True when the group's backend reduces / broadcasts `t` where it lives.  Decided by capability: a device tensor
     is staged through the host only for a backend known to lack device support (pure `gloo`); `nccl`, the composite
@@ -26,8 +37,7 @@ def _direct(dist, t: Tensor, group=None) -> bool:
     global _warned_staged
     if t.device.type == "cpu":
         return True
-    backend = str(dist.get_backend(group)).lower()
-    if "nccl" in backend or backend not in ("gloo", "cpu:gloo"):
+    if device_capable(dist, group):
         return True
     if not _warned_staged:
         import warnings

@@ -75,8 +75,9 @@ def standardizing_stats(batch_t: Tensor, structured_dims: bool = False, min_std:
     if len(batch_t) > 1:
         t_mean, t_std = _location_scale(batch_t[keep], structured_dims, min_std)
     else:
-        t_mean = _location_scale(batch_t[keep], structured_dims, min_std)[0]
-        t_std = torch.ones(1)
+        kept = batch_t[keep]
+        t_mean = kept.mean() if structured_dims else kept.mean(dim=0)      # (no std of a single row: torch warns, and
+        t_std = torch.ones(1)                                              #  the reference substitutes 1 anyway)
         logging.warning("Using a one-dimensional batch will instantiate a Standardize transform with (mean, std) "
                         "parameters which are not representative of the data.")
     if bool(torch.isnan(t_mean).any() | torch.isnan(t_std).any()):

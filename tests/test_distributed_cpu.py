@@ -138,3 +138,7 @@ def test_collectives_choose_the_staged_path_by_capability_not_by_name():
     import torch
 
     assert collectives._direct(FakeDist("gloo"), torch.zeros(1))      # host tensors never need staging
+    # a per-device map is judged by its cuda entry: gloo or nothing for cuda means staging
+    for backend in ("cpu:gloo,cuda:gloo", "cpu:gloo"):
+        assert not collectives.device_capable(FakeDist(backend)), backend
+    assert collectives.device_capable(FakeDist("cpu:gloo,cuda:nccl"))

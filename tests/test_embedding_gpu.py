@@ -179,7 +179,7 @@ def test_mcmc_fused_potential_embeds_the_observation():
     """MCMCPosterior's fused potential must evaluate the flow on the EMBEDDED x_o."""
     from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
     from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
-    from sbi_amd.utils.potentialutils import transformed_potential
+    from sbi_amd.inference.posteriors.mcmc_posterior import unconstrained_potential
     from sbi_amd.utils.sbiutils import mcmc_transform
 
     est, theta, x = _frozen_embedding_estimator()
@@ -195,7 +195,7 @@ def test_mcmc_fused_potential_embeds_the_observation():
     assert fused is not None
     u = torch.randn(64, 3, device="cuda")
     logp, lad = fused(u)
-    ref = transformed_potential(u, post.potential_fn, tf, "cuda", track_gradients=False)
+    ref = unconstrained_potential(post.potential_fn, tf, "cuda")(u)
     assert (logp - lad - ref).abs().max() <= 1e-4
     s = post.sample((40,), show_progress_bars=False)
     assert s.shape == (40, 3) and torch.isfinite(s).all()

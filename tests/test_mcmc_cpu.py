@@ -7,7 +7,7 @@ from torch.distributions import MultivariateNormal
 
 from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
 from sbi_amd.samplers.mcmc import SliceSamplerVectorized, proposal_init, resample_given_potential_fn, sir_init
-from sbi_amd.utils.potentialutils import transformed_potential
+from sbi_amd.inference.posteriors.mcmc_posterior import unconstrained_potential
 from sbi_amd.utils.sbiutils import mcmc_transform
 from sbi_amd.utils.torchutils import BoxUniform
 
@@ -38,7 +38,7 @@ def test_transformed_potential_subtracts_log_abs_det():
 
     th = box.sample((20,))
     u = tf(th)
-    got = transformed_potential(u, potential, tf, "cpu")
+    got = unconstrained_potential(potential, tf, "cpu")(u)
     want = potential(th) - tf.log_abs_det_jacobian(th, u)
     assert torch.allclose(got, want, atol=1e-6)
 
