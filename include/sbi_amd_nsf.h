@@ -242,6 +242,24 @@ int sbi_amd_nsf_table_pack(const sbi_amd_nsf_config* cfg, const float* params, f
  * or reusing the map buffer, tell the library: a later allocation at the same address must not pass for a table. */
 int sbi_amd_nsf_release_step_map(const int32_t* map);
 
+/* Stable stream compaction of accepted proposal draws: the body of accept_reject_sample's loop
+ * (sbi/samplers/rejection/rejection.py:368-409 -- `candidates[are_accepted]` per condition, appended in order, plus the
+ * running counts of the batch-size rule) as ONE launch (csrc/compact.hip: acceptance test, single-pass scan with
+ * decoupled look-back, order-preserving scatter).
+ *   candidates (batch_rows, num_xos, event_floats) fp32; acceptance from `accepted` (batch_rows, num_xos) bytes, or --
+ *   accepted == NULL -- from the box lo <= theta <= hi (box_low / box_high: event_floats floats each; what torch's
+ *   interval support check of a BoxUniform prior evaluates; NaN fails);
+ *   out (num_samples, num_xos, event_floats): row r of condition x lands at state[x] + #accepted rows before r, rows
+ *   past num_samples are dropped;  state int64[3 num_xos]: [0, X) rows filled (in/out, clamped to num_samples),
+ *   [X, 2X) accepted so far (in/out), [2X, 3X) accepted by this call (out) -- the one read-back of an iteration;
+ *   control int32[2 num_xos], zero before the first call (left zero by every call);  scan uint64[
+ *   sbi_amd_accept_compact_scan_words(batch_rows, num_xos)], zero-initialised once;  generation != 0, different from
+ *   the previous call's on the same scan buffer (a counter).  batch_rows < 2^31. */
+int64_t sbi_amd_accept_compact_scan_words(int64_t batch_rows, int32_t num_xos);
+int sbi_amd_accept_compact(const float* candidates, const uint8_t* accepted, const float* box_low, const float* box_high,
+                           int64_t batch_rows, int32_t num_xos, int32_t event_floats, float* out, int64_t num_samples,
+                           int64_t* state, int32_t* control, uint64_t* scan, uint32_t generation, void* stream);
+
 /* One tick of the vectorised slice sampler for all chains (the loop body of SliceSamplerVectorized.run,
  * sbi/samplers/mcmc/slice_numpy.py:353-587): consumes the log-probabilities of `next_param` (what the batched
  * log_prob kernel just produced), advances every chain's BEGIN/LOWER/UPPER/SAMPLE_SLICE state, writes the next

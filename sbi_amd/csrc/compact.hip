@@ -1,0 +1,142 @@
+// compact.hip -- stable stream compaction of accepted proposal draws: the loop body of accept_reject_sample
+// (sbi/samplers/rejection/rejection.py:368-409: `candidates[are_accepted]` appended per condition, running counts for
+// the batch-size rule) as ONE launch and one small read-back per iteration.
+//   * acceptance: either a caller-provided mask (any prior: torch evaluates `within_support`) or, for a box prior,
+//     lo <= theta <= hi evaluated here on the candidates as they are read (NaN fails, as torch's interval check does);
+//   * order-preserving: row r of condition x goes to out[filled[x] + #accepted rows before r]  (single-pass scan with
+//     decoupled look-back: one 8-byte {generation, flag, count} word per tile, agent-scope relaxed accesses -- the word
+//     is its own flag, nothing else is published between workgroups);
+//   * rows past num_samples are dropped; the last workgroup to finish folds the totals into `state`.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sbi_amd_nsf.h"
+
+#define CP_THREADS 256
+#define CP_RPT 4                          // consecutive rows per thread (keeps the order: thread-major)
+#define CP_TILE (CP_THREADS * CP_RPT)
+
+__device__ __forceinline__ unsigned long long cp_word(unsigned gen, unsigned flag, unsigned val) {
+  return ((unsigned long long)(gen & 0x3fffffffu) << 34) | ((unsigned long long)flag << 32) | val;
+}
+
+// state (int64, per condition x): [0, X) filled, [X, 2X) total accepted so far, [2X, 3X) accepted by this call
+// ctl (int32, per condition): [0, X) tile tickets, [X, 2X) finished tiles -- both left at 0 by the last workgroup
+__global__ void __launch_bounds__(CP_THREADS)
+accept_compact_kernel(const float* __restrict__ cand, const unsigned char* __restrict__ mask,
+                      const float* __restrict__ lo, const float* __restrict__ hi, long long bs, int num_xos, int ev,
+                      float* __restrict__ out, long long num_samples, long long* __restrict__ state,
+                      int* __restrict__ ctl, unsigned long long* __restrict__ scan, int ntiles, unsigned gen) {
+  const int xo = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_tile;
+  __shared__ int s_wave[CP_THREADS / 64];
+  __shared__ long long s_excl;
+  if (tid == 0) s_tile = __hip_atomic_fetch_add(&ctl[xo], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int tile = s_tile;                 // tiles are taken in dispatch order: a predecessor is always running or done
+  const long long row0 = (long long)tile * CP_TILE + (long long)tid * CP_RPT;
+  // ---- acceptance of this thread's rows
+  bool acc[CP_RPT];
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < CP_RPT; ++u) {
+    const long long r = row0 + u;
+    bool a = false;
+    if (r < bs) {
+      if (mask) {
+        a = mask[r * num_xos + xo] != 0;
+      } else {
+        const float* c = cand + (r * num_xos + xo) * ev;
+        a = true;
+        for (int d = 0; d < ev; ++d) a = a && (c[d] >= lo[d]) && (c[d] <= hi[d]);
+      }
+    }
+    acc[u] = a;
+    cnt += a ? 1 : 0;
+  }
+  // ---- exclusive scan of the per-thread counts inside the tile
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int wave_base = 0, tile_total = 0;
+#pragma unroll
+  for (int w = 0; w < CP_THREADS / 64; ++w) {
+    if (w < wave) wave_base += s_wave[w];
+    tile_total += s_wave[w];
+  }
+  const int thread_excl = wave_base + incl - cnt;
+  // ---- decoupled look-back over the tiles of this condition
+  unsigned long long* st = scan + (long long)xo * ntiles;
+  if (tid == 0) {
+    long long excl = 0;
+    if (tile > 0) {
+      __hip_atomic_store(&st[tile], cp_word(gen, 1, (unsigned)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = tile - 1; i >= 0; --i) {
+        unsigned long long w;
+        do {
+          w = __hip_atomic_load(&st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((w >> 34) == (gen & 0x3fffffffu) && ((w >> 32) & 3u) != 0) break;
+          __builtin_amdgcn_s_sleep(1);
+        } while (true);
+        excl += (long long)(w & 0xffffffffu);
+        if (((w >> 32) & 3u) == 2) break;          // an inclusive prefix: everything before it is in
+      }
+    }
+    __hip_atomic_store(&st[tile], cp_word(gen, 2, (unsigned)(excl + tile_total)), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    s_excl = excl;
+  }
+  __syncthreads();
+  // ---- scatter (stable), dropping rows past the request
+  long long dest = state[xo] + s_excl + thread_excl;
+#pragma unroll
+  for (int u = 0; u < CP_RPT; ++u) {
+    if (acc[u]) {
+      if (dest < num_samples) {
+        const float* c = cand + ((row0 + u) * num_xos + xo) * ev;
+        float* o = out + (dest * num_xos + xo) * ev;
+        for (int d = 0; d < ev; ++d) o[d] = c[d];
+      }
+      ++dest;
+    }
+  }
+  // ---- the last workgroup of this condition folds the totals in (everybody has read state[xo] by then)
+  __syncthreads();
+  if (tid == 0) {
+    const int done = __hip_atomic_fetch_add(&ctl[num_xos + xo], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == ntiles - 1) {
+      const unsigned long long w = __hip_atomic_load(&st[ntiles - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long total = (long long)(w & 0xffffffffu);
+      const long long f = state[xo] + total;
+      state[2 * num_xos + xo] = total;
+      state[num_xos + xo] += total;
+      state[xo] = f < num_samples ? f : num_samples;
+      ctl[xo] = 0;
+      ctl[num_xos + xo] = 0;
+    }
+  }
+}
+
+extern "C" int64_t sbi_amd_accept_compact_scan_words(int64_t batch_rows, int32_t num_xos) {
+  if (batch_rows < 0 || num_xos < 1) return SBI_AMD_E_BADARG;
+  return ((batch_rows + CP_TILE - 1) / CP_TILE) * (int64_t)num_xos;
+}
+
+extern "C" int sbi_amd_accept_compact(const float* candidates, const uint8_t* accepted, const float* box_low,
+                                      const float* box_high, int64_t batch_rows, int32_t num_xos, int32_t event_floats,
+                                      float* out, int64_t num_samples, int64_t* state, int32_t* control,
+                                      uint64_t* scan, uint32_t generation, void* stream) {
+  if (!candidates || !out || !state || !control || !scan || num_xos < 1 || event_floats < 1 || batch_rows < 0 ||
+      num_samples < 0 || batch_rows >= (1ll << 31) || (!accepted && (!box_low || !box_high)) || generation == 0)
+    return SBI_AMD_E_BADARG;
+  if (batch_rows == 0) return 0;
+  const int ntiles = (int)((batch_rows + CP_TILE - 1) / CP_TILE);
+  hipLaunchKernelGGL(accept_compact_kernel, dim3(ntiles, num_xos), dim3(CP_THREADS), 0, (hipStream_t)stream, candidates,
+                     accepted, box_low, box_high, (long long)batch_rows, num_xos, event_floats, out,
+                     (long long)num_samples, (long long*)state, control, (unsigned long long*)scan, ntiles, generation);
+  return (int)hipGetLastError();
+}

@@ -8,10 +8,11 @@ from the running acceptance rate (:406-409), warns once below
 and returns ``(samples (num_samples, num_xos, *event), acceptance_rate (num_xos,))``.
 
 MI355X-first differences (results are the same set of samples in the same order):
-accepted candidates are compacted ON THE DEVICE into a preallocated output buffer
-with a stable prefix-sum scatter (no boolean-mask gathers, no per-condition Python
-loop, no list/cat), and the loop reads back ONE small tensor per iteration (the
-per-condition accept counts the batch-size rule needs) instead of 2+ syncs.
+on a ROCm device an iteration is the proposal's kernels plus ONE launch (csrc/compact.hip:
+acceptance test -- fused for a box prior, else a mask from `accept_reject_fn` -- single-pass
+scan, order-preserving scatter into a preallocated buffer) and ONE small read-back (the
+per-condition accept counts the batch-size rule needs).  Host tensors (the CPU golden replays)
+take the same steps as torch operations.
 """
 
 from __future__ import annotations
@@ -78,37 +79,60 @@ def accept_reject_sample(
             )
 
         candidates = proposal(torch.Size((sampling_batch_size,)), **proposal_sampling_kwargs)
-        are_accepted = accept_reject_fn(candidates).reshape(sampling_batch_size, num_xos)
         cand = candidates.reshape(sampling_batch_size, num_xos, *candidates.shape[candidates.ndim - 1 :])
-        acc_i = are_accepted.to(torch.long)
-        num_accepted = acc_i.sum(dim=0)
-        if num_samples_possible == 0 and sampling_batch_size == num_samples:
-            # First pass, sized for the whole request (what `DirectPosterior.sample` asks for): when EVERY candidate is
-            # accepted -- an unbounded prior, or a posterior well inside a box -- the candidates ARE the result, in the
-            # order the compaction would have left them, and the cumsum / scatter over all rows (a fifth of a
-            # 10^6-draw call) is skipped.  Costs the iteration's host read a little earlier.
-            if int(num_accepted.min()) == sampling_batch_size:
-                return cand.reshape(num_samples, *candidates.shape[1:]), torch.ones(num_xos, device=cand.device)
-        if out is None:
-            # one extra row: the dump slot rejected / surplus candidates are scattered to
-            buf = torch.empty((num_samples + 1, num_xos, *cand.shape[2:]), dtype=cand.dtype, device=cand.device)
-            out = buf[:num_samples]
-            flat = buf.view(-1, *cand.shape[2:])
-            filled = torch.zeros(num_xos, dtype=torch.long, device=cand.device)
-            total_accepted = torch.zeros(num_xos, dtype=torch.long, device=cand.device)
-            xo_idx = torch.arange(num_xos, device=cand.device).unsqueeze(0)
+        on_device = cand.is_cuda and cand.dtype == torch.float32 and cand.ndim == 3
+        box = getattr(accept_reject_fn, "box_bounds", None) if on_device else None
+        if box is not None and (box[0].numel() != cand.shape[-1] or box[0].device != cand.device):
+            box = None
+        if on_device:
+            # ---- one launch: acceptance + stable compaction + running counts (include/sbi_amd_nsf.h)
+            from sbi_amd import _lib
 
-        # stable compaction: destination row of every accepted candidate, per condition
-        dest = torch.cumsum(acc_i, dim=0) - 1 + filled.unsqueeze(0)              # (bs, num_xos)
-        keep = are_accepted & (dest < num_samples)
-        dest = torch.where(keep, dest, torch.full_like(dest, num_samples))      # overflow row
-        flat.index_copy_(0, (dest * num_xos + xo_idx).reshape(-1), cand.reshape(-1, *cand.shape[2:]))
-        filled = torch.clamp(filled + num_accepted, max=num_samples)
-        total_accepted += num_accepted
-        num_samples_possible += sampling_batch_size
-
-        # the ONE host read-back of the iteration
-        stats = torch.stack([num_accepted, total_accepted]).cpu()
+            lib = _lib.load()
+            if out is None:
+                ev = cand.shape[-1]
+                out = torch.empty((num_samples, num_xos, ev), dtype=cand.dtype, device=cand.device)
+                state = torch.zeros(3 * num_xos, dtype=torch.long, device=cand.device)
+                control = torch.zeros(2 * num_xos, dtype=torch.int32, device=cand.device)
+                words = lib.sbi_amd_accept_compact_scan_words(max(max_sampling_batch_size, sampling_batch_size), num_xos)
+                scan = torch.zeros(int(words), dtype=torch.long, device=cand.device)
+                generation = 0
+                filled = state[:num_xos]
+            mask = None
+            if box is None:
+                mask = accept_reject_fn(candidates).reshape(sampling_batch_size, num_xos).to(torch.bool).contiguous()
+            cand_c = cand.contiguous()
+            generation += 1
+            with torch.cuda.device(cand.device):
+                rc = lib.sbi_amd_accept_compact(
+                    _lib.ptr(cand_c), _lib.ptr(mask), None if box is None else _lib.ptr(box[0]),
+                    None if box is None else _lib.ptr(box[1]), sampling_batch_size, num_xos, cand.shape[-1], _lib.ptr(out),
+                    num_samples, _lib.ptr(state), _lib.ptr(control), _lib.ptr(scan), generation,
+                    _lib.current_stream(cand.device))
+            _lib.check(rc, "accept_compact")
+            num_samples_possible += sampling_batch_size
+            stats = state[num_xos:].cpu().reshape(2, num_xos)[[1, 0]]      # the ONE host read-back: [this call, so far]
+        else:
+            are_accepted = accept_reject_fn(candidates).reshape(sampling_batch_size, num_xos)
+            acc_i = are_accepted.to(torch.long)
+            num_accepted = acc_i.sum(dim=0)
+            if out is None:
+                # one extra row: the dump slot rejected / surplus candidates are scattered to
+                buf = torch.empty((num_samples + 1, num_xos, *cand.shape[2:]), dtype=cand.dtype, device=cand.device)
+                out = buf[:num_samples]
+                flat = buf.view(-1, *cand.shape[2:])
+                filled = torch.zeros(num_xos, dtype=torch.long, device=cand.device)
+                total_accepted = torch.zeros(num_xos, dtype=torch.long, device=cand.device)
+                xo_idx = torch.arange(num_xos, device=cand.device).unsqueeze(0)
+            # stable compaction: destination row of every accepted candidate, per condition
+            dest = torch.cumsum(acc_i, dim=0) - 1 + filled.unsqueeze(0)              # (bs, num_xos)
+            keep = are_accepted & (dest < num_samples)
+            dest = torch.where(keep, dest, torch.full_like(dest, num_samples))      # overflow row
+            flat.index_copy_(0, (dest * num_xos + xo_idx).reshape(-1), cand.reshape(-1, *cand.shape[2:]))
+            filled = torch.clamp(filled + num_accepted, max=num_samples)
+            total_accepted += num_accepted
+            num_samples_possible += sampling_batch_size
+            stats = torch.stack([num_accepted, total_accepted]).cpu()
         min_num_accepted = int(stats[0].min())
         num_remaining -= min_num_accepted
         acceptance_rate = stats[1].to(torch.float32) / num_samples_possible
