@@ -242,6 +242,22 @@ int sbi_amd_nsf_table_pack(const sbi_amd_nsf_config* cfg, const float* params, f
  * or reusing the map buffer, tell the library: a later allocation at the same address must not pass for a table. */
 int sbi_amd_nsf_release_step_map(const int32_t* map);
 
+/* Data-parallel exchange (SURVEY 8b `allreduce_flat`, 8e; the reference trains on one device and has none,
+ * sbi/inference/trainers/base.py:1150-1193): ONE in-place SUM all-reduce of the flat fp32 gradient buffer per step over
+ * RCCL (xGMI inside a node), enqueued on `stream` between the backward pass (sbi_amd_nsf_train_backward) and
+ * sbi_amd_adam_clip_step*: every rank then clips and steps identically (csrc/adam_math.h) and replicas stay bit-identical.
+ * librccl.so is resolved with dlopen on first use (SBI_AMD_E_UNSUPPORTED when it is absent); return codes >= 10000 are
+ * 10000 + ncclResult_t.  One communicator per process and device:
+ *   rank 0: sbi_amd_rccl_unique_id(id) -> ship the sbi_amd_rccl_unique_id_bytes() bytes to every rank (any channel) ->
+ *   every rank, with its device current: sbi_amd_rccl_comm_init(&comm, world, rank, id) -> per step
+ *   sbi_amd_allreduce_flat(comm, grad, count, stream) -> sbi_amd_rccl_comm_destroy(comm).
+ * Python's default remains torch.distributed's `nccl` backend (the same RCCL): sbi_amd/utils/collectives.py. */
+int32_t sbi_amd_rccl_unique_id_bytes(void);
+int sbi_amd_rccl_unique_id(void* id_out);
+int sbi_amd_rccl_comm_init(void** comm_out, int32_t world, int32_t rank, const void* id_bytes);
+int sbi_amd_rccl_comm_destroy(void* comm);
+int sbi_amd_allreduce_flat(void* comm, float* grad_bucket, int64_t count, void* stream);
+
 /* Stable stream compaction of accepted proposal draws: the body of accept_reject_sample's loop
  * (sbi/samplers/rejection/rejection.py:368-409 -- `candidates[are_accepted]` per condition, appended in order, plus the
  * running counts of the batch-size rule) as ONE launch (csrc/compact.hip: acceptance test, single-pass scan with

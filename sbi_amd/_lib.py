@@ -111,6 +111,11 @@ _SIGNATURES = {
         c_int, [POINTER(NSFConfigC), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sbi_amd_nsf_table_pack": (c_int, [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_void_p]),
     "sbi_amd_nsf_release_step_map": (c_int, [c_void_p]),
+    "sbi_amd_rccl_unique_id_bytes": (c_int32, []),
+    "sbi_amd_rccl_unique_id": (c_int, [c_void_p]),
+    "sbi_amd_rccl_comm_init": (c_int, [POINTER(c_void_p), c_int32, c_int32, c_void_p]),
+    "sbi_amd_rccl_comm_destroy": (c_int, [c_void_p]),
+    "sbi_amd_allreduce_flat": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sbi_amd_accept_compact_scan_words": (c_int64, [c_int64, c_int32]),
     "sbi_amd_accept_compact": (
         c_int,

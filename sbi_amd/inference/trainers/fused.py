@@ -26,7 +26,8 @@ from sbi_amd.utils.collectives import all_reduce_sum
 
 class FusedTrainStep:
     def __init__(self, estimator: NSFFlow, lr: float = 5e-4, clip_max_norm: Optional[float] = 5.0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, distributed: bool = False, process_group=None):
+                 betas=(0.9, 0.999), eps: float = 1e-8, distributed: bool = False, process_group=None,
+                 native_allreduce: bool = False):
         self.est = estimator
         self.net = estimator.net
         p = self.net.flat_params
@@ -48,6 +49,13 @@ class FusedTrainStep:
             self.world = dist.get_world_size(process_group)
         else:
             self.world = 1
+        # the gradient all-reduce through the library's own RCCL entry point (sbi_amd_allreduce_flat) instead of
+        # torch.distributed.all_reduce: what a C host binds; the process group only ships the communicator id once
+        self._native_allreduce = None
+        if distributed and native_allreduce:
+            from sbi_amd.utils.collectives import NativeAllReduce
+
+            self._native_allreduce = NativeAllReduce(self.dist, p.device, process_group)
 
     # -- state for resume_training / best-weights bookkeeping -----------------------
     def state_dict(self):
@@ -142,9 +150,13 @@ class FusedTrainStep:
         gb = global_batch if global_batch is not None else n * self.world
         x = self._embedded(x)
         losses, _ = self.net.train_pass(theta, x, None, 1.0 / gb, self.grad, workspace=self._workspace(n))
-        if self.distributed:
+        if self._native_allreduce is not None:
+            self._native_allreduce(self.grad)
+        elif self.distributed:
             all_reduce_sum(self.dist, self.grad, self.group)
         self._mark_grad_from_pass()
+        if self._native_allreduce is not None and self.world > 1:
+            self._grad_from_pass = False      # (written through a raw pointer: the pass's |grad|^2 partials are stale)
         return losses
 
     def _mark_grad_from_pass(self) -> None:

@@ -69,3 +69,47 @@ def broadcast_from_rank0(dist, t: Tensor, group=None) -> Tensor:
     dist.broadcast(host, src=0, group=group)
     t.copy_(host)
     return t
+
+
+class NativeAllReduce:
+    """The step's gradient all-reduce through the kernel library's own entry point (`sbi_amd_allreduce_flat`: RCCL
+    resolved by the library, include/sbi_amd_nsf.h) instead of `torch.distributed.all_reduce` -- the path a C / C++ host
+    takes.  `dist` (any initialised torch.distributed group, e.g. gloo) is only used ONCE, to ship rank 0's 128-byte
+    RCCL id to the other ranks.  Call it on a contiguous fp32 device tensor; the reduction is enqueued on the current
+    stream of the tensor's device."""
+
+    def __init__(self, dist, device, group=None):
+        import ctypes
+
+        from sbi_amd import _lib
+
+        self._lib = _lib
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        nbytes = int(lib.sbi_amd_rccl_unique_id_bytes())
+        box = [None]
+        if self.rank == 0:
+            buf = (ctypes.c_char * nbytes)()
+            _lib.check(lib.sbi_amd_rccl_unique_id(buf), "rccl_unique_id")
+            box[0] = bytes(buf)
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.sbi_amd_rccl_comm_init(ctypes.byref(comm), self.world, self.rank, box[0]), "rccl_comm_init")
+        self._comm = comm
+
+    def __call__(self, t: Tensor) -> Tensor:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+            raise ValueError("NativeAllReduce takes a contiguous float32 tensor on the communicator's device")
+        with torch.cuda.device(self.device):
+            rc = self._lib.load().sbi_amd_allreduce_flat(self._comm, self._lib.ptr(t), t.numel(),
+                                                         self._lib.current_stream(self.device))
+        self._lib.check(rc, "allreduce_flat")
+        return t
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None):
+            self._lib.load().sbi_amd_rccl_comm_destroy(self._comm)
+            self._comm = None
