@@ -351,8 +351,7 @@ def npe_train_leg(device, rank, world, epochs):
 
     from sbi_amd.inference import NPE
 
-    def run(n_sims, batch, ep, graph):
-        os.environ["SBI_AMD_GRAPH_EPOCH"] = "1" if graph else "0"
+    def run(n_sims, batch, ep):
         prior = Independent(Normal(torch.zeros(D, device=device), (0.1**0.5) * torch.ones(D, device=device)), 1)
         theta, x = make_data(n_sims, "cpu", seed=0)
         torch.manual_seed(1)
@@ -373,30 +372,14 @@ def npe_train_leg(device, rank, world, epochs):
         return {"value": batch * steps / dt, "unit": "pairs/s", "train_steps": steps, "epochs": ep,
                 "ms_per_epoch": dt / ep * 1e3, "simulations": n_sims, "training_batch_size": batch,
                 "validation_rows_per_epoch": ((n_sims - n_train) // bv) * bv,
-                "final_validation_loss": inf.summary["validation_loss"][-1],
-                "epochs_replayed_as_hip_graph": getattr(inf, "_graph_epochs", 0)}
+                "final_validation_loss": inf.summary["validation_loss"][-1]}
 
-    prev = os.environ.get("SBI_AMD_GRAPH_EPOCH")
-    try:
-        keep = ("value", "ms_per_epoch", "epochs_replayed_as_hip_graph")
-        head = run(N_SIMS, BATCH, epochs, False)
-        if world == 1:       # (epochs are only captured with one rank)
-            head["hip_graph_epochs"] = {k: v for k, v in run(N_SIMS, BATCH, epochs, True).items() if k in keep}
-        dense = run(728_200, BATCH, max(2, epochs // 10), False)
-        # sbi's default training_batch_size on the same simulations: 450 steps + 50 validation batches per epoch
-        small = run(N_SIMS, 200, 6, False)
-        if world == 1:
-            small["hip_graph_epochs"] = {k: v for k, v in run(N_SIMS, 200, 6, True).items() if k in keep}
-    finally:
-        if prev is None:
-            os.environ.pop("SBI_AMD_GRAPH_EPOCH", None)
-        else:
-            os.environ["SBI_AMD_GRAPH_EPOCH"] = prev
+    head = run(N_SIMS, BATCH, epochs)
+    dense = run(728_200, BATCH, max(2, epochs // 10))
+    # sbi's default training_batch_size on the same simulations: 450 steps + 50 validation batches per epoch
+    small = run(N_SIMS, 200, 6)
     return {"metric": "NPE.train() (theta,x)-pairs/sec (M2, SURVEY 8d)", **head, "dense_epochs": dense,
-            "batch_200": small, "n_gpus": world,
-            "note": "`hip_graph_epochs`: the same call with SBI_AMD_GRAPH_EPOCH=1 (epochs after the first captured once "
-                    "and replayed as one HIP graph; the timed call includes its own capture): opt-in, bit-identical "
-                    "results, slower than stream launches on this stack unless the host is the bottleneck"}
+            "batch_200": small, "n_gpus": world}
 
 
 def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):

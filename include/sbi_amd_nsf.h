@@ -168,33 +168,6 @@ int sbi_amd_shuffled_gather(const float* a, int32_t da, const float* b, int32_t 
                             int64_t n_perm, uint64_t key, int64_t offset, int64_t count, float* a_out, float* b_out,
                             int64_t* idx_out, void* stream);
 
-/* Data parallelism and this ABI.  SURVEY 8(b) sketched an `allreduce_flat` export; it is deliberately NOT here.  The
- * training pass leaves d( sum_n w_n loss_n ) / d params of the rank's rows in ONE flat buffer (grad_out), with the
- * 1 / global_batch weighting already inside the kernels (uniform_weight / row_weight), so the whole collective of a step
- * is a single SUM all-reduce of `param_count` floats between sbi_amd_nsf_loss_fwd_bwd and sbi_amd_adam_clip_step, in stream
- * order.  The communicator (rank discovery, bootstrap, xGMI topology, the lifetime of an ncclComm_t) belongs to the
- * host process's launcher -- `torch.distributed` with backend "nccl" (= RCCL) in sbi_amd/inference/trainers/fused.py,
- * `ncclAllReduce(grad, grad, P, ncclFloat, ncclSum, comm, stream)` for a C caller -- and wrapping that one call would
- * only add a second owner for the communicator.  Replicas that apply sbi_amd_adam_clip_step to identical reduced
- * gradients stay bit-identical (csrc/adam_math.h pins the roundings). */
-
-/* Epochs as HIP graphs (trainers/base.py:1150-1225 is a Python loop over DataLoader batches).  A captured
- * launch must not depend on anything the host changes from epoch to epoch; two things in a training step do -- the
- * sampler's per-epoch key and Adam's step count.  Both move to device memory:
- *   clock      int64[2]: [0] epoch number, [1] optimizer steps taken      bias_corr  float[2]: 1 - beta1^step, sqrt(1 - beta2^step)
- *   sbi_amd_train_clock_tick(clock, bias_corr, 0, ...)   epoch += 1                       (one thread; end of an epoch)
- *   sbi_amd_train_clock_tick(clock, bias_corr, 1, beta1, beta2, stream)   step += 1, bias corrections (before the update)
- *   sbi_amd_shuffled_gather_clock(..., seed, &clock[0], ...)              key = splitmix64(seed, epoch) in the kernel:
- *                                                                         same orders as sbi_amd_shuffled_gather
- *   sbi_amd_adam_clip_step_clock(..., bias_corr, ...)                     sqnorm_parts NULL: norm kernel first */
-int sbi_amd_train_clock_tick(int64_t* clock, float* bias_corr, int32_t which, float beta1, float beta2, void* stream);
-int sbi_amd_shuffled_gather_clock(const float* a, int32_t da, const float* b, int32_t db, const int64_t* base_idx,
-                                  int64_t n_perm, uint64_t seed, const int64_t* epoch_dev, int64_t offset,
-                                  int64_t count, float* a_out, float* b_out, int64_t* idx_out, void* stream);
-int sbi_amd_adam_clip_step_clock(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
-                                 const float* bias_corr, float lr, float beta1, float beta2, float eps, float max_norm,
-                                 const float* sqnorm_parts, int64_t n_parts, float* scratch, void* stream);
-
 /* Fused global-norm clip + Adam on the flat buffer: replaces
  * clip_grad_norm_(max_norm) + torch.optim.Adam.step (trainers/base.py:1181-1187,
  * :1097).  `step` is the 1-based step count; max_norm <= 0 disables clipping.
@@ -281,13 +254,19 @@ int sbi_amd_accept_compact(const float* candidates, const uint8_t* accepted, con
  * log_prob kernel just produced), advances every chain's BEGIN/LOWER/UPPER/SAMPLE_SLICE state, writes the next
  * evaluation points back into `next_param`, stores accepted sweeps into `samples`
  * (num_chains, num_samples, dim) after `tuning` width-tuning sweeps and counts finished chains in *done_count.
- * uniforms: (num_chains, 4 + dim) U[0,1) draws per tick from the caller's generator.
- * istate: (num_chains, 4) int32 {state, dim index, sweep, -}; fstate: (num_chains, 8) {cxi, wi, lx, ux, xi, logu}. */
+ * uniforms: (num_chains, 4 + dim) U[0,1) draws per tick from the caller's generator, or NULL: the kernel draws its own
+ *   (Philox4x32-10, counter = (tick_no, chain, block), key = seed; the reference's sampler uses NumPy's global generator:
+ *   there is no stream to reproduce, `seed` comes from torch's generator so that torch.manual_seed fixes a run).
+ * istate: (num_chains, 4) int32 {state, dim index, sweep, -}; fstate: (num_chains, 8) {cxi, wi, lx, ux, xi, logu}.
+ * theta_next / logabsdet_next (both or neither): the NEXT evaluation point mapped to constrained space by the
+ *   transform `kind` (p0, p1: see sbi_amd_mcmc_to_constrained) and its log|det| -- what the batched log_prob kernel and
+ *   this call's `logp_offset` read in the next tick, so a tick is two launches: log_prob, this. */
 int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples, int32_t tuning, float max_width,
                             const float* logp, const float* logp_offset /* optional (num_chains): subtracted */,
                             const float* uniforms, float* x, float* next_param, float* width,
                             int32_t* order, int32_t* istate, float* fstate, float* samples, int32_t* done_count,
-                            void* stream);
+                            uint64_t seed, uint64_t tick_no, int32_t kind, const float* p0, const float* p1,
+                            float* theta_next, float* logabsdet_next, void* stream);
 
 /* Unconstrained -> constrained parameters for the transforms of mcmc_transform (sbi/utils/sbiutils.py:867-980)
  * and the log|det| term of transformed_potential (sbi/utils/potentialutils.py:15-51) in one launch:

@@ -127,17 +127,6 @@ _SIGNATURES = {
         [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_int64, c_int64, c_void_p, c_void_p,
          c_void_p, c_void_p],
     ),
-    "sbi_amd_shuffled_gather_clock": (
-        c_int,
-        [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_uint64, c_void_p, c_int64, c_int64, c_void_p,
-         c_void_p, c_void_p, c_void_p],
-    ),
-    "sbi_amd_train_clock_tick": (c_int, [c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
-    "sbi_amd_adam_clip_step_clock": (
-        c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float,
-         c_void_p, c_int64, c_void_p, c_void_p],
-    ),
     "sbi_amd_rq_spline": (
         c_int,
         [c_int32, c_int32, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
@@ -146,7 +135,8 @@ _SIGNATURES = {
     "sbi_amd_mcmc_slice_tick": (
         c_int,
         [c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int32, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p],
     ),
     "sbi_amd_mcmc_to_constrained": (
         c_int,

@@ -36,12 +36,7 @@ grad_sqnorm_partials(const float* __restrict__ g, long long count, float* __rest
 __global__ void __launch_bounds__(ADAM_THREADS)
 adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
             long long count, float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-            float max_norm, const float* __restrict__ parts, int npart, float* __restrict__ scratch,
-            const float* __restrict__ bias_corr_dev) {
-  if (bias_corr_dev) {      // captured epochs: the step count lives on the device (sbi_amd_train_clock_tick)
-    bc1 = bias_corr_dev[0];
-    bc2_sqrt = bias_corr_dev[1];
-  }
+            float max_norm, const float* __restrict__ parts, int npart, float* __restrict__ scratch) {
   float norm;
   const float coef = adam_clip_coef_block(parts, npart, max_norm, &norm);
   if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = norm;
@@ -57,7 +52,7 @@ adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restric
 
 static int adam_launch(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, int64_t step,
                        float lr, float beta1, float beta2, float eps, float max_norm, const float* parts, int64_t n_parts,
-                       float* scratch, hipStream_t st, const float* bias_corr_dev = nullptr) {
+                       float* scratch, hipStream_t st) {
   static_assert(ADAM_THREADS == ADAM_BLOCK, "adam_clip_coef_block is written for the update kernel's workgroup size");
   int nwg = (int)((count + ADAM_THREADS * 4 - 1) / (ADAM_THREADS * 4));     // norm kernel: <= ADAM_NWG partial sums (scratch)
   if (nwg > ADAM_NWG) nwg = ADAM_NWG;
@@ -76,7 +71,7 @@ static int adam_launch(float* params, const float* grad, float* exp_avg, float* 
   }
   hipLaunchKernelGGL(adam_update, dim3(uwg), dim3(ADAM_THREADS), 0, st, params, grad, exp_avg, exp_avg_sq,
                      (long long)count, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, parts, (int)n_parts,
-                     scratch, bias_corr_dev);
+                     scratch);
   return (int)hipGetLastError();
 }
 
@@ -101,19 +96,4 @@ extern "C" int sbi_amd_adam_clip_step_parts(float* params, const float* grad, fl
   if (count == 0) return 0;
   return adam_launch(params, grad, exp_avg, exp_avg_sq, count, step, lr, beta1, beta2, eps, max_norm, sqnorm_parts,
                      n_parts, scratch, (hipStream_t)stream);
-}
-
-// The same step with the bias corrections read from DEVICE memory (bias_corr[0] = 1 - beta1^step, bias_corr[1] =
-// sqrt(1 - beta2^step), maintained by sbi_amd_train_clock_tick): nothing in the launch depends on the host's step
-// count, so it can sit in a HIP graph that is replayed every epoch.  sqnorm_parts may be NULL (norm kernel first).
-extern "C" int sbi_amd_adam_clip_step_clock(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                            int64_t count, const float* bias_corr, float lr, float beta1, float beta2,
-                                            float eps, float max_norm, const float* sqnorm_parts, int64_t n_parts,
-                                            float* scratch, void* stream) {
-  if (!params || !grad || !exp_avg || !exp_avg_sq || !scratch || !bias_corr || count < 0 ||
-      (sqnorm_parts && (n_parts < 1 || n_parts > (1 << 24))))
-    return SBI_AMD_E_BADARG;
-  if (count == 0) return 0;
-  return adam_launch(params, grad, exp_avg, exp_avg_sq, count, 1, lr, beta1, beta2, eps, max_norm, sqnorm_parts,
-                     sqnorm_parts ? n_parts : 0, scratch, (hipStream_t)stream, bias_corr);
 }

@@ -244,6 +244,11 @@ class MCMCPosterior:
             logp, _ = est._kernel_log_prob(theta, x_row, False)
             return logp, lad
 
+        def log_q(theta: Tensor) -> Tensor:      # the estimator's log-density at constrained points, one launch
+            return est._kernel_log_prob(theta, x_row, False)[0]
+
+        # the slice sampler's tick kernel applies the transform itself (sbi_amd_mcmc_slice_tick): two launches per tick
+        potential_.fused_spec = (kind, p0, p1, log_q)
         return potential_
 
     def _get_initial_params(self, init_strategy: str, num_chains: int, **kwargs) -> Tensor:

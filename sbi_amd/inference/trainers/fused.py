@@ -66,7 +66,6 @@ class FusedTrainStep:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
-        self.sync_clock()
 
     # -- device snapshots for the software-pipelined epoch loop of NPE.train() -------------------
     def snapshot(self) -> dict:
@@ -89,30 +88,11 @@ class FusedTrainStep:
         self.exp_avg.copy_(snap["exp_avg"])
         self.exp_avg_sq.copy_(snap["exp_avg_sq"])
         self.step_count = int(snap["step"])
-        self.sync_clock()
 
-    # -- device-resident clock (epochs as HIP graphs: include/sbi_amd_nsf.h "Epochs as HIP graphs") --------------
     # images (bit 0 throughput, bit 1 cooperative) the step's table-driven re-pack refreshes IN ADDITION to the one the
     # training batches read: a loop whose validation batches take the other kernel family and that has only a step or
     # two per epoch saves the separate pack launch per epoch (NPE.train sets it; 0: only the training image)
     tail_extra_images = 0
-    clock: Optional[Tensor] = None          # int64[2] on the device: [epoch number, optimizer steps taken]
-    bias_corr: Optional[Tensor] = None      # float[2]: 1 - beta1^step, sqrt(1 - beta2^step)
-    _clock_mode = False                     # True while an epoch is being CAPTURED: apply() reads the device clock
-
-    def sync_clock(self, epoch: Optional[int] = None) -> None:
-        """Write the host's step count (and, if given, the epoch number) into the device clock; allocates it on first
-        use.  Called before a captured epoch is first replayed and whenever the host rewinds the optimizer state."""
-        if self.clock is None:
-            if epoch is None:
-                return
-            dev = self.net.flat_params.device
-            self.clock = torch.zeros(2, dtype=torch.int64, device=dev)
-            self.bias_corr = torch.ones(2, dtype=torch.float32, device=dev)
-        self.clock[1:2].fill_(int(self.step_count))
-        if epoch is not None:
-            self.clock[0:1].fill_(int(epoch))
-
     def restore(self, snap: dict) -> None:
         """Weights AND optimizer state of a snapshot.  The write goes behind autograd's back (`.data`), so the tensor
         version the packed-weight cache is keyed on does not move: drop the cache, or log_prob / sample after a
@@ -309,23 +289,11 @@ class FusedTrainStep:
         p = self.net.flat_params
         dev = p.device
         tail = self._tail()
-        clocked = self._clock_mode       # captured epoch: the step count is the device clock's, the host adds it up per replay
-        if not clocked:
-            self.step_count += 1
+        self.step_count += 1
         parts = self._norm_parts()
         self._grad_from_pass = False         # (whoever changes self.grad by hand and calls apply() again gets the norm kernel)
         with torch.cuda.device(dev):
-            if clocked:
-                rc = lib.sbi_amd_train_clock_tick(_lib.ptr(self.clock), _lib.ptr(self.bias_corr), 1, self.betas[0],
-                                                  self.betas[1], _lib.current_stream(dev))
-                _lib.check(rc, "train_clock_tick")
-                rc = lib.sbi_amd_adam_clip_step_clock(
-                    _lib.ptr(p.data), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                    p.numel(), _lib.ptr(self.bias_corr), self.lr, self.betas[0], self.betas[1], self.eps, self.clip,
-                    None if parts is None else parts[0], 0 if parts is None else parts[1], _lib.ptr(self.scratch),
-                    _lib.current_stream(dev),
-                )
-            elif parts is not None:      # |grad|^2 as partial sums the gradient reduction left in the workspace
+            if parts is not None:      # |grad|^2 as partial sums the gradient reduction left in the workspace
                 rc = lib.sbi_amd_adam_clip_step_parts(
                     _lib.ptr(p.data), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                     p.numel(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.clip,

@@ -489,74 +489,10 @@ class PosteriorEstimatorTrainer:
         elif fused:
             self._stepper.tail_extra_images = 0
 
-        # Epochs as HIP graphs, OPT-IN (SBI_AMD_GRAPH_EPOCH=1): after one eager epoch (which sizes the
-        # workspace, builds the re-pack table and leaves the allocator warm) the epoch's device work -- per batch: gather,
-        # forward, T backward launches, reduction, clip + Adam, re-pack; then the validation pass and the loss sums -- is
-        # captured ONCE and replayed with one host call per epoch.  Nothing in it depends on the host: the sampler's
-        # epoch number and Adam's step count live in device memory (`FusedTrainStep.clock`, ticked by the graph itself).
-        # What stays outside the graph: the snapshot of the weights / optimizer state (every in-flight epoch record needs
-        # its own copy), the read-back of the two loss sums and the events.  Not captured (the eager loop runs): the
-        # atomic loss and validation orders that need fresh random numbers, more than one rank, index-path data.
-        # Results are bit-identical to the eager loop (tests/test_graph_epoch_gpu.py).  Why it is not the default:
-        # measured on MI355X / ROCm 7.2 (profiles/r5_bench.json, `npe_train.*.hip_graph_epochs`) a replayed kernel
-        # node costs MORE than a stream launch -- 72.0 vs 63.5 ms per epoch at sbi's default batch 200 (450 steps, ~3 200
-        # nodes), 1.07 vs 1.00 ms at batch 65 536 -- so the graph only pays where the HOST cannot keep the stream fed.
-        graphable = (pipelined and sampler is not None and not atomic and d is None and n_val_batches * Bv == n_val
-                     and _os.environ.get("SBI_AMD_GRAPH_EPOCH", "0") == "1")
-        gstate = {"graph": None, "sums": None, "warm": False, "failed": False}
-
-        def epoch_body() -> Tensor:
-            """One epoch's device work with no host-dependent launch argument (capturable)."""
-            tr_rows, va_rows = [], []
-            net.train()
-            for b in range(n_train_batches):
-                th, xx = sampler.batch_clock(self._stepper.clock, *my_range(b * B, B))
-                tr_rows.append(self._stepper.step(th, xx, global_batch=B))
-            net.eval()
-            for b in range(n_val_batches):
-                va_rows.append(val_batch_losses(b, val_idx))
-            sums_ = loss_sums(tr_rows, va_rows, torch.zeros(2, device=self._device))
-            rc = _lib_mod.load().sbi_amd_train_clock_tick(_lib_mod.ptr(self._stepper.clock), None, 0, 0.0, 0.0,
-                                                          _lib_mod.current_stream(torch.device(self._device)))
-            _lib_mod.check(rc, "train_clock_tick")
-            return sums_
-
-        def capture_epoch(e: int) -> bool:
-            self._stepper.sync_clock(epoch=e)
-            torch.cuda.synchronize(self._device)
-            g = torch.cuda.CUDAGraph()
-            self._stepper._clock_mode = True
-            try:
-                with torch.cuda.graph(g):
-                    gstate["sums"] = epoch_body()
-                gstate["graph"] = g
-                return True
-            except Exception as exc:      # noqa: BLE001 -- any capture failure: keep training on the eager loop
-                warnings.warn(f"sbi_amd: the epoch could not be captured as a HIP graph ({exc!r}); NPE.train() "
-                              "continues on the eager loop", stacklevel=2)
-                gstate["failed"] = True
-                return False
-            finally:
-                self._stepper._clock_mode = False
-
         def launch_epoch(e: int) -> dict:
             """Enqueue one epoch's device work (training steps, validation pass, [loss all-reduce]); nothing here
             waits for the device.  Returns the record `finish_epoch` turns into the epoch's host bookkeeping."""
             rec = {"epoch": e, "t0": time.time()}
-            if graphable and gstate["warm"] and not gstate["failed"] and (gstate["graph"] is not None or capture_epoch(e)):
-                rec["ev0"] = torch.cuda.Event(enable_timing=True)
-                rec["ev0"].record()
-                gstate["graph"].replay()
-                self._graph_epochs = getattr(self, "_graph_epochs", 0) + 1
-                self._stepper.step_count += n_train_batches       # (the device clock counted them itself)
-                rec["snap"] = snap_ring[e % len(snap_ring)] = self._stepper.snapshot_into(snap_ring[e % len(snap_ring)])
-                rec["host"] = host_ring[e % len(host_ring)]
-                rec["host"].copy_(gstate["sums"], non_blocking=True)
-                rec["event"] = torch.cuda.Event(enable_timing=True)
-                rec["event"].record()
-                rec["graph"] = True
-                return rec
-            gstate["warm"] = True
             if pipelined:      # the epoch's own device time (the host clock would also count the NEXT epoch's enqueue)
                 rec["ev0"] = torch.cuda.Event(enable_timing=True)
                 rec["ev0"].record()
@@ -696,10 +632,6 @@ class PosteriorEstimatorTrainer:
             self._summarize(self._round)
         if cfg.show_train_summary and rank == 0:
             print(self._describe_round())
-        if gstate["graph"] is not None:
-            # replays moved the weights behind the host-side cache bookkeeping of the packed images: start clean
-            getattr(net, "net", net).__dict__.pop("_packed_cache", None)
-            gstate["graph"] = gstate["sums"] = None
         net.zero_grad(set_to_none=True)
         return deepcopy(net)
 

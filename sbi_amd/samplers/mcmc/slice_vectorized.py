@@ -54,7 +54,33 @@ class SliceSamplerVectorized:
         done = torch.zeros(1, dtype=torch.int32, device=dev)
         max_width = self.max_width if self.max_width != float("inf") else 3.0e38
         tick = 0
-        while True:
+        fused = getattr(self._log_prob_fn, "fused_spec", None)
+        if fused is not None:
+            # Two launches per tick: the batched log_prob kernel on the constrained point, then the tick kernel, which
+            # also draws its uniforms (Philox keyed by a seed from torch's generator) and maps the NEXT evaluation point
+            # to constrained space.  (The reference's sampler draws from NumPy's global generator,
+            # slice_numpy.py:353-587: a distribution to match, not a stream.)
+            kind, p0, p1, log_q = fused
+            seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+            theta = torch.empty_like(nxt)
+            lad = torch.empty(C, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.sbi_amd_mcmc_to_constrained(kind, C, D, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(nxt), _lib.ptr(theta),
+                                                     _lib.ptr(lad), _lib.current_stream(dev))
+            _lib.check(rc, "mcmc_to_constrained")
+            while True:
+                logp = log_q(theta)
+                with torch.cuda.device(dev):
+                    rc = lib.sbi_amd_mcmc_slice_tick(C, D, int(num_samples), self.tuning, max_width, _lib.ptr(logp),
+                                                     _lib.ptr(lad), None, _lib.ptr(x), _lib.ptr(nxt), _lib.ptr(width),
+                                                     _lib.ptr(order), _lib.ptr(istate), _lib.ptr(fstate),
+                                                     _lib.ptr(samples), _lib.ptr(done), seed, tick, kind, _lib.ptr(p0),
+                                                     _lib.ptr(p1), _lib.ptr(theta), _lib.ptr(lad), _lib.current_stream(dev))
+                _lib.check(rc, "mcmc_slice_tick")
+                tick += 1
+                if tick % self.poll_every == 0 and int(done.item()) == C:
+                    break
+        while fused is None:
             out = self._log_prob_fn(nxt)
             # a (log_prob, offset) pair keeps the potential's "- log|det|" out of a separate launch
             logp, offset = out if isinstance(out, tuple) else (out, None)
@@ -67,7 +93,8 @@ class SliceSamplerVectorized:
                                                  _lib.ptr(offset), _lib.ptr(u), _lib.ptr(x), _lib.ptr(nxt),
                                                  _lib.ptr(width),
                                                  _lib.ptr(order), _lib.ptr(istate), _lib.ptr(fstate),
-                                                 _lib.ptr(samples), _lib.ptr(done), _lib.current_stream(dev))
+                                                 _lib.ptr(samples), _lib.ptr(done), 0, 0, 0, None, None, None, None,
+                                                 _lib.current_stream(dev))
             _lib.check(rc, "mcmc_slice_tick")
             tick += 1
             if tick % self.poll_every == 0 and int(done.item()) == C:

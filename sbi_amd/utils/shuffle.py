@@ -61,22 +61,6 @@ class ShuffledGather:
                 _lib.current_stream(self.dev))
         _lib.check(rc, "shuffled_gather")
 
-    def batch_clock(self, clock: Tensor, offset: int, count: int) -> Tuple[Tensor, Tensor]:
-        """`batch` with the epoch number read from DEVICE memory (`clock[0]`, int64): the launch does not depend on
-        anything the host changes per epoch, so it can be captured in a HIP graph and replayed (NPE.train)."""
-        if clock.dtype != torch.int64 or not clock.is_cuda:
-            raise TypeError("batch_clock expects the int64 device clock of a FusedTrainStep")
-        th = torch.empty(count, self.theta_all.shape[1], dtype=torch.float32, device=self.dev)
-        xx = torch.empty(count, self.x_all.shape[1], dtype=torch.float32, device=self.dev)
-        with torch.cuda.device(self.dev):
-            rc = _lib.load().sbi_amd_shuffled_gather_clock(
-                _lib.ptr(self.theta_all), self.theta_all.shape[1], _lib.ptr(self.x_all), self.x_all.shape[1],
-                None if self.base_idx is None else _lib.ptr(self.base_idx), self.n, self.seed & _M64,
-                _lib.ptr(clock), int(offset), int(count), _lib.ptr(th), _lib.ptr(xx), None,
-                _lib.current_stream(self.dev))
-        _lib.check(rc, "shuffled_gather_clock")
-        return th, xx
-
     def batch(self, epoch: int, offset: int, count: int) -> Tuple[Tensor, Tensor]:
         th = torch.empty(count, self.theta_all.shape[1], dtype=torch.float32, device=self.dev)
         xx = torch.empty(count, self.x_all.shape[1], dtype=torch.float32, device=self.dev)

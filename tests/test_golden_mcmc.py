@@ -75,7 +75,7 @@ def test_tick_kernel_walks_the_reference_sampler_trajectories():
         u = table[tick].contiguous()
         rc = lib.sbi_amd_mcmc_slice_tick(C, D, NS, TUNE, 3.0e38, _lib.ptr(logp), None, _lib.ptr(u), _lib.ptr(x),
                                          _lib.ptr(nxt), _lib.ptr(width), _lib.ptr(order), _lib.ptr(istate),
-                                         _lib.ptr(fstate), _lib.ptr(samples), _lib.ptr(done), _lib.current_stream(dev))
+                                         _lib.ptr(fstate), _lib.ptr(samples), _lib.ptr(done), 0, 0, 0, None, None, None, None, _lib.current_stream(dev))
         assert rc == 0
         if tick % 32 == 31 and int(done.item()) == C:
             break

@@ -175,7 +175,7 @@ def test_tick_kernel_matches_tensorised_restatement_bit_for_bit():
         assert torch.equal(logp, f(st["nxt"]))
         rc = lib.sbi_amd_mcmc_slice_tick(C, D, NS, TUNE, MAXW, _lib.ptr(logp), None, _lib.ptr(u), _lib.ptr(x), _lib.ptr(nxt),
                                          _lib.ptr(width), _lib.ptr(order), _lib.ptr(istate), _lib.ptr(fstate),
-                                         _lib.ptr(samples), _lib.ptr(done), _lib.current_stream(torch.device(dev)))
+                                         _lib.ptr(samples), _lib.ptr(done), 0, 0, 0, None, None, None, None, _lib.current_stream(torch.device(dev)))
         assert rc == 0
         _torch_tick(st, logp, u, NS, TUNE, MAXW)
         assert torch.equal(istate[:, 0].long(), st["state"]), tick

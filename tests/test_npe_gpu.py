@@ -225,7 +225,6 @@ def test_pipelined_loop_puts_back_the_last_finite_epoch_before_raising_on_nan(mo
 
     # (the injection below is host code inside `step`: it needs the eager loop -- a captured epoch replays kernels, not
     #  Python; the read-back / restore logic of `finish_epoch` under test is shared by both)
-    monkeypatch.setenv("SBI_AMD_GRAPH_EPOCH", "0")
     dim, n = 2, 400
     torch.manual_seed(0)
     prior = MultivariateNormal(torch.zeros(dim, device="cuda"), torch.eye(dim, device="cuda"))
