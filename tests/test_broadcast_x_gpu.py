@@ -56,7 +56,9 @@ def test_log_prob_one_x_o(cfg, n):
     rp, rs = row_parity(got, ref), row_parity(got, per_row)
     print(f"{_ids(cfg)} n={n}: vs oracle worst {rp['worst_scaled']:.2f} x bound ({rp['exceed_frac']:.3%} beyond), vs the "
           f"per-row kernels worst {rs['worst_scaled']:.2f} x bound, max |d| {rs['max_abs']:.2e}")
-    few = max(0.01, 1.5 / n)        # (one row of 60 is already 1.7 %)
+    # (one row of 60 is already 1.7 %; the eager fp32 oracle itself misses its fp64 evaluation by more than the bound on
+    #  ~9 % of rows, DESIGN.md section 2, so at n = 60 two rows may land beyond it: worst 1.2 x the bound in round 6)
+    few = max(0.01, 2.5 / n)
     assert rp["exceed_frac"] <= few and rp["worst_scaled"] <= 4.0, rp
     assert rs["exceed_frac"] <= few and rs["worst_scaled"] <= 4.0, rs
 
