@@ -830,7 +830,7 @@ def main(argv=None):
         th_all, x_all = make_data(n_train, device, seed=1000 + (rank if args.scaling == "weak" else 0))
         leg = TrainLeg(est, th_all, x_all, B, distributed, GB)
         wall, dev_ms = timed(leg, args.steps, args.warmup, device, dist)
-        # roofline: the fused step's kernels only (pack, forward, T backward launches, reduce, [all-reduce], clip+Adam),
+        # roofline: the fused step's kernels only (pack, forward, the backward launch over all T transforms, reduce, [all-reduce], clip+Adam),
         # HIP events on the launch stream around every step; the sampler's gather kernel is in `value` only
         fused_ms = leg.fused_ms(args.steps)
         results["train"] = {"value": GB * args.steps / wall, "unit": "pairs/s",
@@ -920,7 +920,7 @@ def main(argv=None):
                                            "`strong_scaling` object"),
                        **({"shared_gpu": "all ranks on device 0 over gloo (SBI_AMD_BENCH_SHARE_GPU=1): a code-path "
                                          "run, not a scaling measurement"} if share_gpu else {})},
-            # whole step (forward + T backward launches + reduce + clip/Adam) against dense fp32 MFMA;
+            # whole step (forward + one backward launch over the T transforms + reduce + clip/Adam) against dense fp32 MFMA;
             # per-kernel durations: profiles/*kernel_stats.csv
             "roofline": r["roofline"],
         }
