@@ -182,7 +182,9 @@ nsf_coop_pack_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restric
 // the parameter the word belongs to (CoShape::dw_tb); padding words are skipped.  Finishes LULinear's diagonal as the
 // throughput path's nsf_grad_reduce_kernel does:  d/d(unconstrained_upper_diag_i) =
 //   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i).   Rider: loss_out = -log p.
+#ifndef CO_RED_GROUPS
 #define CO_RED_GROUPS 8
+#endif
 __global__ void __launch_bounds__(64 * CO_RED_GROUPS)
 nsf_coop_reduce_kernel(const NsfPlan pl, const CoopPlan cp, const float* __restrict__ params,
                        const float* __restrict__ partial, float* __restrict__ grad, const float* __restrict__ logp,

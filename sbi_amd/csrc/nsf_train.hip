@@ -11,7 +11,9 @@
 // finishes LULinear's diagonal: d/d(unconstrained_upper_diag_i) =
 //   (dL/dU_ii + (sum_n dL/dlogabsdet_n) / U_ii) * sigmoid(unconstrained_i)
 // block = 64 params x 8 slab groups: enough loads in flight to stream the ~100 MB of partials.
+#ifndef RED_GROUPS
 #define RED_GROUPS 8
+#endif
 // grid (ceil(PLP / 256), T): one thread sums FOUR consecutive slab words (16-byte loads, 4 x 8-way in flight) over the
 // workgroups' slabs; a slab is indexed relative to its transform's parameter block, so the words are 16-byte aligned
 __global__ void __launch_bounds__(64 * RED_GROUPS)
