@@ -134,9 +134,9 @@ def test_inverse_transform_and_round_trip():
     with torch.no_grad():
         ref = oracle.inverse_transform(theta, x)
     noise = est.inverse_transform(theta.cuda(), x.cuda())
-    assert (noise.cpu() - ref).abs().max() <= 5e-5
+    assert (noise.cpu() - ref).abs().max() <= 3e-5      # (measured 9.5e-6: tools/diag/measure_gates.py)
     back = est.sample_from_noise(noise, x.cuda())
-    assert (back.cpu() - theta).abs().max() <= 1e-4
+    assert (back.cpu() - theta).abs().max() <= 3e-5      # (measured 6.2e-6, tail rows included)
 
 
 def test_broadcast_condition_and_sample_dim():
@@ -186,7 +186,7 @@ def test_full_size_round_trip_65536():
     x = (torch.randn(n, 10, generator=g) * 0.45).cuda()
     theta, ld = est.sample_from_noise(noise, x, with_logabsdet=True)
     back = est.inverse_transform(theta, x)
-    assert (back - noise).abs().max() <= 2e-4
+    assert (back - noise).abs().max() <= 2.5e-5      # (measured 5.0e-6 over 65 536 rows)
     lp = est.log_prob(theta, x)[0]
     base = -0.5 * (noise**2).sum(1) - est.net._log_z.to(noise.device).float()
-    assert (lp - (base - ld)).abs().max() <= 2e-4
+    assert (lp - (base - ld)).abs().max() <= 1e-4      # (measured 3.6e-5 max, 2.3e-5 at the 99.9th percentile: two fp32 log-det sums of 25 terms each)
