@@ -231,6 +231,22 @@ int sbi_amd_rccl_comm_init(void** comm_out, int32_t world, int32_t rank, const v
 int sbi_amd_rccl_comm_destroy(void* comm);
 int sbi_amd_allreduce_flat(void* comm, float* grad_bucket, int64_t count, void* stream);
 
+/* Multi-round NPE-C, atomic proposal-posterior loss (sbi/inference/trainers/npe/npe_c.py:356-440): the host-side
+ * arithmetic around the batched log_prob as two launches (csrc/atomic.hip).
+ *   sbi_amd_atomic_atoms: for every row b of theta (batch, dim) draws num_atoms - 1 contrasting rows != b, uniform without
+ *     replacement (npe_c.py:387-392; Philox keyed by `seed`, or taken from choices_in (batch, num_atoms - 1) when given),
+ *     optionally returns them (choices_out) and writes the atom tensor atoms_out (num_atoms, batch, dim), atom 0 = the
+ *     row itself -- atoms-major, so sbi_amd_nsf_train_forward(..., n = num_atoms * batch, x_rows = batch) pairs row r
+ *     with x[r % batch] and the context is never repeated.  num_atoms <= 64 (SBI_AMD_E_UNSUPPORTED beyond).
+ *   sbi_amd_atomic_weights: log_q, log_prior (num_atoms, batch) -> log_prob_out (batch) = u[0] - logsumexp_a u[a],
+ *     u = log_q - log_prior (+ masks * log_q[0] for the combined loss, npe_c.py:425-436), and weights_out (num_atoms,
+ *     batch) = scale * d log_prob_out[b] / d log_q[a, b]: the row weights of sbi_amd_nsf_train_backward, which
+ *     differentiates sum_n w_n * (-log q_n) (scale = 1 / global_batch for the loss -log_prob_out). */
+int sbi_amd_atomic_atoms(const float* theta, int32_t batch, int32_t num_atoms, int32_t dim, uint64_t seed,
+                         const int64_t* choices_in, int64_t* choices_out, float* atoms_out, void* stream);
+int sbi_amd_atomic_weights(const float* log_q, const float* log_prior, const float* masks, int32_t batch,
+                           int32_t num_atoms, float scale, float* log_prob_out, float* weights_out, void* stream);
+
 /* Stable stream compaction of accepted proposal draws: the body of accept_reject_sample's loop
  * (sbi/samplers/rejection/rejection.py:368-409 -- `candidates[are_accepted]` per condition, appended in order, plus the
  * running counts of the batch-size rule) as ONE launch (csrc/compact.hip: acceptance test, single-pass scan with

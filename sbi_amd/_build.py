@@ -14,7 +14,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libsbi_amd_nsf.so"
 SOURCES = ["nsf_plan.cpp", "nsf_flow.hip", "nsf_flow_inv.hip", "nsf_train.hip", "nsf_train_k4.hip", "nsf_train_k5.hip", "nsf_train_k8.hip", "nsf_train_k16.hip", "fmpe.hip", "ode.hip",
-           "adam.hip", "spline_abi.hip", "step_tail.hip", "shuffle.hip", "compact.hip", "allreduce.hip", "mcmc_slice.hip", "nsf_gtrain.hip", "nsf_coop_plan.cpp", "nsf_coop.hip", "nsf_coop_k4.hip", "nsf_coop_k5.hip", "nsf_coop_k8.hip", "nsf_coop_k16.hip", "maf.hip", "maf_k4.hip", "maf_k5.hip", "maf_k8.hip", "maf_k16.hip"]
+           "adam.hip", "spline_abi.hip", "step_tail.hip", "shuffle.hip", "compact.hip", "allreduce.hip", "atomic.hip", "mcmc_slice.hip", "nsf_gtrain.hip", "nsf_coop_plan.cpp", "nsf_coop.hip", "nsf_coop_k4.hip", "nsf_coop_k5.hip", "nsf_coop_k8.hip", "nsf_coop_k16.hip", "maf.hip", "maf_k4.hip", "maf_k5.hip", "maf_k8.hip", "maf_k16.hip"]
 HEADERS = ["adam_math.h", "nsf_plan.h", "nsf_plan_layout.h", "nsf_coop_wide_kernel.h", "nsf_device.h", "nsf_flow_kernel.h", "nsf_train_kernel.h", "debug_env.h", "maf_kernel.h", "nsf_gtrain_kernel.h", "nsf_coop.h", "nsf_coop_kernel.h", "nsf_coop_host.h", "../../include/sbi_amd_maf.h",
            "../../include/sbi_amd_nsf.h", "../../include/sbi_amd_fmpe.h"]
 HASH_PATH = LIB_PATH.with_suffix(".so.srchash")   # travels with the .so (git-ignored, not gpurun-ignored)

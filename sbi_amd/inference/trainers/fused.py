@@ -165,22 +165,48 @@ class FusedTrainStep:
         A = clamp_num_atoms(num_atoms, B)
         self._last_rows = A * B
         gb = global_batch if global_batch is not None else B * self.world
-        if choices is None:
-            choices = sample_contrasting_indices(B, A, theta.device)
-        flat = build_atoms(theta, choices).reshape(A * B, -1).contiguous()
         ws = self._workspace(A * B)
-        lp = train_forward(self.net, flat, x, ws).reshape(A, B)
-        lprior = prior.log_prob(flat).reshape(A, B)
-        un = lp - lprior
-        lse = torch.logsumexp(un, dim=0)
-        lpp = un[0] - lse
-        w = -torch.exp(un - lse)          # d lpp_b / d log q[a, b] = delta_{a0} - softmax_a
-        w[0] += 1.0
-        if use_combined_loss:             # + masks * log q(theta_b | x_b): the same values as atom 0
-            m = masks.reshape(-1).to(lp.dtype)
-            lpp = m * lp[0] + lpp
-            w[0] += m
-        train_backward(self.net, x, A * B, (w / gb).reshape(-1).contiguous(), self.grad, ws)
+        fused_host = (theta.is_cuda and theta.dtype == torch.float32 and theta.ndim == 2 and A - 1 <= 63
+                      and (choices is None or choices.is_cuda))
+        if fused_host:
+            # the arithmetic around the batched log_prob as two launches (csrc/atomic.hip) instead of ~80 eager tensor
+            # operations: contrasting rows + atom tensor, then log q~ and the softmax weights of the backward pass
+            lib = _lib.load()
+            dev = theta.device
+            th = theta.contiguous()
+            flat = torch.empty(A * B, th.shape[1], dtype=torch.float32, device=dev)
+            seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item()) if choices is None else 0
+            ch = None if choices is None else choices.to(torch.int64).contiguous()
+            with torch.cuda.device(dev):
+                rc = lib.sbi_amd_atomic_atoms(_lib.ptr(th), B, A, th.shape[1], seed, _lib.ptr(ch), None, _lib.ptr(flat),
+                                              _lib.current_stream(dev))
+            _lib.check(rc, "atomic_atoms")
+            lp = train_forward(self.net, flat, x, ws).reshape(-1).contiguous()
+            lprior = prior.log_prob(flat).reshape(-1).to(torch.float32).contiguous()
+            m = masks.reshape(-1).to(torch.float32).contiguous() if use_combined_loss else None
+            lpp = torch.empty(B, dtype=torch.float32, device=dev)
+            w = torch.empty(A * B, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.sbi_amd_atomic_weights(_lib.ptr(lp), _lib.ptr(lprior), _lib.ptr(m), B, A, 1.0 / gb, _lib.ptr(lpp),
+                                                _lib.ptr(w), _lib.current_stream(dev))
+            _lib.check(rc, "atomic_weights")
+            train_backward(self.net, x, A * B, w, self.grad, ws)
+        else:
+            if choices is None:
+                choices = sample_contrasting_indices(B, A, theta.device)
+            flat = build_atoms(theta, choices).reshape(A * B, -1).contiguous()
+            lp = train_forward(self.net, flat, x, ws).reshape(A, B)
+            lprior = prior.log_prob(flat).reshape(A, B)
+            un = lp - lprior
+            lse = torch.logsumexp(un, dim=0)
+            lpp = un[0] - lse
+            w = -torch.exp(un - lse)          # d lpp_b / d log q[a, b] = delta_{a0} - softmax_a
+            w[0] += 1.0
+            if use_combined_loss:             # + masks * log q(theta_b | x_b): the same values as atom 0
+                m = masks.reshape(-1).to(lp.dtype)
+                lpp = m * lp[0] + lpp
+                w[0] += m
+            train_backward(self.net, x, A * B, (w / gb).reshape(-1).contiguous(), self.grad, ws)
         if self.distributed:
             all_reduce_sum(self.dist, self.grad, self.group)
         self._mark_grad_from_pass()

@@ -84,3 +84,56 @@ def test_two_round_npe_c_linear_gaussian_c2st():
     score = c2st(samples, target).item()
     print(f"two-round NPE-C c2st={score:.3f} epochs={inf.summary['epochs_trained']}")
     assert 0.4 <= score <= 0.6
+
+
+def test_device_atom_sampler_is_uniform_without_replacement():
+    """csrc/atomic.hip: contrasting rows as npe_c.py:387-392 draws them -- num_atoms - 1 distinct rows != b, every row
+    equally likely at every position -- and the atoms-major atom tensor built from them."""
+    from sbi_amd import _lib
+
+    lib = _lib.load()
+    B, A, D = 50, 8, 3
+    theta = torch.randn(B, D, device="cuda")
+    counts = torch.zeros(A - 1, B, B, dtype=torch.long)          # [position, row, picked row]
+    reps = 400
+    for seed in range(1, reps + 1):
+        ch = torch.empty(B, A - 1, dtype=torch.int64, device="cuda")
+        atoms = torch.empty(A * B, D, device="cuda")
+        rc = lib.sbi_amd_atomic_atoms(_lib.ptr(theta), B, A, D, seed * 7919, None, _lib.ptr(ch), _lib.ptr(atoms),
+                                      _lib.current_stream(torch.device("cuda")))
+        assert rc == 0
+        c = ch.cpu()
+        own = torch.arange(B)[:, None]
+        assert ((c >= 0) & (c < B) & (c != own)).all()
+        assert all(len(set(r.tolist())) == A - 1 for r in c)
+        assert torch.equal(atoms.reshape(A, B, D)[0], theta) and torch.equal(atoms.reshape(A, B, D)[1:],
+                                                                              theta[ch].transpose(0, 1))
+        for pos in range(A - 1):
+            counts[pos, torch.arange(B), c[:, pos]] += 1
+    # every (position, row) histogram over the B - 1 other rows: expected reps / (B - 1) each
+    exp = reps / (B - 1)
+    off_diag = counts[:, ~torch.eye(B, dtype=torch.bool)].reshape(A - 1, B, B - 1).float()
+    chi2 = ((off_diag - exp) ** 2 / exp).sum(-1)                   # ~ chi-square with B - 2 = 48 degrees of freedom
+    assert chi2.mean() < 48 + 3 * (2 * 48 / (B * (A - 1))) ** 0.5 * 5 and chi2.max() < 110, (chi2.mean(), chi2.max())
+    # totals per picked row, over everything: flat
+    tot = counts.sum((0, 1)).float()
+    assert (tot / tot.mean() - 1).abs().max() < 0.08
+
+
+def test_fused_atomic_step_with_the_device_sampler_trains():
+    oracle, est, theta_d, x_d = matched_pair(D=4, C=3)
+    prior_g = MultivariateNormal(torch.zeros(4, device="cuda"), 0.1 * torch.eye(4, device="cuda"))
+    B, A = 512, 10
+    th, xx = theta_d[:B].cuda(), x_d[:B].cuda()
+    masks = torch.zeros(B, 1, device="cuda")
+    stepper = FusedTrainStep(est, distributed=False)
+    torch.manual_seed(3)
+    first = stepper.atomic_step(th, xx, masks, prior_g, A).mean().item()
+    for _ in range(30):
+        last = stepper.atomic_step(th, xx, masks, prior_g, A).mean().item()
+    assert torch.isfinite(torch.tensor(last)) and last < first
+    # same torch seed -> same contrasting sets -> same losses (the kernel's Philox key comes from torch's generator)
+    _, est2, _, _ = matched_pair(D=4, C=3)
+    st2 = FusedTrainStep(est2, distributed=False)
+    torch.manual_seed(3)
+    assert abs(st2.atomic_step(th, xx, masks, prior_g, A).mean().item() - first) < 1e-6
