@@ -759,9 +759,12 @@ __device__ __forceinline__ void precise_bin(const SplineSide<K>& S, int idx, con
 
 // forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
 // receive y and ld.
-template <int K, bool INV, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
-__device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const PL& pl, int part,
-                                               float& y, float& ld, Y&& yield = Y()) {
+// PREC = false: the plain fp32 bin (what the eager reference computes).  The TRAINING forward of the static default
+// layout runs that way: its log p only feeds the reported training loss, the backward pass recomputes the spline in
+// fp32 anyway, and the fp64 re-derivation costs ~4 % of the forward kernel.
+template <int K, bool INV, int VAR, bool PREC, class Y, class PL>
+__device__ __forceinline__ void rq_spline_pair_impl(const float* __restrict__ p, float x, const PL& pl, int part,
+                                                    float& y, float& ld, Y&& yield) {
   SplineSide<K> S;
   spline_side<K, Y, VAR>(p + part * K, pl, part, S, static_cast<Y&&>(yield));
   SplineSel o;
@@ -770,7 +773,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   float h_i = o.ch_n - o.ch_i;
   float xm = x - o.cw_i;          // distance of the input from the bin's left knot
   float ch_lo = 0.f;              // low word of the bin's bottom knot
-  if (NSF_PRECISE_SPLINE && !INV && VAR == 0) {   // (compile time: the fp32 knot selects of spline_select then fold away)
+  if (PREC && NSF_PRECISE_SPLINE && !INV && VAR == 0) {   // (compile time: the fp32 knot selects of spline_select then fold away)
     double ext, knot;
     precise_bin<K>(S, o.idx, pl, part, ext, knot);
     // part 0 holds the width side, part 1 the height side: each rounds its own three scalars, then they swap
@@ -790,7 +793,7 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   if (!INV) {
     // (the bin was found on the fp32 knots: against the re-derived knot the input can sit an ulp outside [0, 1], and
     //  in a saturated bin -- slope 1e3 between slopes 1e-3 -- that turns the derivative's numerator negative)
-    const float th = NSF_PRECISE_SPLINE ? __builtin_amdgcn_fmed3f(xm * rw_i, 0.f, 1.f) : xm * rw_i;
+    const float th = (PREC && NSF_PRECISE_SPLINE) ? __builtin_amdgcn_fmed3f(xm * rw_i, 0.f, 1.f) : xm * rw_i;
     const float tt = th * (1.f - th);
     const float num = h_i * (delta * (th * th) + o.d_i * tt);
     const float den = delta + ((o.d_i + o.d_n - 2.f * delta) * tt);
@@ -821,6 +824,11 @@ __device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, floa
   }
   y = o.inside ? yo : x;
   ld = o.inside ? lo : 0.f;
+}
+template <int K, bool INV, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
+__device__ __forceinline__ void rq_spline_pair(const float* __restrict__ p, float x, const PL& pl, int part,
+                                               float& y, float& ld, Y&& yield = Y()) {
+  rq_spline_pair_impl<K, INV, VAR, true>(p, x, pl, part, y, ld, static_cast<Y&&>(yield));
 }
 
 // ---- LULinear on the per-wave state rows (nflows transforms/lu.py) ----------

@@ -21,6 +21,9 @@
 #ifndef NSF_FLOW_PREFETCH
 #define NSF_FLOW_PREFETCH 1      // A/B: -DNSF_FLOW_PREFETCH=0 in SBI_AMD_EXTRA_HIPCC_FLAGS
 #endif
+#ifndef NSF_TRAIN_FWD_FP32_BIN
+#define NSF_TRAIN_FWD_FP32_BIN 1 // the training forward (stash + spline-parameter stash) of the static layout: fp32 bin
+#endif
 #ifndef NSF_INV_PREFETCH
 #define NSF_INV_PREFETCH 6       // float4 per thread (of 8) the 12-wave sampling kernel requests early; per-row variant: half
 #endif
@@ -51,7 +54,8 @@ static bool flow_plan_is_static(const NsfPlan& pl, const NsfPlan& st) {
 // SP = 0: layout from the kernel argument; SP = 8 / 12: the static default layout for 8- / 12-wave workgroups
 // BX: one condition row for the whole launch (x_rows == 1, no training stash): the context-only terms of every
 // transform's conditioner are folded once per workgroup (nsf_device.h, conditioner_hidden<KSH, true>)
-template <int K, int KSH, bool INV, int SP = 0, bool BX = false>
+// PREC = false: the spline's bin in plain fp32 (nsf_device.h, rq_spline_pair): the training forward of the static layout
+template <int K, int KSH, bool INV, int SP = 0, bool BX = false, bool PREC = true>
 __global__ void __launch_bounds__(INV ? 768 : 512)
 nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float* __restrict__ zstats,
                 const float* __restrict__ in, const float* __restrict__ x, long long n, long long x_rows,
@@ -213,8 +217,8 @@ nsf_flow_kernel(const NsfPlan pl_, const float* __restrict__ packed, const float
         const int dd = live ? dd_raw : c * pl.DCH;
         const int zi = id.j * pl.ZW + 2 * dd + par;
         float y, ld;
-        rq_spline_pair<K, INV>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl_, part,
-                               y, ld, yield);
+        rq_spline_pair_impl<K, INV, 0, PREC>(sc + ((c & 1) ? pl.sc_pst2 : pl.sc_pst) + sl * pl.DS + id.j * pl.PSW, zs[zi], pl_,
+                                             part, y, ld, yield);
         // every lane stores: partner / idle lanes hold the same y for the same zi (idempotent)
         zs[zi] = y;
         ld_acc += (live && part == 0) ? ld : 0.f;
@@ -321,17 +325,17 @@ static inline bool nsf_bx_applies(const NsfPlan& pl, int nw, int64_t x_rows, con
          nsf_lds_bytes(pl, nw) + nsf_bx_extra_bytes(pl) <= NSF_LDS_LIMIT_BYTES;
 }
 
-template <int K, int KSH, bool INV, int SP = 0, bool BX = false>
+template <int K, int KSH, bool INV, int SP = 0, bool BX = false, bool PREC = true>
 static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                        const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
                        float* z_stash, float* astash, float* pstash, hipStream_t stream) {
-  if constexpr (!BX) {
+  if constexpr (!BX && PREC) {
     if (nsf_bx_applies(pl, nw, x_rows, z_stash, astash))
       return launch_flow<K, KSH, INV, SP, true>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash,
                                                 astash, pstash, stream);
   }
   const int64_t lds_bytes = nsf_lds_bytes(pl, nw) + (BX ? nsf_bx_extra_bytes(pl) : 0);
-  auto kern = nsf_flow_kernel<K, KSH, INV, SP, BX>;
+  auto kern = nsf_flow_kernel<K, KSH, INV, SP, BX, PREC>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   const int64_t rows_per_wg = 16 * nw;
@@ -348,6 +352,8 @@ static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const
                            float* z_stash, float* astash, float* pstash, hipStream_t st) {
   if constexpr (K == 10) {     // the benchmark configuration: layout folded into the kernel
     if constexpr (!INV) {
+      if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8) && NSF_TRAIN_FWD_FP32_BIN && astash && pstash)
+        return launch_flow<10, 13, INV, 8, false, false>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
       if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8))
         return launch_flow<10, 13, INV, 8>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
     } else {
