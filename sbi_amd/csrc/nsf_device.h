@@ -759,9 +759,11 @@ __device__ __forceinline__ void precise_bin(const SplineSide<K>& S, int idx, con
 
 // forward returns logabsdet, inverse returns -logabsdet (as nflows does); both lanes of the pair
 // receive y and ld.
-// PREC = false: the plain fp32 bin (what the eager reference computes).  The TRAINING forward of the static default
-// layout runs that way: its log p only feeds the reported training loss, the backward pass recomputes the spline in
-// fp32 anyway, and the fp64 re-derivation costs ~4 % of the forward kernel.
+// PREC = false: the plain fp32 bin (what the eager reference computes).  The forward half of the fused training step
+// (sbi_amd_nsf_loss_fwd_bwd, static default layout) runs that way: its log p only feeds the reported training loss,
+// the backward pass recomputes the spline in fp32 anyway, and the fp64 re-derivation costs ~4 % of the forward kernel.
+// Every log_prob a caller can see -- sbi_amd_nsf_log_prob, and sbi_amd_nsf_train_forward behind `estimator.log_prob`
+// under autograd and the atomic loss -- keeps PREC = true.
 template <int K, bool INV, int VAR, bool PREC, class Y, class PL>
 __device__ __forceinline__ void rq_spline_pair_impl(const float* __restrict__ p, float x, const PL& pl, int part,
                                                     float& y, float& ld, Y&& yield) {

@@ -24,7 +24,7 @@ nsf_pack_kernel(const NsfPlan pl, const float* __restrict__ params, float* __res
 template <bool INV>
 int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* in,
                          const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                         float* z_stash, float* astash, float* pstash, void* stream) {
+                         float* z_stash, float* astash, float* pstash, void* stream, bool fp32_bin) {
   if (n == 0) return 0;
   if (!cfg || !packed || !zstats || !in || !x || !out_main || n < 0 || x_rows < 1) return SBI_AMD_E_BADARG;
   NsfPlan pl;
@@ -33,27 +33,28 @@ int dispatch_flow(const sbi_amd_nsf_config* cfg, const float* packed, const floa
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   switch (cfg->K) {
-    case 4: return launch_flow_ksh<4, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
-    case 5: return launch_flow_ksh<5, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
-    case 8: return launch_flow_ksh<8, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
-    case 10: return launch_flow_ksh<10, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
-    case 16: return launch_flow_ksh<16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
+    case 4: return launch_flow_ksh<4, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st, fp32_bin);
+    case 5: return launch_flow_ksh<5, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st, fp32_bin);
+    case 8: return launch_flow_ksh<8, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st, fp32_bin);
+    case 10: return launch_flow_ksh<10, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st, fp32_bin);
+    case 16: return launch_flow_ksh<16, INV>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st, fp32_bin);
     default: return SBI_AMD_E_UNSUPPORTED;
   }
 }
 
 
 template int dispatch_flow<false>(const sbi_amd_nsf_config*, const float*, const float*, const float*, const float*,
-                                  int64_t, int64_t, float*, float*, float*, float*, float*, void*);
+                                  int64_t, int64_t, float*, float*, float*, float*, float*, void*, bool);
 // inverse instantiations live in nsf_flow_inv.hip (separate TU: parallel build)
 extern template int dispatch_flow<true>(const sbi_amd_nsf_config*, const float*, const float*, const float*,
-                                        const float*, int64_t, int64_t, float*, float*, float*, float*, float*, void*);
+                                        const float*, int64_t, int64_t, float*, float*, float*, float*, float*, void*, bool);
 
 // used by the training path (nsf_train.hip): forward with per-layer state stash
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
-                       float* z_stash, float* astash, float* pstash, void* stream) {
-  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, astash, pstash, stream);
+                       float* z_stash, float* astash, float* pstash, void* stream, bool fp32_bin) {
+  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, z_stash, astash, pstash, stream,
+                              fp32_bin);
 }
 
 // The packed buffer holds TWO images: [throughput image: T LDS images | cooperative image: fragment-ordered, forward
@@ -109,7 +110,7 @@ extern "C" int sbi_amd_nsf_log_prob(const sbi_amd_nsf_config* cfg, const float* 
   if (coop_applies(cfg, n, false, &pl, &cp))   // small batches: four cooperating waves per 16-row tile (nsf_coop.h)
     return coop_log_prob(cfg, pl, cp, packed + nsf_packed_floats(pl), zstats, theta, x, n, x_rows, logp_out,
                          noise_out, stream);
-  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, nullptr, nullptr, stream);
+  return dispatch_flow<false>(cfg, packed, zstats, theta, x, n, x_rows, logp_out, noise_out, nullptr, nullptr, nullptr, stream, false);
 }
 
 extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
@@ -128,5 +129,5 @@ extern "C" int sbi_amd_nsf_sample(const sbi_amd_nsf_config* cfg, const float* pa
     }
     if (wide) return SBI_AMD_E_UNSUPPORTED;
   }
-  return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, nullptr, stream);
+  return dispatch_flow<true>(cfg, packed, zstats, noise, x, n, x_rows, theta_out, logabsdet_out, nullptr, nullptr, nullptr, stream, false);
 }

@@ -22,7 +22,7 @@
 #define NSF_FLOW_PREFETCH 1      // A/B: -DNSF_FLOW_PREFETCH=0 in SBI_AMD_EXTRA_HIPCC_FLAGS
 #endif
 #ifndef NSF_TRAIN_FWD_FP32_BIN
-#define NSF_TRAIN_FWD_FP32_BIN 1 // the training forward (stash + spline-parameter stash) of the static layout: fp32 bin
+#define NSF_TRAIN_FWD_FP32_BIN 1 // the forward half of sbi_amd_nsf_loss_fwd_bwd (the fused training step), static layout: fp32 bin
 #endif
 #ifndef NSF_INV_PREFETCH
 #define NSF_INV_PREFETCH 6       // float4 per thread (of 8) the 12-wave sampling kernel requests early; per-row variant: half
@@ -349,10 +349,10 @@ static int launch_flow(const NsfPlan& pl, int nw, const float* packed, const flo
 template <int K, bool INV>
 static int launch_flow_ksh(const NsfPlan& pl, int nw, const float* packed, const float* zstats, const float* in,
                            const float* x, int64_t n, int64_t x_rows, float* out_main, float* out_aux,
-                           float* z_stash, float* astash, float* pstash, hipStream_t st) {
+                           float* z_stash, float* astash, float* pstash, hipStream_t st, bool fp32_bin = false) {
   if constexpr (K == 10) {     // the benchmark configuration: layout folded into the kernel
     if constexpr (!INV) {
-      if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8) && NSF_TRAIN_FWD_FP32_BIN && astash && pstash)
+      if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8) && NSF_TRAIN_FWD_FP32_BIN && fp32_bin && astash)
         return launch_flow<10, 13, INV, 8, false, false>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);
       if (nw == 8 && flow_plan_is_static(pl, kStaticFlow8))
         return launch_flow<10, 13, INV, 8>(pl, nw, packed, zstats, in, x, n, x_rows, out_main, out_aux, z_stash, astash, pstash, st);

@@ -7,7 +7,7 @@
 
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
-                       float* z_stash, float* astash, float* pstash, void* stream);
+                       float* z_stash, float* astash, float* pstash, void* stream, bool fp32_bin);
 
 static int g_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -105,7 +105,7 @@ int nsf_g_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, cons
   if (rc) return rc;
   const GWs w = g_ws_layout(pl, gp, n);
   rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, workspace + w.logp, workspace + w.noise,
-                          workspace + w.stash, workspace + w.ast, nullptr, stream);
+                          workspace + w.stash, workspace + w.ast, nullptr, stream, false);
   if (rc) return rc;
   if (logp_out) {
     hipError_t e = hipMemcpyAsync(logp_out, workspace + w.logp, sizeof(float) * n, hipMemcpyDeviceToDevice,

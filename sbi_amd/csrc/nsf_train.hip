@@ -104,7 +104,7 @@ static bool fast_path_refuses(int rc) {
 
 int nsf_log_prob_stash(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* theta,
                        const float* x, int64_t n, int64_t x_rows, float* logp_out, float* noise_out,
-                       float* z_stash, float* astash, float* pstash, void* stream);
+                       float* z_stash, float* astash, float* pstash, void* stream, bool fp32_bin);
 
 // workgroups of nsf_grad_reduce_kernel = partial sums of squares it leaves behind the activation stash
 static inline int64_t thr_sq_parts(const NsfPlan& pl, const TrainPlan& tp) { return (int64_t)((tp.PLP / 4 + 63) / 64) * pl.T; }
@@ -178,9 +178,9 @@ static bool ws_family_mismatch(const void* ws, int fam, int64_t n) {
 }
 
 // forward half of the training pass: log p of every row + the per-transform state / activation stash
-extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
-                                         const float* theta, const float* x, int64_t n, int64_t x_rows,
-                                         float* logp_out, float* workspace, void* stream) {
+static int train_forward_impl(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
+                              const float* theta, const float* x, int64_t n, int64_t x_rows, float* logp_out,
+                              float* workspace, void* stream, bool fp32_bin) {
   if (!cfg || !packed || !zstats || !theta || !x || !workspace || n < 1 || x_rows < 1) return SBI_AMD_E_BADARG;
   NsfPlan pl;
   {
@@ -207,7 +207,7 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
   int64_t o_stash, o_noise, o_logp, o_gza, o_gzb, o_part, o_ast, o_pst;
   ws_layout(pl, tp, n, &o_stash, &o_noise, &o_logp, &o_gza, &o_gzb, &o_part, &o_ast, &o_pst);
   rc = nsf_log_prob_stash(cfg, packed, zstats, theta, x, n, x_rows, workspace + o_logp, workspace + o_noise,
-                          workspace + o_stash, workspace + o_ast, TR_PSTASH ? workspace + o_pst : nullptr, stream);
+                          workspace + o_stash, workspace + o_ast, TR_PSTASH ? workspace + o_pst : nullptr, stream, fp32_bin);
   if (rc) return rc;
   if (logp_out) {
     hipError_t e = hipMemcpyAsync(logp_out, workspace + o_logp, sizeof(float) * n, hipMemcpyDeviceToDevice,
@@ -215,6 +215,12 @@ extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const fl
     if (e != hipSuccess) return (int)e;
   }
   return 0;
+}
+
+extern "C" int sbi_amd_nsf_train_forward(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
+                                         const float* theta, const float* x, int64_t n, int64_t x_rows,
+                                         float* logp_out, float* workspace, void* stream) {
+  return train_forward_impl(cfg, packed, zstats, theta, x, n, x_rows, logp_out, workspace, stream, false);
 }
 
 // backward half; loss_out (optional) = -log p of the stash's forward pass, written by the reduction kernel
@@ -319,7 +325,8 @@ extern "C" int sbi_amd_nsf_loss_fwd_bwd(const sbi_amd_nsf_config* cfg, const flo
                                         float* workspace, void* stream) {
   if (!cfg || !params || !packed || !zstats || !theta || !x || !grad_out || !workspace || n < 1 || x_rows < 1)
     return SBI_AMD_E_BADARG;
-  int rc = sbi_amd_nsf_train_forward(cfg, packed, zstats, theta, x, n, x_rows, nullptr, workspace, stream);
+  // (the fused step's forward: its log p is the reported training loss only -- plain fp32 bin, nsf_device.h)
+  int rc = train_forward_impl(cfg, packed, zstats, theta, x, n, x_rows, nullptr, workspace, stream, true);
   if (rc) return rc;
   return train_backward_impl(cfg, params, packed, zstats, x, n, x_rows, row_weight, uniform_weight, grad_out,
                              grad_theta_out, grad_x_out, workspace, loss_out, stream);
