@@ -284,6 +284,21 @@ int sbi_amd_mcmc_slice_tick(int32_t num_chains, int32_t dim, int32_t num_samples
                             uint64_t seed, uint64_t tick_no, int32_t kind, const float* p0, const float* p1,
                             float* theta_next, float* logabsdet_next, void* stream);
 
+/* The PERSISTENT form of the same loop: `nticks` ticks of all chains in ONE launch.  A workgroup of the cooperative
+ * forward kernel owns 16 chains and alternates the log-density of their next evaluation points (one x_o: x_o is the
+ * embedded, not yet standardized condition row, C floats) with the tick of their state machines; chains never interact,
+ * so nothing is exchanged between workgroups and nothing returns to the host in between.  Requirements: a configuration
+ * the cooperative kernels take (theta-dim 2 ... 16, hidden <= 64); `packed` holds the cooperative image
+ * (sbi_amd_nsf_pack_images bit 2); theta_next (num_chains, dim) holds the constrained image of next_param on entry (and
+ * on exit), logabsdet_next (num_chains) its log|det|; logp_scratch: num_chains floats; uniforms always in-kernel
+ * (Philox: seed, tick0 + tick).  Poll *done_count between launches. */
+int sbi_amd_mcmc_slice_run(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats, const float* x_o,
+                           int32_t num_chains, int32_t num_samples, int32_t tuning, float max_width, float* x,
+                           float* next_param, float* width, int32_t* order, int32_t* istate, float* fstate,
+                           float* samples, int32_t* done_count, uint64_t seed, uint64_t tick0, int32_t nticks,
+                           int32_t kind, const float* p0, const float* p1, float* theta_next, float* logabsdet_next,
+                           float* logp_scratch, void* stream);
+
 /* Unconstrained -> constrained parameters for the transforms of mcmc_transform (sbi/utils/sbiutils.py:867-980)
  * and the log|det| term of transformed_potential (sbi/utils/potentialutils.py:15-51) in one launch:
  * kind 0 identity; kind 1 theta = p0 + p1 * u (z-scoring with the prior's mean p0 / std p1);

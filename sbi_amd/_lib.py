@@ -116,6 +116,12 @@ _SIGNATURES = {
     "sbi_amd_rccl_comm_init": (c_int, [POINTER(c_void_p), c_int32, c_int32, c_void_p]),
     "sbi_amd_rccl_comm_destroy": (c_int, [c_void_p]),
     "sbi_amd_allreduce_flat": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "sbi_amd_mcmc_slice_run": (
+        c_int,
+        [POINTER(NSFConfigC), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int32, c_int32, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "sbi_amd_atomic_atoms": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sbi_amd_atomic_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                        c_void_p]),

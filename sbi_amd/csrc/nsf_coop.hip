@@ -127,6 +127,37 @@ int coop_log_prob(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPl
   return co_dispatch_fwd(cfg, pl, cp, a, (hipStream_t)stream);
 }
 
+// `nticks` ticks of the vectorised slice sampler for all chains in ONE launch (nsf_coop_kernel.h, MC = true).
+// theta_next must hold the constrained image of next_param on entry (sbi_amd_mcmc_to_constrained) and does on exit.
+extern "C" int sbi_amd_mcmc_slice_run(const sbi_amd_nsf_config* cfg, const float* packed, const float* zstats,
+                                      const float* x_o, int32_t num_chains, int32_t num_samples, int32_t tuning,
+                                      float max_width, float* x, float* next_param, float* width, int32_t* order,
+                                      int32_t* istate, float* fstate, float* samples, int32_t* done_count, uint64_t seed,
+                                      uint64_t tick0, int32_t nticks, int32_t kind, const float* p0, const float* p1,
+                                      float* theta_next, float* logabsdet_next, float* logp_scratch, void* stream) {
+  if (!cfg || !packed || !zstats || !x_o || num_chains < 1 || num_samples < 0 || tuning < 0 || nticks < 0 || !x ||
+      !next_param || !width || !order || !istate || !fstate || !samples || !done_count || !theta_next ||
+      !logabsdet_next || !logp_scratch || kind < 0 || kind > 2 || (kind && (!p0 || !p1)))
+    return SBI_AMD_E_BADARG;
+  if (nticks == 0) return 0;
+  NsfPlan pl;
+  CoopPlan cp;
+  int rc = nsf_build_plan(cfg, 1, &pl);
+  if (rc && rc != SBI_AMD_E_LDS) return rc;
+  if (pl.H > 16 * NSF_HT) return SBI_AMD_E_UNSUPPORTED;            // (the wide kernels have no sampler mode)
+  rc = coop_build_plan(pl, num_chains, 1, false, &cp);
+  if (rc) return rc;
+  McArgs mc{};
+  mc.num_samples = num_samples; mc.tuning = tuning; mc.nticks = nticks; mc.kind = kind; mc.max_width = max_width;
+  mc.seed = seed; mc.tick0 = tick0; mc.p0 = p0; mc.p1 = p1;
+  mc.x = x; mc.next_param = next_param; mc.width = width; mc.fstate = fstate; mc.samples = samples;
+  mc.theta_next = theta_next; mc.lad_next = logabsdet_next; mc.logp_buf = logp_scratch;
+  mc.order = order; mc.istate = istate; mc.done_count = done_count;
+  CoFwdArgs a = {packed + nsf_packed_floats(pl), zstats, theta_next, x_o, (long long)num_chains, 1, logp_scratch, nullptr,
+                 nullptr, nullptr, nullptr, &mc};
+  return co_dispatch_fwd(cfg, pl, cp, a, (hipStream_t)stream);
+}
+
 int coop_train_forward(const sbi_amd_nsf_config* cfg, const NsfPlan& pl, const CoopPlan& cp, const float* cimg,
                        const float* zstats, const float* theta, const float* x, int64_t n, int64_t x_rows,
                        float* logp_out, float* workspace, void* stream) {

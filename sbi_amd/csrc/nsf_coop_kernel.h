@@ -7,6 +7,7 @@
 //                             weight-gradient slabs (tile order, nsf_coop_reduce_kernel sums them)
 #include <hip/hip_runtime.h>
 #include "nsf_coop.h"
+#include "mcmc_tick.h"
 #include "nsf_device.h"
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -375,12 +376,26 @@ __device__ __forceinline__ void co_gemm_ctx(const f4 (&a)[2], int kcq, const flo
     }
 }
 
-template <int K, int KSH, int NT, bool LEAN>
+// MC = true: the PERSISTENT slice sampler (sbi_amd_mcmc_slice_run).  A workgroup owns 16 chains for the whole launch
+// and alternates, `nticks` times, the log-density of the chains' next evaluation points (this forward pass, one x_o)
+// with one tick of their state machines (mcmc_tick.h, run by the 16 threads that hold the rows' log-densities) --
+// chains never interact, so there is no rendezvous between workgroups and no launch per tick.  The reference runs
+// the same loop in Python around batched potential calls (sbi/samplers/mcmc/slice_numpy.py:353-587).
+struct McArgs {
+  int num_samples, tuning, nticks, kind;
+  float max_width;
+  unsigned long long seed, tick0;
+  const float *p0, *p1;                       // the constrained map's parameters (sbi_amd_mcmc_to_constrained)
+  float *x, *next_param, *width, *fstate, *samples, *theta_next, *lad_next, *logp_buf;
+  int *order, *istate, *done_count;
+};
+template <int K, int KSH, int NT, bool LEAN, bool MC = false>
 __global__ void __launch_bounds__(64 * CO_WAVES, LEAN ? 2 : 1)
 nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __restrict__ zstats,
                     const float* __restrict__ theta, const float* __restrict__ x, long long n, long long x_rows,
                     float* __restrict__ logp, float* __restrict__ noise_out, float* __restrict__ zst,
-                    float* __restrict__ ast, long long* __restrict__ dbg) {
+                    float* __restrict__ ast, long long* __restrict__ dbg, const McArgs mc) {
+  static_assert(!MC || (NT == 1 && !LEAN), "the persistent sampler runs one-tile workgroups");
   // debug timeline (SBI_AMD_TIMELINE): cycle stamps of workgroup 0's waves while they walk transform 1
 #ifdef NSF_DEBUG
 #define TSC(i) do { if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 1) \
@@ -439,17 +454,23 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
     }
   }
   __syncthreads();
+  __shared__ float mc_theta[MC ? 16 * 16 : 1];      // MC: the chains' next evaluation points (constrained space)
+  float ld_acc[NT];
+  float ld_const0 = 0.f;
+  for (int d = 0; d < D; ++d) ld_const0 += logf(fabsf(th_scale[d]));
+  float ld_const = ld_const0;
+  int buf = 0;
+  const int nticks = MC ? mc.nticks : 1;
+  for (int tick = 0; tick < nticks; ++tick) {
   for (int i = tid; i < R * D; i += 64 * CO_WAVES) {
     const int r = i / D, d = i - r * D;
     const long long row = row0 + r;
-    zs[r * ZS + d] = row < n ? theta[row * D + d] * th_scale[d] + th_shift[d] : 0.f;
+    const float th = (MC && tick > 0) ? mc_theta[r * 16 + d] : (row < n ? theta[row * D + d] : 0.f);
+    zs[r * ZS + d] = row < n ? th * th_scale[d] + th_shift[d] : 0.f;
   }
-  float ld_acc[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) ld_acc[u] = 0.f;
-  float ld_const = 0.f;
-  for (int d = 0; d < D; ++d) ld_const += logf(fabsf(th_scale[d]));
-  int buf = 0;
+  ld_const = ld_const0;
   // stash addresses of this wave's fragments: slot s of transform t, row tile u is (abase[u] + t * astride + s * 256)
   float* abase[NT];
   const long long astride = nt16 * k.slots * 256;
@@ -603,7 +624,7 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
     const f4 blu = co_load_bias(img + kp.blu, 0, id.g);
     const float ld_lu = img[kp.ld];
     {
-      const int tn = t + 1 < k.T ? t + 1 : t;           // (the last transform re-requests itself: harmless)
+      const int tn = t + 1 < k.T ? t + 1 : (MC ? 0 : t);   // (last transform: re-requests itself, harmless; MC: the next tick's first)
       const float* imgn = cimg + (long long)tn * k.img_floats;
       const CoKP& kn = k.p[tn & 1];
       co_load_w0(imgn, k, kn, wave, id, w0);
@@ -692,9 +713,21 @@ nsf_coop_fwd_kernel(const CoK k, const float* __restrict__ cimg, const float* __
         ss += z * z;
         if (noise_out) noise_out[row * D + d] = z;
       }
-      logp[row] = -0.5f * ss + ld + ld_const - k.log_z;
+      const float lp = -0.5f * ss + ld + ld_const - k.log_z;
+      if constexpr (MC) {
+        // this thread holds chain `row`'s log-density: advance its state machine and publish the next evaluation point
+        mc.logp_buf[row] = lp;
+        slice_tick_one((int)row, D, mc.num_samples, mc.tuning, mc.max_width, mc.logp_buf, mc.lad_next, nullptr, mc.x,
+                       mc.next_param, mc.width, mc.order, mc.istate, mc.fstate, mc.samples, mc.done_count, mc.seed,
+                       mc.tick0 + (unsigned long long)tick, mc.kind, mc.p0, mc.p1, mc.theta_next, mc.lad_next);
+        for (int d = 0; d < D; ++d) mc_theta[tid * 16 + d] = mc.theta_next[row * D + d];
+      } else {
+        logp[row] = lp;
+      }
     }
   }
+  if constexpr (MC) __syncthreads();
+  }   // ticks
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -1241,6 +1274,7 @@ struct CoFwdArgs {
   long long n, x_rows;
   float *logp, *noise, *zst, *ast;
   long long* dbg;
+  const McArgs* mc;      // non-null: the persistent slice sampler (theta = the chains' next evaluation points)
 };
 struct CoBwdArgs {
   const float *cimg, *zstats, *x;
@@ -1252,14 +1286,14 @@ struct CoBwdArgs {
   long long* dbg;
 };
 
-template <int K, int KSH, int NT, bool LEAN>
+template <int K, int KSH, int NT, bool LEAN, bool MC = false>
 static int co_launch_fwd(const CoK& k, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
-  auto kern = nsf_coop_fwd_kernel<K, KSH, NT, LEAN>;
+  auto kern = nsf_coop_fwd_kernel<K, KSH, NT, LEAN, MC>;
   const int lds_bytes = 4 * cp.lds_floats;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(cp.grid), dim3(64 * CO_WAVES), (size_t)lds_bytes, st, k, a.cimg, a.zstats, a.theta, a.x,
-                     a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast, a.dbg);
+                     a.n, a.x_rows, a.logp, a.noise, a.zst, a.ast, a.dbg, (MC && a.mc) ? *a.mc : McArgs{});
   return (int)hipGetLastError();
 }
 template <int K, int KSH, int NT>

@@ -754,6 +754,16 @@ static int cow_launch_bwd(const CoK& k, const CoopPlan& cp, const CoBwdArgs& a, 
 template <int K>
 int co_fwd_k(const NsfPlan& pl, const CoopPlan& cp, const CoFwdArgs& a, hipStream_t st) {
   CoK k;
+  if (a.mc) {      // persistent slice sampler: one-tile workgroups (16 chains each), whatever the chain count
+    if (cp.MT == 2) return SBI_AMD_E_UNSUPPORTED;
+    CoopPlan cf = cp;
+    if (cp.NT != 1) {
+      int rc = coop_build_plan(pl, a.n, 1, false, &cf);
+      if (rc) return rc;
+    }
+    coop_make_consts(pl, cf, &k);
+    return pl.KSH == 13 ? co_launch_fwd<K, 13, 1, false, true>(k, cf, a, st) : co_launch_fwd<K, 16, 1, false, true>(k, cf, a, st);
+  }
   if (cp.MT == 2) {       // hidden > 64: the wide kernel, always one tile per workgroup (the backward pass may take two)
     CoopPlan cf = cp;
     if (cp.NT != 1) {

@@ -248,7 +248,7 @@ class MCMCPosterior:
             return est._kernel_log_prob(theta, x_row, False)[0]
 
         # the slice sampler's tick kernel applies the transform itself (sbi_amd_mcmc_slice_tick): two launches per tick
-        potential_.fused_spec = (kind, p0, p1, log_q)
+        potential_.fused_spec = (kind, p0, p1, log_q, net, x_row)
         return potential_
 
     def _get_initial_params(self, init_strategy: str, num_chains: int, **kwargs) -> Tensor:

@@ -60,7 +60,7 @@ class SliceSamplerVectorized:
             # also draws its uniforms (Philox keyed by a seed from torch's generator) and maps the NEXT evaluation point
             # to constrained space.  (The reference's sampler draws from NumPy's global generator,
             # slice_numpy.py:353-587: a distribution to match, not a stream.)
-            kind, p0, p1, log_q = fused
+            kind, p0, p1, log_q, net, x_row = fused
             seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
             theta = torch.empty_like(nxt)
             lad = torch.empty(C, dtype=torch.float32, device=dev)
@@ -68,7 +68,32 @@ class SliceSamplerVectorized:
                 rc = lib.sbi_amd_mcmc_to_constrained(kind, C, D, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(nxt), _lib.ptr(theta),
                                                      _lib.ptr(lad), _lib.current_stream(dev))
             _lib.check(rc, "mcmc_to_constrained")
-            while True:
+            # Persistent form first: `poll_every` ticks of every chain per launch (a workgroup owns 16 chains and
+            # alternates their log-density with their tick; sbi_amd_mcmc_slice_run).  Configurations the cooperative
+            # kernels do not take fall back to two launches per tick.
+            persistent = bool(getattr(self, "persistent", True))
+            if persistent:
+                from sbi_amd.neural_nets.estimators.nsf_flow import packed_weights
+
+                packed = packed_weights(net, rows=None)
+                cfg = net.hyper.c_config()
+                scratch = torch.empty(C, dtype=torch.float32, device=dev)
+            while persistent:
+                with torch.cuda.device(dev):
+                    rc = lib.sbi_amd_mcmc_slice_run(cfg, _lib.ptr(packed), _lib.ptr(net.zstats), _lib.ptr(x_row), C,
+                                                    int(num_samples), self.tuning, max_width, _lib.ptr(x), _lib.ptr(nxt),
+                                                    _lib.ptr(width), _lib.ptr(order), _lib.ptr(istate), _lib.ptr(fstate),
+                                                    _lib.ptr(samples), _lib.ptr(done), seed, tick, self.poll_every, kind,
+                                                    _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(theta), _lib.ptr(lad),
+                                                    _lib.ptr(scratch), _lib.current_stream(dev))
+                if rc == _lib.E_UNSUPPORTED and tick == 0:
+                    persistent = False
+                    break
+                _lib.check(rc, "mcmc_slice_run")
+                tick += self.poll_every
+                if int(done.item()) == C:
+                    break
+            while not persistent:
                 logp = log_q(theta)
                 with torch.cuda.device(dev):
                     rc = lib.sbi_amd_mcmc_slice_tick(C, D, int(num_samples), self.tuning, max_width, _lib.ptr(logp),

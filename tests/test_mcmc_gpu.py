@@ -185,3 +185,36 @@ def test_tick_kernel_matches_tensorised_restatement_bit_for_bit():
     assert int(done.item()) == C and bool((st["state"] == 4).all())
     assert torch.equal(samples, st["samples"]) and torch.equal(width, st["width"])
     assert torch.equal(order.long(), st["order"])
+
+
+def test_persistent_sampler_equals_the_two_launch_loop():
+    """sbi_amd_mcmc_slice_run (one launch per `poll_every` ticks, a workgroup owns 16 chains) against the loop of
+    log_prob + tick launches: same Philox counters, same log-density kernel -> the same chains, bit for bit."""
+    from torch.distributions import MultivariateNormal
+
+    from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
+    from sbi_amd.inference.potentials.posterior_based_potential import posterior_estimator_based_potential
+    from sbi_amd.samplers.mcmc import SliceSamplerVectorized
+    from sbi_amd.utils.sbiutils import mcmc_transform
+    from tests.helpers import matched_pair
+
+    _, est, _, x = matched_pair(D=4, C=3)
+    prior = MultivariateNormal(torch.zeros(4, device="cuda"), torch.eye(4, device="cuda"))
+    potential_fn, _ = posterior_estimator_based_potential(est, prior, x_o=None)
+    tf = mcmc_transform(prior, device="cuda")
+    post = MCMCPosterior(potential_fn, prior, tf, num_chains=100, thin=1, warmup_steps=3, device="cuda")
+    x_o = x[:1].cuda()
+    post.set_default_x(x_o)
+    post.potential_fn.set_x(x_o, x_is_iid=True)
+    fused = post._fused_potential()
+    assert fused is not None and len(fused.fused_spec) == 6
+    init = torch.randn(100, 4, device="cuda") * 0.3
+    outs = []
+    for persistent in (True, False):
+        torch.manual_seed(11)
+        s = SliceSamplerVectorized(fused, init.clone(), num_chains=100, thin=1, tuning=10, poll_every=16)
+        s.persistent = persistent
+        outs.append((s.run(12).clone(), s.num_ticks))
+    assert outs[0][1] >= outs[1][1] and outs[0][1] - outs[1][1] < 16
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.isfinite(outs[0][0]).all() and outs[0][0].std() > 0.05
