@@ -489,8 +489,8 @@ def fmpe_leg(args, B, rank, world, device, dist, distributed, global_batch):
 
 def mcmc_leg(est, x, device, with_cpu=False):
     """MCMCPosterior (slice_np_vectorized on the device, sbi/samplers/mcmc/slice_numpy.py:353-587) over the
-    NSF potential, one x_o: every tick of every chain's state machine is one launch of `slice_tick_kernel` around one
-    batched log_prob call (x_rows == 1: the broadcast-x kernels)."""
+    NSF potential, one x_o: the persistent sampler kernel (sbi_amd_mcmc_slice_run) runs 64 ticks of every chain per launch
+    -- a workgroup owns 16 chains and alternates their log-density (cooperative forward pass) with their tick."""
     from torch.distributions import Independent, Normal
 
     from sbi_amd.inference.posteriors.mcmc_posterior import MCMCPosterior
