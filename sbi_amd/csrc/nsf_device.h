@@ -298,13 +298,14 @@ __device__ __forceinline__ float rcp_nr(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(r, fmaf(-x, r, 1.f), r);
 }
+// exp(x) = 2^t * exp(x - t ln 2) with t = fl(x log2 e): the residual x - t ln 2 (|.| <= |t| 2^-24) is what the rounding
+// of t loses; ln 2 = hi + lo keeps it to a few 1e-9 relative.  exp2, three FMAs and a multiply.
 __device__ __forceinline__ float exp_f(float x) {
-  const float L2E = 1.4426950408889634f, L2E_LO = 1.9259629911e-8f;   // log2(e) = hi + lo
-  const float t = x * L2E;
-  float tl = fmaf(x, L2E, -t);
-  tl = fmaf(x, L2E_LO, tl);
+  const float t = x * 1.4426950408889634f;
+  float r = fmaf(-t, 0.693147182464599609375f, x);      // ln 2 = hi + lo
+  r = fmaf(-t, -1.90465429995776804525e-9f, r);
   const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, tl * 0.6931471805599453f, e);
+  return fmaf(e, r, e);
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return rcp_f(1.0f + exp_f(-x)); }
 // the residual blocks' GLU gate: 32 of these per lane and transform.  Without the two-float argument product the
@@ -586,12 +587,27 @@ __device__ __forceinline__ float xchg32(float x) {   // value held by lane ^ 32
   return __uint_as_float((threadIdx.x & 32) ? r.x : r.y);
 }
 __device__ __forceinline__ int xchg32i(int x) { return __float_as_int(xchg32(__int_as_float(x))); }
+// the values the pair's part-0 lane (lanes 0-31) and part-1 lane (32-63) hold, in BOTH lanes: one swap, no select
+__device__ __forceinline__ void pair_both(float x, float& from0, float& from1) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const unsigned u = __float_as_uint(x);
+  const u2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  from0 = __uint_as_float(r.x);
+  from1 = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void pair_both_i(int x, int& from0, int& from1) {
+  float a, b;
+  pair_both(__int_as_float(x), a, b);
+  from0 = __float_as_int(a);
+  from1 = __float_as_int(b);
+}
 
 template <int K>
 struct SplineSide {
-  float e[K];       // exp(logit - max); softmax probabilities after normalise()
+  float e[K];       // exp(logit - max): the softmax numerators
   float inv_s;      // 1 / sum(e)
   float c[K + 1];   // knots of this side in [-B, B]
+  float n2, a;      // size of bin k on [-B, B]: e[k] * n2 + a   (n2 = 2B (1 - K min) / sum(e), a = 2B min)
 };
 
 // "Yield points": a VALU-heavy routine calls y() between small groups of instructions; the functor
@@ -625,34 +641,79 @@ __device__ __forceinline__ float spline_logit_grad(float q, const PL& pl) {
   return r * r;
 }
 
+// NSF_SOFTMAX_EXP: how the K softmax numerators of a side are taken (nflows parametrisation).  1 (default): exp2 of ONE
+// fma -- the logit scale 1/sqrt(hidden), the max subtraction and log2(e) folded into it: two instructions per logit
+// instead of six.  The exponent then carries its own rounding, <= |t| 1.2e-7 relative on a numerator, which a bin of
+// softmax mass p turns into <= p |ln p| / (p + min_bin) of that on the bin's size (<= 2.6e-7 at min_bin = 1e-3).
+// 0: the compensated exp_f (1 ulp).  Same-box A/B (profiles/r6h_spline_ab.txt, 16 384 rows against the oracle in fp64):
+// log_prob rms 2.595e-6 / max 1.65e-5 with 1, 2.603e-6 / 1.62e-5 with 0 (eager fp32 reference: 6.2e-6 / 4.5e-5);
+// log_prob -1.9 %, 10^6 draws -2.6 %.  (A/B: SBI_AMD_EXTRA_HIPCC_FLAGS=-DNSF_SOFTMAX_EXP=0 rebuilds the library.)
+#ifndef NSF_SOFTMAX_EXP
+#define NSF_SOFTMAX_EXP 1
+#endif
 template <int K, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
 __device__ __forceinline__ void spline_side(const float* __restrict__ q, const PL& pl, int part,
                                             SplineSide<K>& S, Y&& y = Y()) {
   const float B = pl.B;
-  float m = -INFINITY;
+  if (VAR == 0) {
+    // nflows: `unnormalized_widths /= sqrt(hidden_features)` (coupling.py), then softmax: the scale is positive, so the
+    // max is taken on the raw logits and scale + shift are one fma per logit (softmax is shift-invariant: the shift
+    // needs no particular rounding)
+    float m = q[0];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    S.e[k] = spline_logit<VAR>(q[k], pl);   // nflows: `unnormalized_widths /= sqrt(hidden_features)` (coupling.py)
-    m = fmaxf(m, S.e[k]);
-    y(k);
-  }
-  float s = 0.f;
+    for (int k = 1; k < K; ++k) {
+      m = fmaxf(m, q[k]);
+      y(k - 1);
+    }
+    y(K - 1);
+    if (NSF_SOFTMAX_EXP == 1) {
+      const float sc = pl.inv_sqrt_h * 1.4426950408889634f;
+      const float nms = -m * sc;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    S.e[k] = exp_f(S.e[k] - m);
-    s += S.e[k];
-    y(K + k);
+      for (int k = 0; k < K; ++k) {
+        S.e[k] = __builtin_amdgcn_exp2f(fmaf(q[k], sc, nms));
+        y(K + k);
+      }
+    } else {
+      const float sc = pl.inv_sqrt_h;
+      const float nms = -m * sc;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        S.e[k] = exp_f(fmaf(q[k], sc, nms));
+        y(K + k);
+      }
+    }
+  } else {
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      S.e[k] = spline_logit<VAR>(q[k], pl);
+      m = fmaxf(m, S.e[k]);
+      y(k);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      S.e[k] = exp_f(S.e[k] - m);
+      y(K + k);
+    }
   }
-  S.inv_s = rcp_nr(s);
-  const float n_ = (part ? pl.one_minus_kh : pl.one_minus_kw) * S.inv_s;
-  const float mn = part ? pl.min_h : pl.min_w;
-  // knots: cumsum -> pad -> affine to [-B,B] -> overwrite ends
-  float cum = 0.f;
+  // knots: knot_{k+1} = -B + 2B ((k+1) min + (1 - K min) P_k / s), P_k the running sum of the numerators (its last
+  // element is the softmax denominator): one add and two FMAs per knot.  nflows reaches the same numbers as cumsum of
+  // the normalised, padded sizes followed by the affine map (one more rounding per knot); the end knots are overwritten.
+  float a = (2.f * B) * (part ? pl.min_h : pl.min_w);
+  asm volatile("" : "+v"(a));      // (the K knot offsets below are loop invariants: hoisted, they would pin K registers)
+  float P[K];
+  P[0] = S.e[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) P[k] = P[k - 1] + S.e[k];
+  S.inv_s = rcp_nr(P[K - 1]);
+  const float n2 = ((2.f * B) * (part ? pl.one_minus_kh : pl.one_minus_kw)) * S.inv_s;
+  S.n2 = n2;
+  S.a = a;
   S.c[0] = -B;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    cum += fmaf(S.e[k], n_, mn);
-    S.c[k + 1] = (2.f * B) * cum + (-B);
+    S.c[k + 1] = fmaf(P[k], n2, fmaf((float)(k + 1), a, -B));
     y(2 * K + k);
   }
   if (VAR == 0) S.c[K] = B;   // nflows overwrites the end knots; zuko keeps B (2 cumsum - 1)
@@ -661,7 +722,9 @@ __device__ __forceinline__ void spline_side(const float* __restrict__ q, const P
 struct SplineSel {   // per-task scalars both lanes hold after the exchange
   int idx;
   bool inside;
-  float cw_i, cw_n, ch_i, ch_n, d_i, d_n, ud_mine;
+  float cw_i, ch_i;     // the bin's left knots
+  float w_i, h_i;       // the bin's width and height
+  float d_i, d_n, ud_mine;
 };
 
 template <int K, bool INV, class Y = NoYield, int VAR = 0, class PL = NsfPlan>
@@ -671,51 +734,67 @@ __device__ __forceinline__ void spline_select(const float* __restrict__ p, float
   // searchsorted (torchutils.py:449-463): sum(x >= knots) - 1, last knot + 1e-6; done by the
   // side that owns the searched knots (widths forward, heights inverse).
   // zuko: torch.searchsorted(knots, x) - 1 = #(knots < x) - 1, transformed iff 0 <= bin < K.
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    cnt += (VAR == 0 ? (x >= S.c[k]) : (x > S.c[k])) ? 1 : 0;
-    y(3 * K + k);
-  }
-  cnt += (VAR == 0 ? (x >= (S.c[K] + 1e-6f)) : (x > S.c[K])) ? 1 : 0;
-  int idx = cnt - 1;
+  int idx;
   if (VAR == 0) {
+    // the clamp to [0, K - 1] that follows the count makes the end knots' comparisons redundant: x < -B and x > B + 1e-6
+    // land in bins 0 and K - 1 either way (and are mapped by the identity, below)
+    idx = 0;
+    y(3 * K);
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      idx += (x >= S.c[k]) ? 1 : 0;
+      y(3 * K + k);
+    }
     o.inside = (x >= -B) && (x <= B);
   } else {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      cnt += (x > S.c[k]) ? 1 : 0;
+      y(3 * K + k);
+    }
+    cnt += (x > S.c[K]) ? 1 : 0;
+    idx = cnt - 1;
     // the side that searched decides (both sides see the same x but own different knots)
     const int in_mine = (idx >= 0 && idx <= K - 1) ? 1 : 0;
-    const int in_oth = xchg32i(in_mine);
-    o.inside = ((part == (INV ? 1 : 0)) ? in_mine : in_oth) != 0;
+    int in0, in1;
+    pair_both_i(in_mine, in0, in1);
+    o.inside = (INV ? in1 : in0) != 0;
+    idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
   }
-  idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
-  const int idx_o = xchg32i(idx);
-  idx = (part == (INV ? 1 : 0)) ? idx : idx_o;
-  float c_i = S.c[0], c_n = S.c[1];
+  {
+    int i0, i1;
+    pair_both_i(idx, i0, i1);
+    idx = INV ? i1 : i0;             // the searching side's bin, in both lanes
+  }
+  // the bin's left knot and its size.  The size is taken from the bin's own softmax numerator, e n2 + a (relative
+  // error ~1e-7 however narrow the bin), not as the difference of two rounded knots as the eager reference does
+  // (relative error ulp(knot) / size: 4e-5 for a bin of the minimum size) -- except in the last bin, whose right knot
+  // nflows overwrites with B
+  float c_i = S.c[0], e_i = S.e[0];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     const bool hit = (idx == k);
     c_i = hit ? S.c[k] : c_i;
-    c_n = hit ? S.c[k + 1] : c_n;
+    e_i = hit ? S.e[k] : e_i;
     y(4 * K + k - 1);
   }
-  const float o_i = xchg32(c_i), o_n = xchg32(c_n);
+  float sz = fmaf(e_i, S.n2, S.a);
+  if (VAR == 0) sz = (idx == K - 1) ? B - c_i : sz;
   o.idx = idx;
-  o.cw_i = part ? o_i : c_i;
-  o.cw_n = part ? o_n : c_n;
-  o.ch_i = part ? c_i : o_i;
-  o.ch_n = part ? c_n : o_n;
+  pair_both(c_i, o.cw_i, o.ch_i);    // part 0 owns the width knots, part 1 the height knots
+  pair_both(sz, o.w_i, o.h_i);
   // derivatives: part 0 evaluates knot idx, part 1 knot idx+1; boundary knots use the constant
   const int kd = idx + part;
-  const int kc = kd - 1 < 0 ? 0 : (kd - 1 > K - 2 ? K - 2 : kd - 1);   // always a valid slot: no branch
-  const float ud_ld = p[2 * K + kc];
-  o.ud_mine = (kd == 0 || kd == K) ? (VAR == 0 ? pl.d_const : 0.f) : ud_ld;
+  const int kc = kd - 1 < 0 ? 0 : (kd - 1 > K - 2 ? K - 2 : kd - 1);   // always a valid slot
+  float ud_ld = p[2 * K + kc];
+  asm volatile("" : "+v"(ud_ld));    // (keeps the read unconditional: the compiler otherwise branches around it)
+  o.ud_mine = ((unsigned)(kd - 1) >= (unsigned)(K - 1)) ? (VAR == 0 ? pl.d_const : 0.f) : ud_ld;
   y(5 * K - 1);
   const float d_mine = VAR == 0 ? pl.min_d + softplus_bf(o.ud_mine)
                                 : exp_f(o.ud_mine * rcp_f(1.f + fabsf(o.ud_mine) * ZUKO_CD));   // boundary: exp(0) = 1
   y(5 * K);
-  const float d_oth = xchg32(d_mine);
-  o.d_i = part ? d_oth : d_mine;
-  o.d_n = part ? d_mine : d_oth;
+  pair_both(d_mine, o.d_i, o.d_n);
 }
 
 // ---- the selected bin re-derived beyond fp32 (density direction, nflows parametrisation) ----------------------------
@@ -771,8 +850,8 @@ __device__ __forceinline__ void rq_spline_pair_impl(const float* __restrict__ p,
   spline_side<K, Y, VAR>(p + part * K, pl, part, S, static_cast<Y&&>(yield));
   SplineSel o;
   spline_select<K, INV, Y, VAR>(p, x, pl, part, S, o, static_cast<Y&&>(yield));
-  float w_i = o.cw_n - o.cw_i;
-  float h_i = o.ch_n - o.ch_i;
+  float w_i = o.w_i;
+  float h_i = o.h_i;
   float xm = x - o.cw_i;          // distance of the input from the bin's left knot
   float ch_lo = 0.f;              // low word of the bin's bottom knot
   if (PREC && NSF_PRECISE_SPLINE && !INV && VAR == 0) {   // (compile time: the fp32 knot selects of spline_select then fold away)
@@ -782,12 +861,10 @@ __device__ __forceinline__ void rq_spline_pair_impl(const float* __restrict__ p,
     const float ext_f = (float)ext;
     const float a_f = part ? (float)knot : (float)((double)x - knot);          // heights: knot (hi) | widths: x - knot
     const float b_f = part ? (float)(knot - (double)(float)knot) : 0.f;        // heights: knot (lo)
-    const float ext_o = xchg32(ext_f), a_o = xchg32(a_f), b_o = xchg32(b_f);
-    w_i = part ? ext_o : ext_f;
-    h_i = part ? ext_f : ext_o;
-    xm = part ? a_o : a_f;
-    o.ch_i = part ? a_f : a_o;
-    ch_lo = part ? b_f : b_o;
+    float unused;
+    pair_both(ext_f, w_i, h_i);
+    pair_both(a_f, xm, o.ch_i);
+    pair_both(b_f, unused, ch_lo);
   }
   const float rw_i = rcp_nr(w_i);
   const float delta = h_i * rw_i;

@@ -479,7 +479,7 @@ __device__ __forceinline__ void rq_spline_pair_bwd(float* __restrict__ p, int pl
   const int idx = o.idx;
   const float d_i = o.d_i, d_n = o.d_n;
   // ---- forward
-  const float w = o.cw_n - o.cw_i, h = o.ch_n - o.ch_i;
+  const float w = o.w_i, h = o.h_i;
   const float rw = rcp_f(w);
   const float delta = h * rw;
   const float th = (x - o.cw_i) * rw;
