@@ -92,10 +92,11 @@ def accept_reject_sample(
             if out is None:
                 ev = cand.shape[-1]
                 out = torch.empty((num_samples, num_xos, ev), dtype=cand.dtype, device=cand.device)
-                state = torch.zeros(3 * num_xos, dtype=torch.long, device=cand.device)
-                control = torch.zeros(2 * num_xos, dtype=torch.int32, device=cand.device)
                 words = lib.sbi_amd_accept_compact_scan_words(max(max_sampling_batch_size, sampling_batch_size), num_xos)
-                scan = torch.zeros(int(words), dtype=torch.long, device=cand.device)
+                zeros = torch.zeros(4 * num_xos + int(words), dtype=torch.long, device=cand.device)    # (one fill)
+                state = zeros[: 3 * num_xos]
+                control = zeros[3 * num_xos : 4 * num_xos].view(torch.int32)
+                scan = zeros[4 * num_xos :]
                 generation = 0
                 filled = state[:num_xos]
             mask = None

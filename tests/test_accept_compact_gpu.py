@@ -26,7 +26,8 @@ def _reference(cand, acc, filled, num_samples):
 
 @pytest.mark.parametrize("bs,X,ev,p,box", [(1, 1, 3, 0.5, False), (1000, 1, 10, 0.3, False), (5000, 3, 4, 0.9, False),
                                            (70000, 1, 10, 0.98, True), (20000, 2, 5, 0.05, True), (4097, 1, 1, 1.0, True),
-                                           (4096, 1, 2, 0.0, False)])
+                                           (4096, 1, 2, 0.0, False), (300000, 1, 10, 0.5, False),
+                                           (2500, 1, 32, 0.7, True), (2500, 1, 33, 0.7, True), (100001, 1, 7, 0.31, True)])
 def test_c_abi_matches_a_host_compaction(bs, X, ev, p, box):
     lib = _lib.load()
     g = torch.Generator().manual_seed(bs + X)
@@ -39,7 +40,7 @@ def test_c_abi_matches_a_host_compaction(bs, X, ev, p, box):
     else:
         acc = torch.rand(bs, X, generator=g) < p
     num_samples = max(1, int(0.6 * bs * max(p, 0.01)))
-    filled0 = np.array([0, 3, 1][:X], np.int64)
+    filled0 = np.array([2, 3, 1][:X], np.int64) if bs > 1000 else np.array([0, 3, 1][:X], np.int64)
     want, f_want, n_acc = _reference(cand.numpy(), acc.numpy(), filled0, num_samples)
     d = "cuda"
     out = torch.full((num_samples, X, ev), float("nan"), device=d)
