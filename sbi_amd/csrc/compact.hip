@@ -19,6 +19,56 @@ __device__ __forceinline__ unsigned long long cp_word(unsigned gen, unsigned fla
   return ((unsigned long long)(gen & 0x3fffffffu) << 34) | ((unsigned long long)flag << 32) | val;
 }
 
+// Decoupled look-back by the WHOLE WORKGROUP (every thread calls it): publish this tile's aggregate, then read
+// CP_THREADS predecessors at a time -- thread t the word of tile (i - t) -- until a window holds an inclusive prefix;
+// the nearest one and the aggregates in front of it are the tile's exclusive prefix.  (A single thread walking back one
+// word per L2 round trip made the launch latency-bound: with ~770 tiles resident at once a late tile walked hundreds
+// of words -- 186 us per 10^6 rows however few bytes moved; a wave-wide window still chains ~15 round trips.)
+// Returns the exclusive prefix in every thread.
+__device__ __forceinline__ long long cp_lookback(unsigned long long* __restrict__ st, int tile, unsigned gen,
+                                                 int tile_total) {
+  __shared__ long long s_sum[CP_THREADS / 64];
+  __shared__ int s_hit[CP_THREADS / 64];
+  __shared__ long long s_res;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long excl = 0;
+  if (tile > 0) {
+    if (tid == 0)
+      __hip_atomic_store(&st[tile], cp_word(gen, 1, (unsigned)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tile - 1;; i -= CP_THREADS) {      // (workgroup-uniform loop: the exit test reads shared memory)
+      const int idx = i - tid;
+      unsigned flag = 2, val = 0;               // (before tile 0: an inclusive prefix of nothing)
+      if (idx >= 0) {
+        unsigned long long w;
+        do {
+          w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((w >> 34) == (gen & 0x3fffffffu) && ((w >> 32) & 3u) != 0) break;
+          __builtin_amdgcn_s_sleep(1);
+        } while (true);
+        flag = (unsigned)(w >> 32) & 3u;
+        val = (unsigned)(w & 0xffffffffu);
+      }
+      const unsigned long long incl = __ballot(flag == 2);
+      const int first = incl ? (int)__builtin_ctzll(incl) : 64;      // nearest inclusive prefix of this wave's window
+      long long v = lane <= first ? (long long)val : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) { s_sum[wave] = v; s_hit[wave] = incl ? 1 : 0; }
+      __syncthreads();
+      bool hit = false;
+#pragma unroll
+      for (int w = 0; w < CP_THREADS / 64; ++w)
+        if (!hit) { excl += s_sum[w]; hit = s_hit[w] != 0; }
+      __syncthreads();
+      if (hit) break;
+    }
+  }
+  if (tid == 0)
+    __hip_atomic_store(&st[tile], cp_word(gen, 2, (unsigned)(excl + tile_total)), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
 // state (int64, per condition x): [0, X) filled, [X, 2X) total accepted so far, [2X, 3X) accepted by this call
 // ctl (int32, per condition): [0, X) tile tickets, [X, 2X) finished tiles -- both left at 0 by the last workgroup
 __global__ void __launch_bounds__(CP_THREADS)
@@ -71,24 +121,9 @@ accept_compact_kernel(const float* __restrict__ cand, const unsigned char* __res
   const int thread_excl = wave_base + incl - cnt;
   // ---- decoupled look-back over the tiles of this condition
   unsigned long long* st = scan + (long long)xo * ntiles;
-  if (tid == 0) {
-    long long excl = 0;
-    if (tile > 0) {
-      __hip_atomic_store(&st[tile], cp_word(gen, 1, (unsigned)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int i = tile - 1; i >= 0; --i) {
-        unsigned long long w;
-        do {
-          w = __hip_atomic_load(&st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((w >> 34) == (gen & 0x3fffffffu) && ((w >> 32) & 3u) != 0) break;
-          __builtin_amdgcn_s_sleep(1);
-        } while (true);
-        excl += (long long)(w & 0xffffffffu);
-        if (((w >> 32) & 3u) == 2) break;          // an inclusive prefix: everything before it is in
-      }
-    }
-    __hip_atomic_store(&st[tile], cp_word(gen, 2, (unsigned)(excl + tile_total)), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    s_excl = excl;
+  {
+    const long long excl = cp_lookback(st, tile, gen, tile_total);
+    if (tid == 0) s_excl = excl;
   }
   __syncthreads();
   // ---- scatter (stable), dropping rows past the request
@@ -107,7 +142,10 @@ accept_compact_kernel(const float* __restrict__ cand, const unsigned char* __res
   // ---- the last workgroup of this condition folds the totals in (everybody has read state[xo] by then)
   __syncthreads();
   if (tid == 0) {
-    const int done = __hip_atomic_fetch_add(&ctl[num_xos + xo], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // (relaxed: an agent-scope release would write this workgroup's 40 KB of output back from L2 before the counter moves,
+    //  one workgroup after the other.  What the last workgroup needs is only that every other one has READ state[xo] --
+    //  each has consumed the value in its scatter above -- and the prefix word it reads is itself an agent-scope atomic.)
+    const int done = __hip_atomic_fetch_add(&ctl[num_xos + xo], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == ntiles - 1) {
       const unsigned long long w = __hip_atomic_load(&st[ntiles - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long total = (long long)(w & 0xffffffffu);
@@ -193,24 +231,9 @@ accept_compact_rows_kernel(const float* __restrict__ cand, const unsigned char* 
   for (int u = 0; u < CP_RPT; ++u)
     if (acc[u]) src[base[u] + below[u]] = u * CP_THREADS + tid;
   // ---- decoupled look-back (as above)
-  if (tid == 0) {
-    long long excl = 0;
-    if (tile > 0) {
-      __hip_atomic_store(&scan[tile], cp_word(gen, 1, (unsigned)tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int i = tile - 1; i >= 0; --i) {
-        unsigned long long w;
-        do {
-          w = __hip_atomic_load(&scan[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((w >> 34) == (gen & 0x3fffffffu) && ((w >> 32) & 3u) != 0) break;
-          __builtin_amdgcn_s_sleep(1);
-        } while (true);
-        excl += (long long)(w & 0xffffffffu);
-        if (((w >> 32) & 3u) == 2) break;
-      }
-    }
-    __hip_atomic_store(&scan[tile], cp_word(gen, 2, (unsigned)(excl + tile_total)), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    s_excl = excl;
+  {
+    const long long excl = cp_lookback(scan, tile, gen, tile_total);
+    if (tid == 0) s_excl = excl;
   }
   __syncthreads();
   // ---- write the tile's accepted rows as one span, dropping rows past the request
@@ -229,7 +252,7 @@ accept_compact_rows_kernel(const float* __restrict__ cand, const unsigned char* 
   // ---- the last workgroup folds the totals in
   __syncthreads();
   if (tid == 0) {
-    const int done = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const int done = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (as above)
     if (done == ntiles - 1) {
       const unsigned long long w = __hip_atomic_load(&scan[ntiles - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long total = (long long)(w & 0xffffffffu);
