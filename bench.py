@@ -11,6 +11,9 @@ Contract (task statement): `python bench.py --gpus N --steps K --warmup W` print
   one batch: device-side gather of the batch from the resident simulations in a fresh pseudo-random order (the
   role of SubsetRandomSampler; one launch, sbi_amd/utils/shuffle.py) -> weight re-pack -> fused loss forward + backward -> [ONE all-reduce of the flat
   98 025-float gradient over RCCL] -> fused global-norm clip + Adam.  Inputs are resident in HBM.
+* Timing of every leg: [~150 ms of UNTIMED steps of the same leg, `preheat()`: a device that was idle runs its first
+  ~40 ms slower, and with W = 5, K = 20 the timed region would measure that ramp] -> W warm-up steps -> barrier +
+  synchronize -> EXACTLY K timed steps -> barrier + synchronize; max over ranks.  The JSON names the preheat.
 * `--scaling weak` (default): 65 536 pairs per GPU per step.  `--scaling strong`: 65 536 pairs per step split N
   ways.  At N > 1 the weak line also carries the strong number as a nested object.
 
@@ -229,17 +232,51 @@ def fmpe_cpu_baseline(fm, theta, x, budget_s=10.0):
 LAST_TIMED: dict = {}     # host-side enqueue statistics of the most recent timed() call
 
 
-def timed(step, steps, warmup, device, dist=None):
-    """W warm-up + K timed steps bracketed by barrier + synchronize; returns (wall s [max over ranks], device ms)."""
-    for _ in range(warmup):
+PREHEAT_MS = float(os.environ.get("SBI_AMD_BENCH_PREHEAT_MS", "150"))
+
+
+def preheat(step, device, dist=None) -> int:
+    """Untimed: keep the device busy with the leg's own step for ~PREHEAT_MS before the W warm-up steps.  After >= 10 ms
+    of idleness the device runs its next ~20 ms of work up to 15 % slower (clock ramp; measured per step by
+    tools/diag/clock_ramp.py, `profiles/r6m_clock_ramp.txt`: 65 536-row step 0.835 / 0.80 / 0.76 ms over steps 0-4 /
+    5-9 / 10-19 after a 10 ... 500 ms pause, 0.722 ms from step ~20 on; no effect after a 2 ms pause).  With the
+    driver's W = 5, K = 20 -- and a 50 ms `gc.collect()` between warm-up and timed steps, as this file had it until
+    round 6 -- the timed region sat entirely inside that ramp: the "slow box" of earlier profile sets.  The number of
+    steps comes from a 3-step probe, max over ranks, so every rank of a data-parallel run does the same count (each
+    step holds a collective).  SBI_AMD_BENCH_PREHEAT_MS=0 switches it off."""
+    if PREHEAT_MS <= 0:
+        return 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
         step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    if dist is not None:
+        t = torch.tensor([ms], dtype=torch.float64, device=device if "nccl" in str(dist.get_backend()).lower() else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    n = int(min(1000, max(0, -(-PREHEAT_MS // max(ms, 1e-3)) - 3)))
+    for _ in range(n):
+        step()
+    return n + 3
+
+
+def timed(step, steps, warmup, device, dist=None):
+    """[untimed preheat, see above] + W warm-up + K timed steps bracketed by barrier + synchronize; returns
+    (wall s [max over ranks], device ms)."""
     # The cyclic garbage collector stays out of the timed region (as `timeit` does): a generation-2 pass over the
     # objects earlier legs left behind is tens of milliseconds of HOST time that would be charged to K device steps
-    # (SBI_AMD_BENCH_KEEP_GC=1 keeps it on, for A/B).
+    # (SBI_AMD_BENCH_KEEP_GC=1 keeps it on, for A/B).  It runs BEFORE the warm-up: nothing that idles the device for
+    # milliseconds may sit between the last warm-up step and the first timed one (see preheat()).
     gc_on = gc.isenabled()
     if os.environ.get("SBI_AMD_BENCH_KEEP_GC") != "1":
         gc.collect()
         gc.disable()
+    n_pre = preheat(step, device, dist)
+    for _ in range(warmup):
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -261,7 +298,7 @@ def timed(step, steps, warmup, device, dist=None):
     if gc_on:
         gc.enable()
     LAST_TIMED.clear()
-    LAST_TIMED.update(host_enqueue_ms_max=max(host) * 1e3, host_enqueue_ms_argmax=host.index(max(host)),
+    LAST_TIMED.update(preheat_steps=n_pre, host_enqueue_ms_max=max(host) * 1e3, host_enqueue_ms_argmax=host.index(max(host)),
                       host_enqueue_ms_median=sorted(host)[len(host) // 2] * 1e3)
     dev_ms = ev0.elapsed_time(ev1)     # HIP events on the stream the kernels are launched on
     t = torch.tensor([wall], dtype=torch.float64, device=device if dist is None or "nccl" in str(dist.get_backend()).lower() else "cpu")
@@ -905,6 +942,9 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # untimed steps of the same leg run BEFORE the W warm-up steps so that the K timed steps do not sit in the
+            # first ~40 ms of a device that was idle (see preheat()); every leg's timed() does the same
+            "preheat": {"target_ms": PREHEAT_MS, "untimed_steps_before_warmup": r.get("host", {}).get("preheat_steps")},
             "config": {"workload": f"BASELINE configs[1]: NPE + NSF theta-dim {D}, x-dim {C}, {N_SIMS} simulations "
                                    f"(90 000-row training split resident in HBM), batch {args.batch} {per}, synthetic "
                                    f"linear-Gaussian; step = shuffled batch gather (device sampler) + fused NPE training "
