@@ -14,7 +14,9 @@ run() { timeout -k 5 "$@" < /dev/null; }
 run 400 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-rccl-leg > $out/trace.log 2>&1
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
-# 2. counters of the training kernels: one group per pass, no trace domains
+# 2. counters of the training kernels: one group per pass, no trace domains.  Counter passes COUNT, they do not time:
+#    bench.py's untimed preheat steps are switched off so that launches per run = warm-up + timed steps
+export SBI_AMD_BENCH_PREHEAT_MS=0
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES" \
@@ -43,6 +45,7 @@ for mode in log_prob train fmpe; do
   specs="$specs $mode=$out/hbm_${mode}_FETCH_SIZE,$out/hbm_${mode}_WRITE_SIZE"
 done
 python $R/tools/pmc_traffic.py $out/traffic.json $commit 4 $specs
+unset SBI_AMD_BENCH_PREHEAT_MS
 # 4. small batches: per-step times of both kernel families and per-kernel traces of the cooperative path
 run 200 python $R/tools/diag/coop_crossover.py > $out/small_batch.txt 2>&1
 for B in 200 8192; do
