@@ -944,7 +944,7 @@ def main(argv=None):
             "dtype": "f32", "data": "synthetic",
             # untimed steps of the same leg run BEFORE the W warm-up steps so that the K timed steps do not sit in the
             # first ~40 ms of a device that was idle (see preheat()); every leg's timed() does the same
-            "preheat": {"target_ms": PREHEAT_MS, "untimed_steps_before_warmup": r.get("host", {}).get("preheat_steps")},
+            "preheat": {"target_ms": PREHEAT_MS, "untimed_steps_before_warmup": r.get("host", {}).get("preheat_steps", LAST_TIMED.get("preheat_steps"))},
             "config": {"workload": f"BASELINE configs[1]: NPE + NSF theta-dim {D}, x-dim {C}, {N_SIMS} simulations "
                                    f"(90 000-row training split resident in HBM), batch {args.batch} {per}, synthetic "
                                    f"linear-Gaussian; step = shuffled batch gather (device sampler) + fused NPE training "

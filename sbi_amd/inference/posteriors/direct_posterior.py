@@ -63,8 +63,13 @@ class DirectPosterior:
     def _x_else_default_x(self, x: Optional[Tensor]) -> Tensor:
         if x is not None:
             x = torch.as_tensor(x, dtype=torch.float32)
-            if self._check_finite_x and not torch.isfinite(x).all():
-                raise ValueError("x_o contains NaN or Inf values.")
+            # the finiteness check reads the tensor back (a device round trip in front of every call): the same tensor
+            # object at the same version was checked before and has not been written since
+            seen = self.__dict__.get("_finite_x_seen")
+            if self._check_finite_x and not (seen is not None and seen[0] is x and seen[1] == x._version):
+                if not torch.isfinite(x).all():
+                    raise ValueError("x_o contains NaN or Inf values.")
+                self._finite_x_seen = (x, x._version)
             return x.to(self._device)
         if self._x is None:
             raise ValueError(
@@ -115,14 +120,17 @@ class DirectPosterior:
             if getattr(sup, "base_constraint", sup) is constraints.real and getattr(sup, "reinterpreted_batch_ndims", 1) == 1:
                 d_ev = int(est.input_shape[-1]) if len(getattr(est, "input_shape", ())) == 1 else None
                 if d_ev is not None:
-                    dev_ = x.device
-                    inside_prior.box_bounds = (torch.full((d_ev,), float("-inf"), device=dev_),
-                                               torch.full((d_ev,), float("inf"), device=dev_))
+                    cached = self.__dict__.get("_real_box")
+                    if cached is None or cached[0].numel() != d_ev or cached[0].device != x.device:
+                        cached = self._real_box = (torch.full((d_ev,), float("-inf"), device=x.device),
+                                                   torch.full((d_ev,), float("inf"), device=x.device))
+                    inside_prior.box_bounds = cached
         kept, _acceptance = rejection.accept_reject_sample(
             est.sample, inside_prior, how_many,
             show_progress_bars=show_progress_bars, max_sampling_batch_size=batch_cap,
             proposal_sampling_kwargs=dict(condition=x), alternative_method="build_posterior(..., sample_with='mcmc')",
-            max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout)
+            max_sampling_time=max_sampling_time, return_partial_on_timeout=return_partial_on_timeout,
+            acceptance_on_device=False)       # (not used here: spares the host-to-device copy of one float per call)
         return kept
 
     def sample(self, sample_shape=torch.Size(), x: Optional[Tensor] = None, max_sampling_batch_size: int = 10_000,

@@ -40,8 +40,11 @@ def accept_reject_sample(
     alternative_method: Optional[str] = None,
     max_sampling_time: Optional[float] = None,
     return_partial_on_timeout: bool = False,
+    acceptance_on_device: bool = True,
     **kwargs,
 ) -> Tuple[Tensor, Tensor]:
+    """(sbi/samplers/rejection/rejection.py:230-457; `acceptance_on_device=False` leaves the returned acceptance rate on
+    the host, where it is computed: callers that ignore it save a copy.)"""
     if kwargs:
         logging.warning(
             "You passed arguments to `rejection_sampling_parameters` that are unused when you do not "
@@ -169,7 +172,7 @@ def accept_reject_sample(
 
     assert out is not None
     samples = out.reshape(num_samples, *candidates.shape[1:])
-    return samples, acceptance_rate.to(samples.device)
+    return samples, acceptance_rate.to(samples.device) if acceptance_on_device else acceptance_rate
 
 
 def rejection_sample(

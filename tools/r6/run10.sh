@@ -1,11 +1,9 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/${1:-r6k}; mkdir -p $out; cd $R
-timeout 600 python -m pytest tests/test_accept_compact_gpu.py tests/test_rejection_posterior_gpu.py tests/test_npe_gpu.py -x -q -m gpu 2>&1 | tail -5 | tee $out/pytest.log
-cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/st; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python $R/tools/diag/sample_timing.py > /tmp/st.log 2>&1; cat /tmp/st.log | grep -v "WARN\|amdgpu" | tee $out/sample_timing.txt
-f=$(ls /tmp/st/*/*kernel_stats.csv | head -1)
-python - $f <<'PY' | tee -a $out/sample_timing.txt
-import csv, sys
-for r in csv.DictReader(open(sys.argv[1])):
-    if 'compact' in r['Name'] or 'nsf_flow' in r['Name']: print('   ', r['Name'][:60], r['Calls'], round(float(r['AverageNs'])/1e3,1), 'us')
+timeout 900 python -m pytest tests/test_accept_compact_gpu.py tests/test_rejection_posterior_gpu.py tests/test_npe_gpu.py tests/test_density_estimator_contract_gpu.py tests/test_npe_multiround_gpu.py -x -q -m gpu 2>&1 | tail -3 | tee $out/pytest.log
+timeout 300 python bench.py --mode sample --no-cpu-baseline 2>/dev/null | tail -1 > $out/sample_bench.json
+python - $out/sample_bench.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); p=d.get("posterior_sample", d)
+print("10^6 draws", p["ms_per_step"], "box1", p["acceptance_below_one"]["box_uniform_1"]["ms_per_step"], "box0.5", p["acceptance_below_one"]["box_uniform_0.5"]["ms_per_step"])
 PY
