@@ -282,13 +282,12 @@ extern "C" int sbi_amd_accept_compact(const float* candidates, const uint8_t* ac
   const int ntiles = (int)((batch_rows + CP_TILE - 1) / CP_TILE);
   if (num_xos == 1 && event_floats <= CP_EV_MAX && ((uintptr_t)candidates & 15) == 0) {
     const size_t lds = ((size_t)CP_TILE * event_floats + CP_TILE) * sizeof(float);
-    static bool attr_set = false;        // (more than 64 KiB of dynamic LDS has to be asked for once)
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)accept_compact_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(((size_t)CP_TILE * CP_EV_MAX + CP_TILE) * sizeof(float))) != hipSuccess)
-        return SBI_AMD_E_UNSUPPORTED;
-      attr_set = true;
-    }
+    // (more than 64 KiB of dynamic LDS has to be asked for once: a function-local static is initialised exactly once,
+    //  whichever thread gets there first)
+    static const hipError_t attr_rc =
+        hipFuncSetAttribute((const void*)accept_compact_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(((size_t)CP_TILE * CP_EV_MAX + CP_TILE) * sizeof(float)));
+    if (attr_rc != hipSuccess) return SBI_AMD_E_UNSUPPORTED;
     hipLaunchKernelGGL(accept_compact_rows_kernel, dim3(ntiles), dim3(CP_THREADS), lds, (hipStream_t)stream, candidates,
                        accepted, box_low, box_high, (long long)batch_rows, event_floats, out, (long long)num_samples,
                        (long long*)state, control, (unsigned long long*)scan, ntiles, generation);
